@@ -1,0 +1,41 @@
+"""Pins oracle/mtets_oracle.py to the golden vectors minted from the real reference."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fields, mtets_oracle
+from tests.helpers import golden_inputs
+
+FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mtets_*.npz")))
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p)[6:-4] for p in FILES])
+def test_oracle_matches_reference_golden(path):
+    g = np.load(path)
+    verts, tets, sdf, msdf = golden_inputs(g)
+    pos = torch.tensor(verts, requires_grad=True)
+    s = torch.tensor(sdf, requires_grad=True)
+    m = torch.tensor(msdf, requires_grad=True)
+    out = mtets_oracle.extract(pos, s, m, torch.tensor(tets))
+    # topology: bit exact
+    assert out["n_verts_watertight"] == int(g["n_verts_watertight"])
+    np.testing.assert_array_equal(out["faces_watertight"].numpy(), g["faces_watertight"])
+    np.testing.assert_array_equal(out["faces_aug"].numpy(), g["faces_aug"])
+    # float outputs: same IEEE ops in the same order -> identical on CPU
+    for k in ("verts_aug", "vertices_watertight", "msdf", "msdf_watertight", "msdf_boundary"):
+        np.testing.assert_array_equal(out[k].detach().numpy(), g[k], err_msg=k)
+    for k in ("v_tng_aug", "v_tng_watertight"):
+        np.testing.assert_allclose(out[k].detach().numpy(), g[k], rtol=0, atol=2e-5, err_msg=k)
+    wv, wm, ww = fields.loss_weights(out["verts_aug"].shape[0], out["n_verts_watertight"], int(g["seed"]))
+    loss = (out["verts_aug"] * torch.tensor(wv)).sum() + (out["msdf"] * torch.tensor(wm)).sum() \
+        + (out["vertices_watertight"] * torch.tensor(ww)).sum()
+    if loss.requires_grad:
+        loss.backward()
+        for name, t in (("grad_pos", pos), ("grad_sdf", s), ("grad_msdf", m)):
+            ref = g[name]
+            got = t.grad.numpy() if t.grad is not None else np.zeros_like(ref)
+            scale = max(1.0, float(np.abs(ref).max()))
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * scale, err_msg=name)
