@@ -1,0 +1,74 @@
+"""ctypes binding of libgshell_hip.so (the C ABI declared in include/gshell_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load this
+module raises, loudly.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C gshell_amd/csrc -j`.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgshell_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gshell_hip.h")
+
+_lib = None
+
+c_void_p, c_int64, c_int, c_float = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+
+
+class GShellHipError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """All `int gs_*(` / `const char* gs_*(` entry points declared in the public header."""
+    with open(HEADER_PATH) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", src)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise GShellHipError(
+                f"{LIB_PATH} not found: the gfx950 HIP library is not built. "
+                "Run `make -C gshell_amd/csrc -j` (or __graft_entry__.build()). There is no CPU fallback.")
+        try:
+            _lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise GShellHipError(f"failed to load {LIB_PATH}: {e}") from e
+        _lib.gs_last_error.restype = ctypes.c_char_p
+        for name in declared_symbols():
+            fn = getattr(_lib, name)          # AttributeError if the .so lacks a declared symbol
+            if name != "gs_last_error":
+                fn.restype = c_int
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().gs_last_error().decode("utf-8", "replace")
+        raise GShellHipError(f"{what}: {msg}" if what else msg)
+
+
+def ptr(t, dtype=None, name="tensor"):
+    """Device pointer of a contiguous CUDA(HIP) tensor (None -> NULL). Mirrors the
+    reference's CHECK_TENSOR guards (render/renderutils/c_src/torch_bindings.cpp:27-31)."""
+    if t is None:
+        return c_void_p(0)
+    if not t.is_cuda:
+        raise GShellHipError(f"{name} must live in HBM (got device {t.device}); the HIP path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise GShellHipError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise GShellHipError(f"{name} must be contiguous")
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

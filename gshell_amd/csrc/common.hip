@@ -1,0 +1,17 @@
+#include "common.hpp"
+#include "../../include/gshell_hip.h"
+
+namespace gs {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+}  // namespace gs
+
+extern "C" const char* gs_last_error(void) { return gs::g_err.c_str(); }
+extern "C" int gs_version(void) { return 100; }
+
+extern "C" int gs_memcpy_d2d(void* dst, const void* src, int64_t bytes, gs_stream_t stream) {
+    if (bytes <= 0) return 0;
+    GS_REQUIRE(dst && src, "gs_memcpy_d2d: null pointer");
+    GS_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}

@@ -1,0 +1,689 @@
+// G-MarchingTets on gfx950: SDF + mSDF on a tet grid -> open triangle mesh, fwd + bwd.
+//
+// Replaces geometry/gshell_tets.py:245-443 (GShell_Tets.__call__) of the reference.  The
+// reference runs ~100 small torch ops with a device-wide lexsort (`torch.unique(dim=0)`, :268),
+// a dozen boolean-mask compactions (each a host sync) and a host-side mask (:419-423).
+// Here the whole extraction is 7 launches and exactly one stream sync:
+//
+//   count phase   k_occ_bits   sdf sign -> 1 bit / grid vertex (wave ballot)          [N]
+//                 k_edge_cross crossing bit per static sorted edge (wave ballot)      [E]
+//                 k_classify   tet sign pattern + mSDF cut case -> 1 byte / tet,
+//                              per-block category counts (ballot + popcount)          [F]
+//                 k_scan       exclusive scans of the per-block counts (1 block)
+//   -- one D2H copy of 11 counters; the caller allocates exact-size outputs --
+//   fill phase    k_vertices   rank crossing edges (prefix popcount) + interpolate    [E/64]
+//                 k_faces      ordered compaction of tets into the reference's face
+//                              order + boundary vertices + mSDF cut                   [F] (1 B/tet)
+//                 k_mask_wt    zero unreferenced watertight vertices                  [V]
+//
+// Mesh vertex ids are ranks of crossing edges in the static lexicographically sorted
+// edge list, which is bit-identical to the reference's sort-based numbering.
+// All float expressions keep the reference's operation order and this file is compiled
+// with -ffp-contract=off, so the forward outputs are bit-identical to the torch CPU
+// reference as well (tests compare with rtol 0 against the oracle).
+#include "../../include/gshell_hip.h"
+#include "mtets_internal.hpp"
+
+namespace {
+
+// ---- case tables (reference gshell_tets.py:82-181), polygon-relative form -------------
+__constant__ int8_t c_ntri[16] = {0, 1, 1, 2, 1, 2, 2, 1, 1, 2, 2, 1, 2, 1, 1, 0};
+// polygon loop of crossing edges per sign pattern, as local tet-edge ids (ref :101-118)
+__constant__ int8_t c_poly[16][4] = {{0, 0, 0, 0}, {1, 0, 2, 0}, {4, 0, 3, 0}, {1, 3, 4, 2}, {3, 1, 5, 0}, {2, 5, 3, 0},
+                                     {1, 5, 4, 0}, {4, 2, 5, 0}, {4, 5, 2, 0}, {4, 5, 1, 0}, {3, 5, 2, 0}, {1, 3, 5, 0},
+                                     {4, 3, 1, 2}, {3, 0, 4, 0}, {2, 0, 1, 0}, {0, 0, 0, 0}};
+// watertight triangles (ref :82-99) re-expressed as indices into the polygon loop:
+// triangles -> (0,1,2); quads -> (0,2,3),(0,1,2)
+__constant__ int8_t c_tri_poly[2][6] = {{0, 1, 2, 0, 0, 0}, {0, 2, 3, 0, 1, 2}};
+// mSDF cut of a triangle / quad (ref :121-175): ids < n are polygon corners, ids >= n are
+// the boundary points on loop edges (c_k, c_k+1)
+__constant__ int8_t c_cut_tri[8][6] = {{0, 0, 0, 0, 0, 0}, {4, 2, 5, 0, 0, 0}, {3, 1, 4, 0, 0, 0}, {3, 1, 2, 3, 2, 5},
+                                       {0, 3, 5, 0, 0, 0}, {0, 3, 4, 0, 4, 2}, {0, 1, 4, 0, 4, 5}, {0, 1, 2, 0, 0, 0}};
+__constant__ int8_t c_ncut_tri[8] = {0, 1, 1, 2, 1, 2, 2, 1};
+__constant__ uint8_t c_used_tri[8] = {0, 52, 26, 46, 41, 29, 51, 7};
+__constant__ int8_t c_cut_quad[16][12] = {
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {6, 3, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {5, 2, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {5, 2, 7, 3, 7, 2, 0, 0, 0, 0, 0, 0}, {4, 1, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {4, 1, 5, 4, 5, 7, 5, 6, 7, 7, 6, 3},
+    {4, 1, 2, 6, 4, 2, 0, 0, 0, 0, 0, 0}, {4, 1, 2, 7, 4, 2, 7, 2, 3, 0, 0, 0}, {0, 4, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 4, 6, 3, 0, 6, 0, 0, 0, 0, 0, 0}, {0, 4, 5, 0, 5, 2, 0, 2, 6, 0, 6, 7}, {0, 4, 5, 0, 5, 2, 0, 2, 3, 0, 0, 0},
+    {0, 1, 5, 7, 0, 5, 0, 0, 0, 0, 0, 0}, {0, 1, 5, 0, 5, 6, 0, 6, 3, 0, 0, 0}, {0, 1, 2, 0, 2, 6, 0, 6, 7, 0, 0, 0},
+    {0, 1, 2, 0, 2, 3, 0, 0, 0, 0, 0, 0}};
+__constant__ int8_t c_ncut_quad[16] = {0, 1, 1, 2, 1, 4, 2, 3, 1, 2, 4, 3, 2, 3, 3, 2};
+__constant__ uint8_t c_used_quad[16] = {0, 200, 100, 172, 50, 250, 86, 158, 145, 89, 245, 61, 163, 107, 199, 15};
+// local tet edge k joins corners (ca,cb)   (ref :178)
+__constant__ int8_t c_edge_ca[6] = {0, 0, 0, 1, 1, 2};
+__constant__ int8_t c_edge_cb[6] = {1, 2, 3, 2, 3, 3};
+
+__device__ __forceinline__ int occ_bit(const uint64_t* __restrict__ bits, int i) {
+    return (int)((bits[i >> 6] >> (i & 63)) & 1ull);
+}
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+
+// Zero crossing of a linear function with end values xa (at a) and xb (at b): weights of a, b.
+// Same op order as ref :278-285 (negate, add, sign*(abs+eps), ==0 fix-up, two divisions).
+__device__ __forceinline__ void sdf_weights(float xa, float xb, float& wa, float& wb) {
+    float x1 = xb * -1.0f;
+    float d = xa + x1;
+    float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+    float den = sg * (fabsf(d) + 1e-12f);
+    if (den == 0.0f) den = 1e-12f;
+    wa = x1 / den;
+    wb = xa / den;
+}
+__device__ __forceinline__ float sgn(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+// Boundary point on a polygon edge from the end values of the (interpolated) mSDF (ref :346-365).
+__device__ __forceinline__ bool msdf_weights(float ma, float mb, float& wa, float& wb) {
+    float x1 = mb * -1.0f;
+    float den = ma + x1;
+    bool nz = (fabsf(sgn(ma) + sgn(mb)) != 2.0f) && (fabsf(den) > 1e-12f);
+    wa = nz ? x1 / den : 0.0f;
+    wb = nz ? ma / den : 0.0f;
+    return nz;
+}
+
+__device__ __forceinline__ int sel4(int a, int b, int c, int d, int k) { return k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d)); }
+
+// ------------------------------------------------------------------------------------
+// count phase
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_occ_bits(const float* __restrict__ sdf, int64_t N, uint64_t* __restrict__ bits) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool o = (i < N) && (sdf[i] > 0.0f);  // strict: sdf == 0 is outside (ref :250)
+    uint64_t m = __ballot(o);
+    if ((threadIdx.x & 63) == 0 && i < N) bits[i >> 6] = m;
+}
+
+// One wave per 64-edge chunk: crossing bit = occ[a] != occ[b]  (ref :271)
+__global__ void __launch_bounds__(256) k_edge_cross(const int2* __restrict__ edges, int64_t E, int64_t nchunks,
+                                                    const uint64_t* __restrict__ occ, uint64_t* __restrict__ mask,
+                                                    int32_t* __restrict__ blk_cnt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * MT_CHUNKS_PER_BLOCK + wave * 64;
+    int cnt = 0;
+#pragma unroll 4
+    for (int j = 0; j < 64; ++j) {
+        int64_t c = c0 + j;
+        int64_t e = c * 64 + lane;
+        bool x = false;
+        if (e < E) {
+            int2 ab = edges[e];
+            x = occ_bit(occ, ab.x) != occ_bit(occ, ab.y);
+        }
+        uint64_t m = __ballot(x);
+        if (lane == 0 && c < nchunks) mask[c] = m;
+        cnt += __popcll(m);
+    }
+    __shared__ int s[4];
+    if (lane == 0) s[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+// categories of a tet code byte: 0:n1 1:n2 2:tri->1 3:tri->2 4..7:quad->1..4
+__device__ __forceinline__ void code_cats(uint8_t cb, int& ntri, int& ci, int& ncut) {
+    ntri = c_ntri[cb & 15];
+    ci = cb >> 4;
+    ncut = ntri == 1 ? c_ncut_tri[ci & 7] : (ntri == 2 ? c_ncut_quad[ci] : 0);
+}
+
+__global__ void __launch_bounds__(256) k_classify(const int4* __restrict__ tets, int64_t F, const uint64_t* __restrict__ occ,
+                                                  const float* __restrict__ sdf, const float* __restrict__ msdf,
+                                                  uint8_t* __restrict__ code_out, int32_t* __restrict__ blk_cnt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int cnt[MT_NCAT];
+#pragma unroll
+    for (int k = 0; k < MT_NCAT; ++k) cnt[k] = 0;
+    for (int tile = 0; tile < MT_TILES; ++tile) {
+        int64_t f = ((int64_t)blockIdx.x * MT_TILES + tile) * MT_BLOCK + threadIdx.x;
+        int ntri = 0, ci = 0, ncut = 0;
+        if (f < F) {
+            int4 t = tets[f];
+            int code = occ_bit(occ, t.x) | (occ_bit(occ, t.y) << 1) | (occ_bit(occ, t.z) << 2) | (occ_bit(occ, t.w) << 3);  // ref :296-297
+            ntri = c_ntri[code];
+            if (ntri) {
+                // mSDF sign at each polygon corner (= crossing edge), ref :289, :330-331
+                const int n = 2 + ntri;
+                for (int k = 0; k < n; ++k) {
+                    int le = c_poly[code][k];
+                    int gi = sel4(t.x, t.y, t.z, t.w, c_edge_ca[le]);
+                    int gj = sel4(t.x, t.y, t.z, t.w, c_edge_cb[le]);
+                    int a = min(gi, gj), b = max(gi, gj);
+                    float wa, wb;
+                    sdf_weights(sdf[a], sdf[b], wa, wb);
+                    float mv = msdf[a] * wa + msdf[b] * wb;
+                    ci = (ci << 1) | (mv > 0.0f ? 1 : 0);  // ref :396-399 (first corner = MSB)
+                }
+                ncut = ntri == 1 ? c_ncut_tri[ci] : c_ncut_quad[ci];
+            }
+            code_out[f] = (uint8_t)(code | (ci << 4));
+        }
+        if (__ballot(ntri != 0) == 0ull) continue;
+        cnt[0] += __popcll(__ballot(ntri == 1));
+        cnt[1] += __popcll(__ballot(ntri == 2));
+        cnt[2] += __popcll(__ballot(ntri == 1 && ncut == 1));
+        cnt[3] += __popcll(__ballot(ntri == 1 && ncut == 2));
+        cnt[4] += __popcll(__ballot(ntri == 2 && ncut == 1));
+        cnt[5] += __popcll(__ballot(ntri == 2 && ncut == 2));
+        cnt[6] += __popcll(__ballot(ntri == 2 && ncut == 3));
+        cnt[7] += __popcll(__ballot(ntri == 2 && ncut == 4));
+    }
+    __shared__ int s[4][MT_NCAT];
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < MT_NCAT; ++k) s[wave][k] = cnt[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < MT_NCAT)
+        blk_cnt[(int64_t)blockIdx.x * MT_NCAT + threadIdx.x] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+}
+
+// Exclusive scan of a strided int sequence by one 1024-thread block (in place); returns total.
+__device__ int scan_sequence_1024(int32_t* seq, int64_t n, int stride, int* lds) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t lo = min((int64_t)tid * per, n), hi = min(lo + per, n);
+    int local = 0;
+    for (int64_t i = lo; i < hi; ++i) local += seq[i * stride];
+    int x = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) lds[w] = x;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int sv = lds[i];
+        if (i < w) woff += sv;
+        tot += sv;
+    }
+    int run = woff + x - local;
+    for (int64_t i = lo; i < hi; ++i) {
+        int v = seq[i * stride];
+        seq[i * stride] = run;
+        run += v;
+    }
+    return tot;
+}
+
+__global__ void __launch_bounds__(1024) k_scan(int32_t* tet_blk, int64_t nb_t, int32_t* edge_blk, int64_t nb_e, int64_t* counts) {
+    __shared__ int lds[16];
+    int c[MT_NCAT];
+    int V = scan_sequence_1024(edge_blk, nb_e, 1, lds);
+#pragma unroll
+    for (int k = 0; k < MT_NCAT; ++k) c[k] = scan_sequence_1024(tet_blk + k, nb_t, MT_NCAT, lds);
+    if (threadIdx.x == 0) {
+        counts[0] = V;
+        counts[1] = c[0];
+        counts[2] = c[1];
+        for (int k = 0; k < 6; ++k) counts[3 + k] = c[2 + k];
+        counts[9] = (int64_t)c[2] + 2ll * c[3] + c[4] + 2ll * c[5] + 3ll * c[6] + 4ll * c[7];
+        counts[10] = (int64_t)V + 3ll * c[0] + 4ll * c[1];
+        for (int k = 11; k < GS_MTETS_NCOUNTS; ++k) counts[k] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// fill phase
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_vertices(const int2* __restrict__ edges, int64_t nchunks, const uint64_t* __restrict__ mask,
+                                                  const int32_t* __restrict__ edge_blk, int32_t* __restrict__ chunk_base,
+                                                  const float* __restrict__ pos, const float* __restrict__ sdf,
+                                                  const float* __restrict__ msdf, float* __restrict__ verts_wt,
+                                                  float* __restrict__ msdf_aug, int32_t* __restrict__ vert_ab) {
+    __shared__ uint64_t s_mask[MT_CHUNKS_PER_BLOCK];
+    __shared__ int s_base[MT_CHUNKS_PER_BLOCK];
+    __shared__ int s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t c = (int64_t)blockIdx.x * MT_CHUNKS_PER_BLOCK + tid;
+    uint64_t m = c < nchunks ? mask[c] : 0ull;
+    int p = __popcll(m), x = p;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    int woff = edge_blk[blockIdx.x];
+    for (int i = 0; i < wave; ++i) woff += s_w[i];
+    int base = woff + x - p;
+    s_mask[tid] = m;
+    s_base[tid] = base;
+    if (c < nchunks) chunk_base[c] = base;
+    __syncthreads();
+    // each wave walks its 64 chunks; lane = edge within the chunk
+    for (int j = 0; j < 64; ++j) {
+        const int lc = wave * 64 + j;
+        const uint64_t mm = s_mask[lc];
+        if (mm == 0ull) continue;
+        if ((mm >> lane) & 1ull) {
+            const int vid = s_base[lc] + __popcll(mm & lanemask_lt());
+            const int64_t e = ((int64_t)blockIdx.x * MT_CHUNKS_PER_BLOCK + lc) * 64 + lane;
+            const int2 ab = edges[e];
+            float wa, wb;
+            sdf_weights(sdf[ab.x], sdf[ab.y], wa, wb);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) verts_wt[(int64_t)vid * 3 + d] = pos[(int64_t)ab.x * 3 + d] * wa + pos[(int64_t)ab.y * 3 + d] * wb;  // ref :286
+            msdf_aug[vid] = msdf[ab.x] * wa + msdf[ab.y] * wb;  // ref :289-290 (same value with/without stop-grad)
+            vert_ab[2 * (int64_t)vid] = ab.x;
+            vert_ab[2 * (int64_t)vid + 1] = ab.y;
+        }
+    }
+}
+
+struct FillArgs {
+    int64_t F, V, M1, M2;
+    int64_t gbase[6];  // first face row of each mSDF-cut group (ref :409-416 order)
+    const uint8_t* code;
+    const int32_t* tet_blk;
+    const int32_t* tet_edge;
+    const int32_t* chunk_base;
+    const uint64_t* edge_mask;
+    const float* verts_wt;
+    float* verts_aug;
+    float* msdf_aug;
+    int64_t* faces_wt;
+    int64_t* faces_aug;
+    int32_t* faces_aug_i32;
+    uint8_t* used_wt;
+    int32_t* poly;
+    uint8_t* cut_code;
+    int32_t* tet_id;
+};
+
+__global__ void __launch_bounds__(256) k_faces(FillArgs A) {
+    __shared__ int s_tot[2][4][MT_NCAT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int run[MT_NCAT];
+#pragma unroll
+    for (int k = 0; k < MT_NCAT; ++k) run[k] = A.tet_blk[(int64_t)blockIdx.x * MT_NCAT + k];
+    const uint64_t lt = lanemask_lt();
+    for (int tile = 0; tile < MT_TILES; ++tile) {
+        const int64_t f = ((int64_t)blockIdx.x * MT_TILES + tile) * MT_BLOCK + threadIdx.x;
+        const uint8_t cb = f < A.F ? A.code[f] : 0;
+        int ntri, ci, ncut;
+        code_cats(cb, ntri, ci, ncut);
+        if (!__syncthreads_or(ntri != 0)) continue;
+        uint64_t b[MT_NCAT];
+        b[0] = __ballot(ntri == 1);
+        b[1] = __ballot(ntri == 2);
+        b[2] = __ballot(ntri == 1 && ncut == 1);
+        b[3] = __ballot(ntri == 1 && ncut == 2);
+        b[4] = __ballot(ntri == 2 && ncut == 1);
+        b[5] = __ballot(ntri == 2 && ncut == 2);
+        b[6] = __ballot(ntri == 2 && ncut == 3);
+        b[7] = __ballot(ntri == 2 && ncut == 4);
+        const int buf = tile & 1;
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < MT_NCAT; ++k) s_tot[buf][wave][k] = __popcll(b[k]);
+        }
+        __syncthreads();
+        int rank[MT_NCAT];
+#pragma unroll
+        for (int k = 0; k < MT_NCAT; ++k) {
+            int woff = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                int sv = s_tot[buf][w][k];
+                if (w < wave) woff += sv;
+                tot += sv;
+            }
+            rank[k] = run[k] + woff + __popcll(b[k] & lt);
+            run[k] += tot;
+        }
+        if (ntri == 0) continue;
+
+        // ---- this lane owns one surface-crossing tet -----------------------------------
+        const int code = cb & 15;
+        const int n = 2 + ntri;
+        int pc[4] = {0, 0, 0, 0};
+        for (int k = 0; k < n; ++k) {
+            int e = A.tet_edge[f * 6 + c_poly[code][k]];
+            pc[k] = A.chunk_base[e >> 6] + __popcll(A.edge_mask[e >> 6] & ((1ull << (e & 63)) - 1ull));
+        }
+        int64_t slot, bnd, prow;  // polygon slot, first boundary vertex id, first poly[] entry
+        int64_t wt_row;
+        if (ntri == 1) {
+            slot = rank[0];
+            bnd = A.V + 3 * slot;
+            prow = 3 * slot;
+            wt_row = slot;
+        } else {
+            slot = A.M1 + rank[1];
+            bnd = A.V + 3 * A.M1 + 4 * (int64_t)rank[1];
+            prow = 3 * A.M1 + 4 * (int64_t)rank[1];
+            wt_row = A.M1 + 2 * (int64_t)rank[1];
+        }
+        // watertight faces (ref :313-316): 1-triangle tets first, then 2-triangle tets
+        for (int j = 0; j < 3 * ntri; ++j)
+            A.faces_wt[wt_row * 3 + j] = sel4(pc[0], pc[1], pc[2], pc[3], c_tri_poly[ntri - 1][j]);
+        for (int k = 0; k < n; ++k) A.poly[prow + k] = pc[k];
+        A.cut_code[slot] = (uint8_t)ci;
+        A.tet_id[slot] = (int32_t)f;
+
+        // boundary vertices on the polygon loop (ref :335-392); private to this tet
+        const int used = ntri == 1 ? c_used_tri[ci] : c_used_quad[ci];
+        for (int k = 0; k < n; ++k) {
+            const int a = pc[k], bb = pc[(k + 1 == n) ? 0 : k + 1];
+            const float ma = A.msdf_aug[a], mb = A.msdf_aug[bb];
+            float wa, wb;
+            msdf_weights(ma, mb, wa, wb);
+            const bool u = (used >> (n + k)) & 1;  // unreferenced vertices are zeroed (ref :419-423)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float p = A.verts_wt[(int64_t)a * 3 + d] * wa + A.verts_wt[(int64_t)bb * 3 + d] * wb;
+                A.verts_aug[(bnd + k) * 3 + d] = u ? p : 0.0f;
+            }
+            A.msdf_aug[bnd + k] = ma * wa + mb * wb;  // ref :383-384
+        }
+
+        // mSDF cut (ref :395-416): group order tri->1, tri->2, quad->1..4; tet order inside a group
+        if (ncut) {
+            const int g = ntri == 1 ? (ncut - 1) : (1 + ncut);
+            int64_t row = A.gbase[g] + (int64_t)ncut * rank[2 + g];
+            for (int j = 0; j < 3 * ncut; ++j) {
+                const int loc = ntri == 1 ? c_cut_tri[ci][j] : c_cut_quad[ci][j];
+                int64_t idx;
+                if (loc < n) {
+                    idx = sel4(pc[0], pc[1], pc[2], pc[3], loc);
+                    A.used_wt[idx] = 1;
+                } else {
+                    idx = bnd + (loc - n);
+                }
+                A.faces_aug[row * 3 + j] = idx;
+                if (A.faces_aug_i32) A.faces_aug_i32[row * 3 + j] = (int32_t)idx;
+            }
+        }
+    }
+}
+
+__global__ void k_mask_wt(int64_t V, const float* __restrict__ verts_wt, const uint8_t* __restrict__ used, float* __restrict__ verts_aug) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V * 3) return;
+    verts_aug[i] = used[i / 3] ? verts_wt[i] : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------
+// One thread per boundary vertex: d(boundary point)/d(polygon-corner position, mSDF).
+__global__ void k_bwd_boundary(int64_t V, int64_t M1, int64_t M2, const float* __restrict__ verts_wt,
+                               const float* __restrict__ msdf_aug, const int32_t* __restrict__ poly,
+                               const uint8_t* __restrict__ cut_code, const float* __restrict__ g_verts_aug,
+                               const float* __restrict__ g_msdf_aug, float* __restrict__ acc /*[V,5]: gv xyz, g mv, g mv_stopgrad*/) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nb = 3 * M1 + 4 * M2;
+    if (j >= nb) return;
+    int n, k;
+    int64_t slot, p0;
+    if (j < 3 * M1) {
+        n = 3; slot = j / 3; k = (int)(j - slot * 3); p0 = slot * 3;
+    } else {
+        int64_t q = j - 3 * M1;
+        n = 4; slot = q / 4; k = (int)(q - slot * 4); p0 = 3 * M1 + slot * 4; slot += M1;
+    }
+    const int ci = cut_code[slot];
+    const int used = n == 3 ? c_used_tri[ci] : c_used_quad[ci];
+    const int a = poly[p0 + k], b = poly[p0 + ((k + 1 == n) ? 0 : k + 1)];
+    const float ma = msdf_aug[a], mb = msdf_aug[b];
+    float wa, wb;
+    const bool nz = msdf_weights(ma, mb, wa, wb);
+    const bool u = (used >> (n + k)) & 1;
+    float g[3] = {0.f, 0.f, 0.f};
+    if (u && g_verts_aug) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) g[d] = g_verts_aug[(V + j) * 3 + d];
+    }
+    const float gms = g_msdf_aug ? g_msdf_aug[V + j] : 0.0f;
+    float gwa = 0.f, gwb = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float pa = verts_wt[(int64_t)a * 3 + d], pb = verts_wt[(int64_t)b * 3 + d];
+        gwa += g[d] * pa;
+        gwb += g[d] * pb;
+        if (g[d] != 0.f) {
+            atomicAdd(&acc[(int64_t)a * 5 + d], g[d] * wa);
+            atomicAdd(&acc[(int64_t)b * 5 + d], g[d] * wb);
+        }
+    }
+    if (nz && (gwa != 0.f || gwb != 0.f)) {
+        // w_a = x1/den, w_b = x0/den, x0 = m_a, x1 = -m_b, den = x0 + x1
+        const float x0 = ma, x1 = -mb, den = x0 + x1;
+        const float gden = -(gwa * x1 + gwb * x0) / (den * den);
+        const float gx1 = gwa / den + gden, gx0 = gwb / den + gden;
+        atomicAdd(&acc[(int64_t)a * 5 + 3], gx0);
+        atomicAdd(&acc[(int64_t)b * 5 + 3], -gx1);
+    }
+    if (gms != 0.f) {  // stop-gradient mSDF: weights are constants (ref :383-384)
+        atomicAdd(&acc[(int64_t)a * 5 + 4], gms * wa);
+        atomicAdd(&acc[(int64_t)b * 5 + 4], gms * wb);
+    }
+}
+
+// One thread per watertight vertex: push accumulated cotangents to the two grid endpoints.
+__global__ void k_bwd_vertices(int64_t V, const float* __restrict__ pos, const float* __restrict__ sdf,
+                               const float* __restrict__ msdf, const int32_t* __restrict__ vert_ab,
+                               const uint8_t* __restrict__ used_wt, const float* __restrict__ g_verts_aug,
+                               const float* __restrict__ g_msdf_aug, const float* __restrict__ g_verts_wt,
+                               const float* __restrict__ acc, float* __restrict__ g_pos, float* __restrict__ g_sdf,
+                               float* __restrict__ g_msdf) {
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const int a = vert_ab[2 * v], b = vert_ab[2 * v + 1];
+    float gv[3];
+    const bool u = used_wt[v] != 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        gv[d] = acc[v * 5 + d];
+        if (u && g_verts_aug) gv[d] += g_verts_aug[v * 3 + d];
+        if (g_verts_wt) gv[d] += g_verts_wt[v * 3 + d];
+    }
+    const float gm = acc[v * 5 + 3];                                          // d/d msdf_vert (full gradient copy)
+    const float gs = acc[v * 5 + 4] + (g_msdf_aug ? g_msdf_aug[v] : 0.0f);    // d/d msdf_vert_stopvgd
+    const float sa = sdf[a], sb = sdf[b], ma = msdf[a], mb = msdf[b];
+    const float x0 = sa, x1 = -sb, d0 = x0 + x1;
+    float den = sgn(d0) * (fabsf(d0) + 1e-12f);
+    const bool den_const = (den == 0.0f);
+    if (den_const) den = 1e-12f;
+    const float wa = x1 / den, wb = x0 / den;
+    float gwa = gm * ma, gwb = gm * mb;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float pa = pos[(int64_t)a * 3 + d], pb = pos[(int64_t)b * 3 + d];
+        gwa += gv[d] * pa;
+        gwb += gv[d] * pb;
+        atomicAdd(&g_pos[(int64_t)a * 3 + d], gv[d] * wa);
+        atomicAdd(&g_pos[(int64_t)b * 3 + d], gv[d] * wb);
+    }
+    atomicAdd(&g_msdf[a], (gm + gs) * wa);
+    atomicAdd(&g_msdf[b], (gm + gs) * wb);
+    float gx1 = gwa / den, gx0 = gwb / den;
+    if (!den_const) {  // d den / d d0 = sign(d0)^2 = 1 ; the ==0 fix-up is a constant (ref :282-283)
+        const float gden = -(gwa * x1 + gwb * x0) / (den * den);
+        gx0 += gden;
+        gx1 += gden;
+    }
+    atomicAdd(&g_sdf[a], gx0);
+    atomicAdd(&g_sdf[b], -gx1);
+}
+
+// ------------------------------------------------------------------------------------
+// tangents of the watertight mesh (forward only; ref :9-78, :318-319, :375-380)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void atlas_uv(int v, const float* __restrict__ lin, int Nuv, float pad, float& u, float& w) {
+    // ref :319 passes t_tex_idx = faces, so the uv of vertex v is entry v of map_uv's table (:210-225)
+    int cell = v >> 2, k = v & 3;
+    float tx = lin[cell % Nuv], ty = lin[cell / Nuv];
+    u = (k == 1 || k == 2) ? tx + pad : tx;
+    w = (k >= 2) ? ty + pad : ty;
+}
+
+__global__ void k_tng_faces(int64_t nf, const float* __restrict__ verts, const int64_t* __restrict__ faces,
+                            const float* __restrict__ lin, int Nuv, float pad, float* __restrict__ acc /*[V,7]*/) {
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    int i[3];
+    float p[3][3], uv[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        i[c] = (int)faces[f * 3 + c];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) p[c][d] = verts[(int64_t)i[c] * 3 + d];
+        atlas_uv(i[c], lin, Nuv, pad, uv[c][0], uv[c][1]);
+    }
+    float q1[3], q2[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { q1[d] = p[1][d] - p[0][d]; q2[d] = p[2][d] - p[0][d]; }
+    float fn[3] = {q1[1] * q2[2] - q1[2] * q2[1], q1[2] * q2[0] - q1[0] * q2[2], q1[0] * q2[1] - q1[1] * q2[0]};
+    float e1x = uv[1][0] - uv[0][0], e1y = uv[1][1] - uv[0][1], e2x = uv[2][0] - uv[0][0], e2y = uv[2][1] - uv[0][1];
+    float den = e1x * e2y - e1y * e2x;
+    den = den > 0.0f ? fmaxf(den, 1e-6f) : fminf(den, -1e-6f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            atomicAdd(&acc[(int64_t)i[c] * 7 + d], fn[d]);
+            atomicAdd(&acc[(int64_t)i[c] * 7 + 3 + d], (q1[d] * e2y - q2[d] * e1y) / den);
+        }
+        atomicAdd(&acc[(int64_t)i[c] * 7 + 6], 1.0f);
+    }
+}
+
+__device__ __forceinline__ void safe_nz(float* x) {
+    float l = sqrtf(fmaxf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2], 1e-20f));
+    x[0] /= l; x[1] /= l; x[2] /= l;
+}
+
+__global__ void k_tng_verts(int64_t V, const float* __restrict__ acc, float* __restrict__ tng) {
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    float n[3] = {acc[v * 7], acc[v * 7 + 1], acc[v * 7 + 2]};
+    if (!(n[0] * n[0] + n[1] * n[1] + n[2] * n[2] > 1e-20f)) { n[0] = 0.f; n[1] = 0.f; n[2] = 1.f; }
+    safe_nz(n);
+    const float cnt = acc[v * 7 + 6];
+    float t[3] = {acc[v * 7 + 3] / cnt, acc[v * 7 + 4] / cnt, acc[v * 7 + 5] / cnt};
+    safe_nz(t);
+    const float dp = t[0] * n[0] + t[1] * n[1] + t[2] * n[2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) t[d] = t[d] - dp * n[d];
+    safe_nz(t);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) tng[v * 3 + d] = t[d];
+}
+
+__global__ void k_tng_boundary(int64_t V, int64_t M1, int64_t M2, const float* __restrict__ msdf_aug,
+                               const int32_t* __restrict__ poly, float* __restrict__ tng) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 3 * M1 + 4 * M2) return;
+    int n, k;
+    int64_t p0;
+    if (j < 3 * M1) { n = 3; p0 = (j / 3) * 3; k = (int)(j - p0); }
+    else { int64_t q = j - 3 * M1; n = 4; p0 = 3 * M1 + (q / 4) * 4; k = (int)(q & 3); }
+    const int a = poly[p0 + k], b = poly[p0 + ((k + 1 == n) ? 0 : k + 1)];
+    float wa, wb;
+    msdf_weights(msdf_aug[a], msdf_aug[b], wa, wb);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) tng[(V + j) * 3 + d] = tng[(int64_t)a * 3 + d] * wa + tng[(int64_t)b * 3 + d] * wb;
+}
+
+}  // namespace
+
+// ====================================================================================
+// C ABI
+// ====================================================================================
+extern "C" int gs_mtets_count(gs_mtets_topo* t, const float* pos, const float* sdf, const float* msdf, gs_stream_t stream_,
+                              int64_t* counts_host) {
+    GS_REQUIRE(t && sdf && msdf && counts_host, "gs_mtets_count: null argument");
+    (void)pos;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (t->F == 0 || t->N == 0) {
+        for (int k = 0; k < GS_MTETS_NCOUNTS; ++k) counts_host[k] = t->last_counts[k] = 0;
+        return 0;
+    }
+    k_occ_bits<<<gs::cdiv(t->N, 256), 256, 0, stream>>>(sdf, t->N, t->occ_bits);
+    k_edge_cross<<<t->nb_e, 256, 0, stream>>>((const int2*)t->edges, t->E, t->nchunks, t->occ_bits, t->edge_mask, t->edge_blk);
+    k_classify<<<t->nb_t, 256, 0, stream>>>((const int4*)t->tet, t->F, t->occ_bits, sdf, msdf, t->tet_code, t->tet_blk);
+    k_scan<<<1, 1024, 0, stream>>>(t->tet_blk, t->nb_t, t->edge_blk, t->nb_e, t->counts_dev);
+    GS_LAUNCH_CHECK();
+    GS_HIP_CHECK(hipMemcpyAsync(t->counts_host, t->counts_dev, sizeof(int64_t) * GS_MTETS_NCOUNTS, hipMemcpyDeviceToHost, stream));
+    GS_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int k = 0; k < GS_MTETS_NCOUNTS; ++k) counts_host[k] = t->last_counts[k] = t->counts_host[k];
+    return 0;
+}
+
+extern "C" int gs_mtets_fill(gs_mtets_topo* t, const float* pos, const float* sdf, const float* msdf, float* verts_aug,
+                             float* msdf_aug, float* verts_wt, int64_t* faces_wt, int64_t* faces_aug, int32_t* faces_aug_i32,
+                             int32_t* vert_ab, uint8_t* used_wt, int32_t* poly, uint8_t* cut_code, int32_t* tet_id,
+                             gs_stream_t stream_) {
+    GS_REQUIRE(t && pos && sdf && msdf, "gs_mtets_fill: null argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t* c = t->last_counts;
+    const int64_t V = c[0], M1 = c[1], M2 = c[2];
+    if (V == 0) return 0;
+    GS_REQUIRE(verts_aug && msdf_aug && verts_wt && faces_wt && vert_ab && used_wt && poly && cut_code && tet_id,
+               "gs_mtets_fill: null output");
+    GS_REQUIRE(c[9] == 0 || faces_aug, "gs_mtets_fill: faces_aug is null");
+    GS_HIP_CHECK(hipMemsetAsync(used_wt, 0, (size_t)V, stream));
+    k_vertices<<<t->nb_e, 256, 0, stream>>>((const int2*)t->edges, t->nchunks, t->edge_mask, t->edge_blk, t->chunk_base, pos, sdf,
+                                            msdf, verts_wt, msdf_aug, vert_ab);
+    FillArgs A;
+    A.F = t->F; A.V = V; A.M1 = M1; A.M2 = M2;
+    A.gbase[0] = 0;
+    A.gbase[1] = A.gbase[0] + c[3];
+    A.gbase[2] = A.gbase[1] + 2 * c[4];
+    A.gbase[3] = A.gbase[2] + c[5];
+    A.gbase[4] = A.gbase[3] + 2 * c[6];
+    A.gbase[5] = A.gbase[4] + 3 * c[7];
+    A.code = t->tet_code; A.tet_blk = t->tet_blk; A.tet_edge = t->tet_edge; A.chunk_base = t->chunk_base;
+    A.edge_mask = t->edge_mask; A.verts_wt = verts_wt; A.verts_aug = verts_aug; A.msdf_aug = msdf_aug;
+    A.faces_wt = faces_wt; A.faces_aug = faces_aug; A.faces_aug_i32 = faces_aug_i32; A.used_wt = used_wt;
+    A.poly = poly; A.cut_code = cut_code; A.tet_id = tet_id;
+    k_faces<<<t->nb_t, 256, 0, stream>>>(A);
+    k_mask_wt<<<gs::cdiv(V * 3, 256), 256, 0, stream>>>(V, verts_wt, used_wt, verts_aug);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_mtets_bwd(int64_t N, int64_t V, int64_t M1, int64_t M2, const float* pos, const float* sdf, const float* msdf,
+                            const float* verts_wt, const float* msdf_aug, const int32_t* vert_ab, const uint8_t* used_wt,
+                            const int32_t* poly, const uint8_t* cut_code, const float* g_verts_aug, const float* g_msdf_aug,
+                            const float* g_verts_wt, float* scratch, float* g_pos, float* g_sdf, float* g_msdf,
+                            gs_stream_t stream_) {
+    (void)N;
+    if (V == 0) return 0;
+    GS_REQUIRE(pos && sdf && msdf && verts_wt && msdf_aug && vert_ab && used_wt && poly && cut_code && scratch && g_pos && g_sdf && g_msdf,
+               "gs_mtets_bwd: null argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    GS_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float) * 5 * (size_t)V, stream));
+    const int64_t nb = 3 * M1 + 4 * M2;
+    if (nb > 0 && (g_verts_aug || g_msdf_aug))
+        k_bwd_boundary<<<gs::cdiv(nb, 256), 256, 0, stream>>>(V, M1, M2, verts_wt, msdf_aug, poly, cut_code, g_verts_aug, g_msdf_aug, scratch);
+    k_bwd_vertices<<<gs::cdiv(V, 256), 256, 0, stream>>>(V, pos, sdf, msdf, vert_ab, used_wt, g_verts_aug, g_msdf_aug, g_verts_wt,
+                                                        scratch, g_pos, g_sdf, g_msdf);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_mtets_tangents(int64_t V, int64_t M1, int64_t M2, int64_t F, const float* verts_wt, const int64_t* faces_wt,
+                                 const float* msdf_aug, const int32_t* poly, const float* lin, int64_t Nuv, float* scratch,
+                                 float* v_tng_aug, gs_stream_t stream_) {
+    (void)F;
+    if (V == 0) return 0;
+    GS_REQUIRE(verts_wt && faces_wt && msdf_aug && poly && lin && scratch && v_tng_aug, "gs_mtets_tangents: null argument");
+    GS_REQUIRE(4 * Nuv * Nuv >= V, "gs_mtets_tangents: uv atlas smaller than the vertex count");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t nf = M1 + 2 * M2, nb = 3 * M1 + 4 * M2;
+    const float pad = (float)(0.9 / (double)Nuv);
+    GS_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float) * 7 * (size_t)V, stream));
+    k_tng_faces<<<gs::cdiv(nf, 256), 256, 0, stream>>>(nf, verts_wt, faces_wt, lin, (int)Nuv, pad, scratch);
+    k_tng_verts<<<gs::cdiv(V, 256), 256, 0, stream>>>(V, scratch, v_tng_aug);
+    if (nb > 0) k_tng_boundary<<<gs::cdiv(nb, 256), 256, 0, stream>>>(V, M1, M2, msdf_aug, poly, v_tng_aug);
+    GS_LAUNCH_CHECK();
+    return 0;
+}

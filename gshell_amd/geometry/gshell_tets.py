@@ -1,0 +1,167 @@
+"""G-MarchingTets extractor -- drop-in for the reference's geometry/gshell_tets.py.
+
+`GShell_Tets.__call__(pos_nx3, sdf_n, msdf_n, tet_fx4)` keeps the reference signature and
+return tuple (gshell_tets.py:245, :426-443) but runs as hand-written HIP kernels
+(gshell_amd/csrc/mtets.hip) through the C ABI in include/gshell_hip.h:
+
+    (verts_aug, faces_aug, None, None, v_tng_aug, extra)
+
+Differences that are deliberate (documented in DESIGN.md):
+  * v_tng_aug / extra['v_tng_watertight'] are computed (forward parity) but carry no
+    gradient; the reference's training path discards them
+    (gshell_tets_geometry.py:206-208, render.py:264-267).
+  * faces are additionally available as int32 (`extra['faces_i32']`) for the rasteriser.
+"""
+import ctypes
+import math
+
+import torch
+
+from .. import _lib
+from .._lib import c_int64, c_void_p, check, ptr, stream
+
+
+class TetTopology:
+    """Static per-grid topology living in HBM (sorted unique edges, tet->edge table)."""
+
+    def __init__(self, tet_fx4: torch.Tensor, num_verts: int):
+        if tet_fx4.dtype != torch.int64:
+            tet_fx4 = tet_fx4.long()
+        tet_fx4 = tet_fx4.contiguous()
+        self.device = tet_fx4.device
+        self.N, self.F = int(num_verts), int(tet_fx4.shape[0])
+        self._h = c_void_p(0)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gs_mtets_topo_create(ptr(tet_fx4, torch.int64, "tet_fx4"), c_int64(self.F), c_int64(self.N),
+                                                  stream(), ctypes.byref(self._h)), "gs_mtets_topo_create")
+        n, f, e = c_int64(), c_int64(), c_int64()
+        self._edges_ptr, self._tet_ptr = c_void_p(), c_void_p()
+        check(_lib.lib().gs_mtets_topo_info(self._h, ctypes.byref(n), ctypes.byref(f), ctypes.byref(e),
+                                            ctypes.byref(self._edges_ptr), ctypes.byref(self._tet_ptr)))
+        self.E = int(e.value)
+        self._edges = None
+        nuv = int(math.ceil(math.sqrt((2 * self.F + 1) // 2))) if self.F > 0 else 1
+        self.Nuv = nuv
+        # torch.linspace(0, 1 - 1/N, N): the uv atlas axis of the reference's map_uv (gshell_tets.py:211-216)
+        self.uv_lin = torch.linspace(0, 1 - (1 / nuv), nuv, dtype=torch.float32, device=self.device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def edges(self) -> torch.Tensor:
+        """[E,2] int32, lexicographically sorted unique (min,max) grid edges (a copy)."""
+        if self._edges is None:
+            out = torch.empty((self.E, 2), dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                check(_lib.lib().gs_memcpy_d2d(ptr(out), self._edges_ptr, c_int64(out.numel() * 4), stream()))
+            self._edges = out
+        return self._edges
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().gs_mtets_topo_destroy(self._h)
+                self._h = c_void_p(0)
+        except Exception:
+            pass
+
+
+class _MarchingTetsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, sdf, msdf, topo: TetTopology, want_tangents: bool):
+        L = _lib.lib()
+        dev = pos.device
+        pos_c, sdf_c, msdf_c = pos.detach().contiguous().float(), sdf.detach().contiguous().float(), msdf.detach().contiguous().float()
+        if pos_c.shape[0] != topo.N or sdf_c.numel() != topo.N or msdf_c.numel() != topo.N:
+            raise _lib.GShellHipError(f"field sizes {tuple(pos_c.shape)}, {sdf_c.numel()}, {msdf_c.numel()} do not match the grid (N={topo.N})")
+        counts = (c_int64 * 16)()
+        with torch.cuda.device(dev):
+            check(L.gs_mtets_count(topo.handle, ptr(pos_c, torch.float32, "pos"), ptr(sdf_c, torch.float32, "sdf"),
+                                   ptr(msdf_c, torch.float32, "msdf"), stream(), counts), "gs_mtets_count")
+            V, M1, M2, T, V_aug = counts[0], counts[1], counts[2], counts[9], counts[10]
+            f32 = dict(dtype=torch.float32, device=dev)
+            verts_aug = torch.empty((V_aug, 3), **f32)
+            msdf_aug = torch.empty((V_aug,), **f32)
+            verts_wt = torch.empty((V, 3), **f32)
+            faces_wt = torch.empty((M1 + 2 * M2, 3), dtype=torch.int64, device=dev)
+            faces_aug = torch.empty((T, 3), dtype=torch.int64, device=dev)
+            faces_i32 = torch.empty((T, 3), dtype=torch.int32, device=dev)
+            vert_ab = torch.empty((V, 2), dtype=torch.int32, device=dev)
+            used_wt = torch.empty((V,), dtype=torch.uint8, device=dev)
+            poly = torch.empty((3 * M1 + 4 * M2,), dtype=torch.int32, device=dev)
+            cut_code = torch.empty((M1 + M2,), dtype=torch.uint8, device=dev)
+            tet_id = torch.empty((M1 + M2,), dtype=torch.int32, device=dev)
+            check(L.gs_mtets_fill(topo.handle, ptr(pos_c), ptr(sdf_c), ptr(msdf_c), ptr(verts_aug), ptr(msdf_aug), ptr(verts_wt),
+                                  ptr(faces_wt), ptr(faces_aug), ptr(faces_i32), ptr(vert_ab), ptr(used_wt), ptr(poly),
+                                  ptr(cut_code), ptr(tet_id), stream()), "gs_mtets_fill")
+            v_tng_aug = torch.zeros((V_aug, 3), **f32)
+            if want_tangents and V > 0:
+                scratch = torch.empty((V, 7), **f32)
+                check(L.gs_mtets_tangents(c_int64(V), c_int64(M1), c_int64(M2), c_int64(topo.F), ptr(verts_wt), ptr(faces_wt),
+                                          ptr(msdf_aug), ptr(poly), ptr(topo.uv_lin), c_int64(topo.Nuv), ptr(scratch),
+                                          ptr(v_tng_aug), stream()), "gs_mtets_tangents")
+        ctx.save_for_backward(pos_c, sdf_c, msdf_c, verts_wt, msdf_aug, vert_ab, used_wt, poly, cut_code)
+        ctx.dims = (topo.N, V, M1, M2)
+        ctx.in_shapes = (pos.shape, sdf.shape, msdf.shape)
+        ctx.mark_non_differentiable(faces_wt, faces_aug, faces_i32, v_tng_aug, tet_id)
+        return verts_aug, msdf_aug, verts_wt, faces_aug, faces_wt, faces_i32, v_tng_aug, tet_id
+
+    @staticmethod
+    def backward(ctx, g_verts_aug, g_msdf_aug, g_verts_wt, *_unused):
+        pos, sdf, msdf, verts_wt, msdf_aug, vert_ab, used_wt, poly, cut_code = ctx.saved_tensors
+        N, V, M1, M2 = ctx.dims
+        dev = pos.device
+        g_pos = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+        g_sdf = torch.zeros((N,), dtype=torch.float32, device=dev)
+        g_msdf = torch.zeros((N,), dtype=torch.float32, device=dev)
+        if V > 0:
+            def prep(g):
+                return None if g is None else g.contiguous().float()
+            ga, gm, gw = prep(g_verts_aug), prep(g_msdf_aug), prep(g_verts_wt)
+            with torch.cuda.device(dev):
+                scratch = torch.empty((V, 5), dtype=torch.float32, device=dev)
+                check(_lib.lib().gs_mtets_bwd(c_int64(N), c_int64(V), c_int64(M1), c_int64(M2), ptr(pos), ptr(sdf), ptr(msdf),
+                                              ptr(verts_wt), ptr(msdf_aug), ptr(vert_ab), ptr(used_wt), ptr(poly), ptr(cut_code),
+                                              ptr(ga), ptr(gm), ptr(gw), ptr(scratch), ptr(g_pos), ptr(g_sdf), ptr(g_msdf),
+                                              stream()), "gs_mtets_bwd")
+        ps, ss, ms = ctx.in_shapes
+        return g_pos.reshape(ps), g_sdf.reshape(ss), g_msdf.reshape(ms), None, None
+
+
+class GShell_Tets:
+    """Same call surface as the reference class (gshell_tets.py:80, :245)."""
+
+    def __init__(self, compute_tangents: bool = True):
+        self.compute_tangents = compute_tangents
+        self._topo_cache = {}
+
+    def topology(self, tet_fx4: torch.Tensor, num_verts: int) -> TetTopology:
+        key = (tet_fx4.data_ptr(), tuple(tet_fx4.shape), str(tet_fx4.device), int(num_verts))
+        topo = self._topo_cache.get(key)
+        if topo is None:
+            topo = TetTopology(tet_fx4, num_verts)
+            self._topo_cache = {key: topo}   # one grid at a time, like the reference
+        return topo
+
+    def __call__(self, pos_nx3, sdf_n, msdf_n, tet_fx4, output_watertight_template=True):
+        if not output_watertight_template:
+            raise NotImplementedError("output_watertight_template=False (mSDF pre-filter, gshell_tets.py:263) is never used "
+                                      "by the reference's call sites and is not implemented")
+        topo = self.topology(tet_fx4, pos_nx3.shape[0])
+        verts_aug, msdf_aug, verts_wt, faces_aug, faces_wt, faces_i32, v_tng_aug, tet_id = _MarchingTetsFn.apply(
+            pos_nx3, sdf_n, msdf_n, topo, self.compute_tangents)
+        V = verts_wt.shape[0]
+        extra = {
+            'n_verts_watertight': V,
+            'vertices_watertight': verts_wt,
+            'faces_watertight': faces_wt,
+            'v_tng_watertight': v_tng_aug[:V],
+            'msdf': msdf_aug,
+            'msdf_watertight': msdf_aug[:V],
+            'msdf_boundary': msdf_aug[V:],
+            # extras of this implementation
+            'faces_i32': faces_i32,
+            'polygon_tet_id': tet_id,
+        }
+        return verts_aug, faces_aug, None, None, v_tng_aug, extra

@@ -1,0 +1,148 @@
+"""G-MarchingTets: HIP path (through the C ABI) vs golden vectors from the real reference
+and vs the CPU oracle on fresh seeded inputs.  Run on the MI355X box: pytest -m gpu."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fields, mtets_oracle
+from tests.helpers import golden_inputs
+
+pytestmark = pytest.mark.gpu
+FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mtets_*.npz")))
+
+
+def _run_hip(verts, tets, sdf, msdf, seed, sdf_2d=False):
+    from gshell_amd.geometry.gshell_tets import GShell_Tets
+    dev = torch.device("cuda")
+    pos = torch.tensor(verts, device=dev, requires_grad=True)
+    s = torch.tensor(sdf, device=dev)
+    if sdf_2d:
+        s = s[:, None]
+    s.requires_grad_(True)
+    m = torch.tensor(msdf, device=dev, requires_grad=True)
+    t = torch.tensor(tets, dtype=torch.long, device=dev)
+    ext = GShell_Tets()
+    v_aug, f_aug, uvs, uv_idx, tng, extra = ext(pos, s, m, t)
+    assert uvs is None and uv_idx is None
+    wv, wm, ww = fields.loss_weights(v_aug.shape[0], extra["n_verts_watertight"], seed)
+    loss = (v_aug * torch.tensor(wv, device=dev)).sum() + (extra["msdf"] * torch.tensor(wm, device=dev)).sum() \
+        + (extra["vertices_watertight"] * torch.tensor(ww, device=dev)).sum()
+    loss.backward()
+    out = dict(verts_aug=v_aug, faces_aug=f_aug, v_tng_aug=tng, vertices_watertight=extra["vertices_watertight"],
+               faces_watertight=extra["faces_watertight"], v_tng_watertight=extra["v_tng_watertight"], msdf=extra["msdf"],
+               msdf_watertight=extra["msdf_watertight"], msdf_boundary=extra["msdf_boundary"], faces_i32=extra["faces_i32"])
+    out = {k: v.detach().cpu().numpy() for k, v in out.items()}
+    out["n_verts_watertight"] = extra["n_verts_watertight"]
+    out["grad_pos"] = pos.grad.cpu().numpy()
+    out["grad_sdf"] = s.grad.reshape(-1).cpu().numpy()
+    out["grad_msdf"] = m.grad.cpu().numpy()
+    return out
+
+
+def _compare(out, ref, grads=True):
+    assert out["n_verts_watertight"] == int(ref["n_verts_watertight"])
+    # integer / index work: bit exact
+    np.testing.assert_array_equal(out["faces_watertight"], np.asarray(ref["faces_watertight"]))
+    np.testing.assert_array_equal(out["faces_aug"], np.asarray(ref["faces_aug"]))
+    np.testing.assert_array_equal(out["faces_i32"], np.asarray(ref["faces_aug"]))
+    assert out["faces_aug"].dtype == np.int64
+    # forward floats: same IEEE ops, same order, no FMA contraction -> exact
+    for k in ("verts_aug", "vertices_watertight", "msdf", "msdf_watertight", "msdf_boundary"):
+        np.testing.assert_array_equal(out[k], np.asarray(ref[k]), err_msg=k)
+    # tangents use float atomics (as the reference's scatter_add does): tolerance 1e-4
+    for k in ("v_tng_aug", "v_tng_watertight"):
+        np.testing.assert_allclose(out[k], np.asarray(ref[k]), rtol=0, atol=1e-4, err_msg=k)
+    if grads:
+        for k in ("grad_pos", "grad_sdf", "grad_msdf"):
+            r = np.asarray(ref[k])
+            scale = max(1.0, float(np.abs(r).max()))
+            # north_star tolerance: gradients within 1e-4 relative (fp32, atomics reorder sums)
+            np.testing.assert_allclose(out[k], r, rtol=1e-4, atol=1e-4 * scale, err_msg=k)
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p)[6:-4] for p in FILES])
+def test_hip_matches_reference_golden(path):
+    g = np.load(path)
+    verts, tets, sdf, msdf = golden_inputs(g)
+    out = _run_hip(verts, tets, sdf, msdf, int(g["seed"]))
+    _compare(out, g)
+
+
+def _oracle(verts, tets, sdf, msdf, seed):
+    pos = torch.tensor(verts, requires_grad=True)
+    s = torch.tensor(sdf, requires_grad=True)
+    m = torch.tensor(msdf, requires_grad=True)
+    o = mtets_oracle.extract(pos, s, m, torch.tensor(tets))
+    wv, wm, ww = fields.loss_weights(o["verts_aug"].shape[0], o["n_verts_watertight"], seed)
+    loss = (o["verts_aug"] * torch.tensor(wv)).sum() + (o["msdf"] * torch.tensor(wm)).sum() \
+        + (o["vertices_watertight"] * torch.tensor(ww)).sum()
+    loss.backward()
+    ref = {k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in o.items()}
+    ref["grad_pos"], ref["grad_sdf"], ref["grad_msdf"] = pos.grad.numpy(), s.grad.numpy(), m.grad.numpy()
+    return ref
+
+
+@pytest.mark.parametrize("gspec,sk,mk,seed,zeros,sdf2d", [
+    (("bcc", 20), "sphere_noise", "rand", 11, 0, False),
+    (("bcc", 26), "two_spheres", "wavy", 12, 200, True),
+    (("kuhn", 24), "skirt", "halfspace", 13, 100, False),
+    (("bcc", 9), "plane", "negative", 14, 0, False),
+    (("bcc", 40), "skirt", "wavy", 15, 0, True),
+])
+def test_hip_matches_oracle_seeded(gspec, sk, mk, seed, zeros, sdf2d):
+    from gshell_amd import grid
+    verts, tets = (grid.bcc_grid(gspec[1]) if gspec[0] == "bcc" else grid.kuhn_grid(gspec[1]))
+    verts = verts.numpy()
+    verts = verts + fields.make_deform(verts, 1.0 / gspec[1], seed)
+    sdf = fields.make_sdf(verts, sk, seed, zeros)
+    msdf = fields.make_msdf(verts, mk, seed, zeros)
+    out = _run_hip(verts, tets.numpy(), sdf, msdf, seed, sdf_2d=sdf2d)
+    ref = _oracle(verts, tets.numpy(), sdf, msdf, seed)
+    _compare(out, ref)
+
+
+def test_empty_surface_is_legal():
+    from gshell_amd import grid
+    from gshell_amd.geometry.gshell_tets import GShell_Tets
+    verts, tets = grid.bcc_grid(4, device="cuda")
+    sdf = torch.full((verts.shape[0],), -1.0, device="cuda", requires_grad=True)
+    msdf = torch.ones_like(sdf)
+    v, f, _, _, tng, extra = GShell_Tets()(verts, sdf, msdf, tets)
+    assert v.shape == (0, 3) and f.shape == (0, 3) and tng.shape == (0, 3) and extra["n_verts_watertight"] == 0
+    (v.sum() + extra["msdf"].sum()).backward()
+    assert float(sdf.grad.abs().sum()) == 0.0
+
+
+def test_full_size_res256_properties():
+    """BASELINE config 3 grid (N=2.28 M, F=13.4 M): size-independent invariants."""
+    from gshell_amd import grid
+    from gshell_amd.geometry.gshell_tets import GShell_Tets
+    dev = torch.device("cuda")
+    verts, tets = grid.bcc_grid(104, device=dev)
+    r = torch.sqrt(verts[:, 0] ** 2 + verts[:, 2] ** 2)
+    sdf = torch.minimum(0.26 - 0.18 * verts[:, 1] - r, 0.36 - verts[:, 1].abs())
+    msdf = 0.12 - verts[:, 1] + 0.05 * torch.sin(8.0 * verts[:, 0])
+    ext = GShell_Tets()
+    v, f, _, _, tng, extra = ext(verts, sdf, msdf, tets)
+    V, fw = extra["n_verts_watertight"], extra["faces_watertight"]
+    assert f.shape[0] > 0 and int(f.max()) < v.shape[0] and int(f.min()) >= 0
+    # closed surface strictly inside the box: every watertight edge is shared by exactly two faces
+    e = torch.cat([fw[:, [0, 1]], fw[:, [1, 2]], fw[:, [2, 0]]], 0)
+    key = torch.minimum(e[:, 0], e[:, 1]) * V + torch.maximum(e[:, 0], e[:, 1])
+    _, cnt = torch.unique(key, return_counts=True)
+    assert bool((cnt == 2).all())
+    # Euler characteristic of a sphere-like closed surface
+    assert V - cnt.shape[0] + fw.shape[0] == 2
+    # vertices lie on the zero level set of the (linear-per-edge) field: |sdf| small at verts
+    rr = torch.sqrt(extra["vertices_watertight"][:, 0] ** 2 + extra["vertices_watertight"][:, 2] ** 2)
+    yy = extra["vertices_watertight"][:, 1]
+    s_at = torch.minimum(0.26 - 0.18 * yy - rr, 0.36 - yy.abs())
+    assert float(s_at.abs().max()) < 2e-3
+    # idempotence: same inputs -> identical outputs
+    v2, f2, _, _, _, _ = ext(verts, sdf, msdf, tets)
+    assert torch.equal(f, f2) and torch.equal(v, v2)
+    # the open mesh keeps only the msdf>0 side
+    assert float(extra["msdf"][f.reshape(-1)].min()) > -1e-6
