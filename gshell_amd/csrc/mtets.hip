@@ -8,12 +8,14 @@
 //   count phase   k_occ_bits   sdf sign -> 1 bit / grid vertex (wave ballot)          [N]
 //                 k_edge_cross crossing bit per static sorted edge (wave ballot)      [E]
 //                 k_classify   tet sign pattern + mSDF cut case -> 1 byte / tet,
-//                              per-block category counts (ballot + popcount)          [F]
-//                 k_scan       exclusive scans of the per-block counts (1 block)
-//   -- one D2H copy of 11 counters; the caller allocates exact-size outputs --
+//                              per-block category counts (ballot + popcount),
+//                              grand totals by one atomic per block                   [F]
+//   -- one D2H copy of 9 counters; the caller allocates exact-size outputs --
 //   fill phase    k_vertices   rank crossing edges (prefix popcount) + interpolate    [E/64]
-//                 k_faces      ordered compaction of tets into the reference's face
-//                              order + boundary vertices + mSDF cut                   [F] (1 B/tet)
+//                 k_compact    ordered compaction of crossing tets (1 B/tet read,
+//                              packed 16-bit block scan) -> polygon slots             [F]
+//                 k_polys      dense, one thread per polygon: watertight faces,
+//                              boundary vertices, mSDF cut in the reference's order   [M1+M2]
 //                 k_mask_wt    zero unreferenced watertight vertices                  [V]
 //
 // Mesh vertex ids are ranks of crossing edges in the static lexicographically sorted
@@ -87,8 +89,10 @@ __device__ __forceinline__ int sel4(int a, int b, int c, int d, int k) { return 
 // ------------------------------------------------------------------------------------
 // count phase
 // ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_occ_bits(const float* __restrict__ sdf, int64_t N, uint64_t* __restrict__ bits) {
+__global__ void __launch_bounds__(256) k_occ_bits(const float* __restrict__ sdf, int64_t N, uint64_t* __restrict__ bits,
+                                                  unsigned long long* __restrict__ counts) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < GS_MTETS_NCOUNTS) counts[threadIdx.x] = 0ull;  // totals are atomically accumulated below
     bool o = (i < N) && (sdf[i] > 0.0f);  // strict: sdf == 0 is outside (ref :250)
     uint64_t m = __ballot(o);
     if ((threadIdx.x & 63) == 0 && i < N) bits[i >> 6] = m;
@@ -97,50 +101,71 @@ __global__ void __launch_bounds__(256) k_occ_bits(const float* __restrict__ sdf,
 // One wave per 64-edge chunk: crossing bit = occ[a] != occ[b]  (ref :271)
 __global__ void __launch_bounds__(256) k_edge_cross(const int2* __restrict__ edges, int64_t E, int64_t nchunks,
                                                     const uint64_t* __restrict__ occ, uint64_t* __restrict__ mask,
-                                                    int32_t* __restrict__ blk_cnt) {
+                                                    int32_t* __restrict__ blk_cnt, unsigned long long* __restrict__ counts) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t c0 = (int64_t)blockIdx.x * MT_CHUNKS_PER_BLOCK + wave * 64;
+    const uint32_t* __restrict__ occ32 = (const uint32_t*)occ;
     int cnt = 0;
-#pragma unroll 4
-    for (int j = 0; j < 64; ++j) {
-        int64_t c = c0 + j;
-        int64_t e = c * 64 + lane;
-        bool x = false;
-        if (e < E) {
-            int2 ab = edges[e];
-            x = occ_bit(occ, ab.x) != occ_bit(occ, ab.y);
+    for (int j = 0; j < 64; j += 4) {
+        int2 ab[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int64_t e = (c0 + j + u) * 64 + lane;
+            ab[u] = e < E ? edges[e] : make_int2(0, 0);
         }
-        uint64_t m = __ballot(x);
-        if (lane == 0 && c < nchunks) mask[c] = m;
-        cnt += __popcll(m);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int64_t c = c0 + j + u;
+            bool x = ((occ32[ab[u].x >> 5] >> (ab[u].x & 31)) ^ (occ32[ab[u].y >> 5] >> (ab[u].y & 31))) & 1u;
+            uint64_t m = __ballot(x);
+            if (lane == 0 && c < nchunks) mask[c] = m;
+            cnt += __popcll(m);
+        }
     }
     __shared__ int s[4];
     if (lane == 0) s[wave] = cnt;
     __syncthreads();
-    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+    if (threadIdx.x == 0) {
+        int tot = s[0] + s[1] + s[2] + s[3];
+        blk_cnt[blockIdx.x] = tot;
+        if (tot) atomicAdd(&counts[0], (unsigned long long)tot);
+    }
 }
 
 // categories of a tet code byte: 0:n1 1:n2 2:tri->1 3:tri->2 4..7:quad->1..4
+// (tables packed into immediates: lane-varying __constant__ lookups are real memory gathers)
 __device__ __forceinline__ void code_cats(uint8_t cb, int& ntri, int& ci, int& ncut) {
-    ntri = c_ntri[cb & 15];
+    ntri = (int)((0x16696994u >> (2 * (cb & 15))) & 3u);                        // c_ntri, 2 bits each
     ci = cb >> 4;
-    ncut = ntri == 1 ? c_ncut_tri[ci & 7] : (ntri == 2 ? c_ncut_quad[ci] : 0);
+    const int nt = (int)((0x6994u >> (2 * (ci & 7))) & 3u);                      // c_ncut_tri
+    const int nq = (int)((0x2332342132412110ull >> (4 * ci)) & 15ull);           // c_ncut_quad, 4 bits each
+    ncut = ntri == 1 ? nt : (ntri == 2 ? nq : 0);
 }
 
 __global__ void __launch_bounds__(256) k_classify(const int4* __restrict__ tets, int64_t F, const uint64_t* __restrict__ occ,
                                                   const float* __restrict__ sdf, const float* __restrict__ msdf,
-                                                  uint8_t* __restrict__ code_out, int32_t* __restrict__ blk_cnt) {
+                                                  uint8_t* __restrict__ code_out, int32_t* __restrict__ blk_cnt,
+                                                  unsigned long long* __restrict__ counts) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t* __restrict__ occ32 = (const uint32_t*)occ;
     int cnt[MT_NCAT];
 #pragma unroll
     for (int k = 0; k < MT_NCAT; ++k) cnt[k] = 0;
-    for (int tile = 0; tile < MT_TILES; ++tile) {
-        int64_t f = ((int64_t)blockIdx.x * MT_TILES + tile) * MT_BLOCK + threadIdx.x;
-        int ntri = 0, ci = 0, ncut = 0;
-        if (f < F) {
-            int4 t = tets[f];
-            int code = occ_bit(occ, t.x) | (occ_bit(occ, t.y) << 1) | (occ_bit(occ, t.z) << 2) | (occ_bit(occ, t.w) << 3);  // ref :296-297
-            ntri = c_ntri[code];
+    for (int tile = 0; tile < MT_TILES; tile += 4) {
+        int4 tt[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int64_t f = ((int64_t)blockIdx.x * MT_TILES + tile + u) * MT_BLOCK + threadIdx.x;
+            tt[u] = f < F ? tets[f] : make_int4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t f = ((int64_t)blockIdx.x * MT_TILES + tile + u) * MT_BLOCK + threadIdx.x;
+            const int4 t = tt[u];
+            int code = ((occ32[t.x >> 5] >> (t.x & 31)) & 1u) | (((occ32[t.y >> 5] >> (t.y & 31)) & 1u) << 1) |
+                       (((occ32[t.z >> 5] >> (t.z & 31)) & 1u) << 2) | (((occ32[t.w >> 5] >> (t.w & 31)) & 1u) << 3);  // ref :296-297
+            if (f >= F) code = 0;
+            int ntri = (int)((0x16696994u >> (2 * code)) & 3u), ci = 0, ncut = 0;
             if (ntri) {
                 // mSDF sign at each polygon corner (= crossing edge), ref :289, :330-331
                 const int n = 2 + ntri;
@@ -156,17 +181,17 @@ __global__ void __launch_bounds__(256) k_classify(const int4* __restrict__ tets,
                 }
                 ncut = ntri == 1 ? c_ncut_tri[ci] : c_ncut_quad[ci];
             }
-            code_out[f] = (uint8_t)(code | (ci << 4));
+            if (f < F) code_out[f] = (uint8_t)(code | (ci << 4));
+            if (__ballot(ntri != 0) == 0ull) continue;
+            cnt[0] += __popcll(__ballot(ntri == 1));
+            cnt[1] += __popcll(__ballot(ntri == 2));
+            cnt[2] += __popcll(__ballot(ntri == 1 && ncut == 1));
+            cnt[3] += __popcll(__ballot(ntri == 1 && ncut == 2));
+            cnt[4] += __popcll(__ballot(ntri == 2 && ncut == 1));
+            cnt[5] += __popcll(__ballot(ntri == 2 && ncut == 2));
+            cnt[6] += __popcll(__ballot(ntri == 2 && ncut == 3));
+            cnt[7] += __popcll(__ballot(ntri == 2 && ncut == 4));
         }
-        if (__ballot(ntri != 0) == 0ull) continue;
-        cnt[0] += __popcll(__ballot(ntri == 1));
-        cnt[1] += __popcll(__ballot(ntri == 2));
-        cnt[2] += __popcll(__ballot(ntri == 1 && ncut == 1));
-        cnt[3] += __popcll(__ballot(ntri == 1 && ncut == 2));
-        cnt[4] += __popcll(__ballot(ntri == 2 && ncut == 1));
-        cnt[5] += __popcll(__ballot(ntri == 2 && ncut == 2));
-        cnt[6] += __popcll(__ballot(ntri == 2 && ncut == 3));
-        cnt[7] += __popcll(__ballot(ntri == 2 && ncut == 4));
     }
     __shared__ int s[4][MT_NCAT];
     if (lane == 0) {
@@ -174,57 +199,23 @@ __global__ void __launch_bounds__(256) k_classify(const int4* __restrict__ tets,
         for (int k = 0; k < MT_NCAT; ++k) s[wave][k] = cnt[k];
     }
     __syncthreads();
-    if (threadIdx.x < MT_NCAT)
-        blk_cnt[(int64_t)blockIdx.x * MT_NCAT + threadIdx.x] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+    if (threadIdx.x < MT_NCAT) {
+        int tot = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+        blk_cnt[(int64_t)blockIdx.x * MT_NCAT + threadIdx.x] = tot;
+        if (tot) atomicAdd(&counts[1 + threadIdx.x], (unsigned long long)tot);
+    }
 }
 
-// Exclusive scan of a strided int sequence by one 1024-thread block (in place); returns total.
-__device__ int scan_sequence_1024(int32_t* seq, int64_t n, int stride, int* lds) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t per = (n + 1023) / 1024;
-    const int64_t lo = min((int64_t)tid * per, n), hi = min(lo + per, n);
+// Sum of seq[i*stride] for i < n, by a 256-thread block (every thread gets the result).
+__device__ int block_prefix_256(const int32_t* __restrict__ seq, int64_t n, int stride, int* lds /*[4]*/) {
     int local = 0;
-    for (int64_t i = lo; i < hi; ++i) local += seq[i * stride];
-    int x = local;
+    for (int64_t i = threadIdx.x; i < n; i += 256) local += seq[i * stride];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int y = __shfl_up(x, o);
-        if (lane >= o) x += y;
-    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
     __syncthreads();
-    if (lane == 63) lds[w] = x;
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = local;
     __syncthreads();
-    int woff = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int sv = lds[i];
-        if (i < w) woff += sv;
-        tot += sv;
-    }
-    int run = woff + x - local;
-    for (int64_t i = lo; i < hi; ++i) {
-        int v = seq[i * stride];
-        seq[i * stride] = run;
-        run += v;
-    }
-    return tot;
-}
-
-__global__ void __launch_bounds__(1024) k_scan(int32_t* tet_blk, int64_t nb_t, int32_t* edge_blk, int64_t nb_e, int64_t* counts) {
-    __shared__ int lds[16];
-    int c[MT_NCAT];
-    int V = scan_sequence_1024(edge_blk, nb_e, 1, lds);
-#pragma unroll
-    for (int k = 0; k < MT_NCAT; ++k) c[k] = scan_sequence_1024(tet_blk + k, nb_t, MT_NCAT, lds);
-    if (threadIdx.x == 0) {
-        counts[0] = V;
-        counts[1] = c[0];
-        counts[2] = c[1];
-        for (int k = 0; k < 6; ++k) counts[3 + k] = c[2 + k];
-        counts[9] = (int64_t)c[2] + 2ll * c[3] + c[4] + 2ll * c[5] + 3ll * c[6] + 4ll * c[7];
-        counts[10] = (int64_t)V + 3ll * c[0] + 4ll * c[1];
-        for (int k = 11; k < GS_MTETS_NCOUNTS; ++k) counts[k] = 0;
-    }
+    return lds[0] + lds[1] + lds[2] + lds[3];
 }
 
 // ------------------------------------------------------------------------------------
@@ -241,6 +232,9 @@ __global__ void __launch_bounds__(256) k_vertices(const int2* __restrict__ edges
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t c = (int64_t)blockIdx.x * MT_CHUNKS_PER_BLOCK + tid;
     uint64_t m = c < nchunks ? mask[c] : 0ull;
+    // vertex id of this block's first crossing edge = crossings in all earlier blocks
+    const int blk_off = block_prefix_256(edge_blk, blockIdx.x, 1, s_w);
+    __syncthreads();
     int p = __popcll(m), x = p;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -249,7 +243,7 @@ __global__ void __launch_bounds__(256) k_vertices(const int2* __restrict__ edges
     }
     if (lane == 63) s_w[wave] = x;
     __syncthreads();
-    int woff = edge_blk[blockIdx.x];
+    int woff = blk_off;
     for (int i = 0; i < wave; ++i) woff += s_w[i];
     int base = woff + x - p;
     s_mask[tid] = m;
@@ -276,15 +270,108 @@ __global__ void __launch_bounds__(256) k_vertices(const int2* __restrict__ edges
     }
 }
 
+// Ordered compaction of surface-crossing tets.  Thread t of a block owns 16 consecutive tets
+// (one 16-byte load of code bytes) per pass, so a block-wide exclusive scan of per-thread
+// category counts reproduces tet order -- the order of the reference's boolean-mask
+// compactions (ref :305-316, :409-416).  Emits, per polygon slot: source tet, cut case and
+// the rank of the tet inside its mSDF-cut group.
+__global__ void __launch_bounds__(256) k_compact(const uint8_t* __restrict__ code, int64_t F, const int32_t* __restrict__ tet_blk,
+                                                 int64_t M1, int32_t* __restrict__ tet_id, uint8_t* __restrict__ cut_code,
+                                                 uint8_t* __restrict__ sign_code, int32_t* __restrict__ grp_rank) {
+    __shared__ int s_red[4];
+    __shared__ unsigned long long s_w[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int run[MT_NCAT];
+    for (int k = 0; k < MT_NCAT; ++k) {
+        run[k] = block_prefix_256(tet_blk + k, (int64_t)blockIdx.x * MT_COMPACT_SPAN, MT_NCAT, s_red);
+        __syncthreads();
+    }
+    constexpr int PASSES = MT_COMPACT_SPAN * MT_TETS_PER_BLOCK / (256 * 16);
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int64_t f0 = (int64_t)blockIdx.x * MT_COMPACT_SPAN * MT_TETS_PER_BLOCK + (int64_t)pass * 4096 + threadIdx.x * 16;
+        uint8_t cb[16];
+        if (f0 + 16 <= F) {
+            uint4 v = *reinterpret_cast<const uint4*>(code + f0);
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cb[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cb[i] = (f0 + i < F) ? code[f0 + i] : 0;
+        }
+        // per-thread category counts packed as 4 x 16-bit fields in two 64-bit words
+        unsigned long long c0 = 0ull, c1 = 0ull;
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int ntri, ci, ncut;
+            code_cats(cb[i], ntri, ci, ncut);
+            if (ntri) {
+                any = true;
+                c0 += 1ull << (16 * (ntri - 1));
+                if (ncut) {
+                    const int g = ntri == 1 ? (ncut - 1) : (1 + ncut);  // 0..5
+                    if (g < 2) c0 += 1ull << (16 * (2 + g));
+                    else c1 += 1ull << (16 * (g - 2));
+                }
+            }
+        }
+        if (!__syncthreads_or(any)) continue;
+        unsigned long long x0 = c0, x1 = c1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned long long y0 = __shfl_up(x0, o), y1 = __shfl_up(x1, o);
+            if (lane >= o) { x0 += y0; x1 += y1; }
+        }
+        if (lane == 63) { s_w[0][wave] = x0; s_w[1][wave] = x1; }
+        __syncthreads();
+        unsigned long long w0 = 0ull, w1 = 0ull, t0 = 0ull, t1 = 0ull;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) { w0 += s_w[0][w]; w1 += s_w[1][w]; }
+            t0 += s_w[0][w]; t1 += s_w[1][w];
+        }
+        unsigned long long e0 = w0 + x0 - c0, e1 = w1 + x1 - c1;  // exclusive prefix of this thread
+        int my[MT_NCAT];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            my[k] = run[k] + (int)((e0 >> (16 * k)) & 0xffff);
+            my[4 + k] = run[4 + k] + (int)((e1 >> (16 * k)) & 0xffff);
+            run[k] += (int)((t0 >> (16 * k)) & 0xffff);
+            run[4 + k] += (int)((t1 >> (16 * k)) & 0xffff);
+        }
+        if (!any) continue;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int ntri, ci, ncut;
+            code_cats(cb[i], ntri, ci, ncut);
+            if (!ntri) continue;
+            int64_t slot;
+            if (ntri == 1) { slot = my[0]; my[0]++; } else { slot = M1 + my[1]; my[1]++; }
+            tet_id[slot] = (int32_t)(f0 + i);
+            cut_code[slot] = (uint8_t)ci;
+            sign_code[slot] = (uint8_t)(cb[i] & 15);
+            int gr = -1;
+            const int g = ncut ? (ntri == 1 ? (ncut - 1) : (1 + ncut)) : -1;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (g == k) { gr = my[2 + k]; my[2 + k]++; }
+            grp_rank[slot] = gr;
+        }
+    }
+}
+
 struct FillArgs {
-    int64_t F, V, M1, M2;
+    int64_t V, M1, M2;
     int64_t gbase[6];  // first face row of each mSDF-cut group (ref :409-416 order)
-    const uint8_t* code;
-    const int32_t* tet_blk;
     const int32_t* tet_edge;
     const int32_t* chunk_base;
     const uint64_t* edge_mask;
     const float* verts_wt;
+    const int32_t* tet_id;
+    const uint8_t* cut_code;
+    const uint8_t* sign_code;
+    const int32_t* grp_rank;
     float* verts_aug;
     float* msdf_aug;
     int64_t* faces_wt;
@@ -292,113 +379,68 @@ struct FillArgs {
     int32_t* faces_aug_i32;
     uint8_t* used_wt;
     int32_t* poly;
-    uint8_t* cut_code;
-    int32_t* tet_id;
 };
 
-__global__ void __launch_bounds__(256) k_faces(FillArgs A) {
-    __shared__ int s_tot[2][4][MT_NCAT];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int run[MT_NCAT];
-#pragma unroll
-    for (int k = 0; k < MT_NCAT; ++k) run[k] = A.tet_blk[(int64_t)blockIdx.x * MT_NCAT + k];
-    const uint64_t lt = lanemask_lt();
-    for (int tile = 0; tile < MT_TILES; ++tile) {
-        const int64_t f = ((int64_t)blockIdx.x * MT_TILES + tile) * MT_BLOCK + threadIdx.x;
-        const uint8_t cb = f < A.F ? A.code[f] : 0;
-        int ntri, ci, ncut;
-        code_cats(cb, ntri, ci, ncut);
-        if (!__syncthreads_or(ntri != 0)) continue;
-        uint64_t b[MT_NCAT];
-        b[0] = __ballot(ntri == 1);
-        b[1] = __ballot(ntri == 2);
-        b[2] = __ballot(ntri == 1 && ncut == 1);
-        b[3] = __ballot(ntri == 1 && ncut == 2);
-        b[4] = __ballot(ntri == 2 && ncut == 1);
-        b[5] = __ballot(ntri == 2 && ncut == 2);
-        b[6] = __ballot(ntri == 2 && ncut == 3);
-        b[7] = __ballot(ntri == 2 && ncut == 4);
-        const int buf = tile & 1;
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < MT_NCAT; ++k) s_tot[buf][wave][k] = __popcll(b[k]);
-        }
-        __syncthreads();
-        int rank[MT_NCAT];
-#pragma unroll
-        for (int k = 0; k < MT_NCAT; ++k) {
-            int woff = 0, tot = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                int sv = s_tot[buf][w][k];
-                if (w < wave) woff += sv;
-                tot += sv;
-            }
-            rank[k] = run[k] + woff + __popcll(b[k] & lt);
-            run[k] += tot;
-        }
-        if (ntri == 0) continue;
+// One thread per polygon (surface-crossing tet), dense.
+__global__ void __launch_bounds__(256) k_polys(FillArgs A) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= A.M1 + A.M2) return;
+    const int ntri = slot < A.M1 ? 1 : 2;
+    const int n = 2 + ntri;
+    const int64_t f = A.tet_id[slot];
+    const int code = A.sign_code[slot], ci = A.cut_code[slot];
+    int pc[4] = {0, 0, 0, 0};
+    for (int k = 0; k < n; ++k) {
+        int e = A.tet_edge[f * 6 + c_poly[code][k]];
+        pc[k] = A.chunk_base[e >> 6] + __popcll(A.edge_mask[e >> 6] & ((1ull << (e & 63)) - 1ull));
+    }
+    int64_t bnd, prow, wt_row;  // first boundary vertex id, first poly[] entry, first watertight face row
+    if (ntri == 1) {
+        bnd = A.V + 3 * slot;
+        prow = 3 * slot;
+        wt_row = slot;
+    } else {
+        const int64_t i2 = slot - A.M1;
+        bnd = A.V + 3 * A.M1 + 4 * i2;
+        prow = 3 * A.M1 + 4 * i2;
+        wt_row = A.M1 + 2 * i2;
+    }
+    // watertight faces (ref :313-316): 1-triangle tets first, then 2-triangle tets
+    for (int j = 0; j < 3 * ntri; ++j) A.faces_wt[wt_row * 3 + j] = sel4(pc[0], pc[1], pc[2], pc[3], c_tri_poly[ntri - 1][j]);
+    for (int k = 0; k < n; ++k) A.poly[prow + k] = pc[k];
 
-        // ---- this lane owns one surface-crossing tet -----------------------------------
-        const int code = cb & 15;
-        const int n = 2 + ntri;
-        int pc[4] = {0, 0, 0, 0};
-        for (int k = 0; k < n; ++k) {
-            int e = A.tet_edge[f * 6 + c_poly[code][k]];
-            pc[k] = A.chunk_base[e >> 6] + __popcll(A.edge_mask[e >> 6] & ((1ull << (e & 63)) - 1ull));
-        }
-        int64_t slot, bnd, prow;  // polygon slot, first boundary vertex id, first poly[] entry
-        int64_t wt_row;
-        if (ntri == 1) {
-            slot = rank[0];
-            bnd = A.V + 3 * slot;
-            prow = 3 * slot;
-            wt_row = slot;
-        } else {
-            slot = A.M1 + rank[1];
-            bnd = A.V + 3 * A.M1 + 4 * (int64_t)rank[1];
-            prow = 3 * A.M1 + 4 * (int64_t)rank[1];
-            wt_row = A.M1 + 2 * (int64_t)rank[1];
-        }
-        // watertight faces (ref :313-316): 1-triangle tets first, then 2-triangle tets
-        for (int j = 0; j < 3 * ntri; ++j)
-            A.faces_wt[wt_row * 3 + j] = sel4(pc[0], pc[1], pc[2], pc[3], c_tri_poly[ntri - 1][j]);
-        for (int k = 0; k < n; ++k) A.poly[prow + k] = pc[k];
-        A.cut_code[slot] = (uint8_t)ci;
-        A.tet_id[slot] = (int32_t)f;
-
-        // boundary vertices on the polygon loop (ref :335-392); private to this tet
-        const int used = ntri == 1 ? c_used_tri[ci] : c_used_quad[ci];
-        for (int k = 0; k < n; ++k) {
-            const int a = pc[k], bb = pc[(k + 1 == n) ? 0 : k + 1];
-            const float ma = A.msdf_aug[a], mb = A.msdf_aug[bb];
-            float wa, wb;
-            msdf_weights(ma, mb, wa, wb);
-            const bool u = (used >> (n + k)) & 1;  // unreferenced vertices are zeroed (ref :419-423)
+    // boundary vertices on the polygon loop (ref :335-392); private to this tet
+    const int used = ntri == 1 ? c_used_tri[ci] : c_used_quad[ci];
+    for (int k = 0; k < n; ++k) {
+        const int a = pc[k], bb = pc[(k + 1 == n) ? 0 : k + 1];
+        const float ma = A.msdf_aug[a], mb = A.msdf_aug[bb];
+        float wa, wb;
+        msdf_weights(ma, mb, wa, wb);
+        const bool u = (used >> (n + k)) & 1;  // unreferenced vertices are zeroed (ref :419-423)
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                float p = A.verts_wt[(int64_t)a * 3 + d] * wa + A.verts_wt[(int64_t)bb * 3 + d] * wb;
-                A.verts_aug[(bnd + k) * 3 + d] = u ? p : 0.0f;
-            }
-            A.msdf_aug[bnd + k] = ma * wa + mb * wb;  // ref :383-384
+        for (int d = 0; d < 3; ++d) {
+            float p = A.verts_wt[(int64_t)a * 3 + d] * wa + A.verts_wt[(int64_t)bb * 3 + d] * wb;
+            A.verts_aug[(bnd + k) * 3 + d] = u ? p : 0.0f;
         }
+        A.msdf_aug[bnd + k] = ma * wa + mb * wb;  // ref :383-384
+    }
 
-        // mSDF cut (ref :395-416): group order tri->1, tri->2, quad->1..4; tet order inside a group
-        if (ncut) {
-            const int g = ntri == 1 ? (ncut - 1) : (1 + ncut);
-            int64_t row = A.gbase[g] + (int64_t)ncut * rank[2 + g];
-            for (int j = 0; j < 3 * ncut; ++j) {
-                const int loc = ntri == 1 ? c_cut_tri[ci][j] : c_cut_quad[ci][j];
-                int64_t idx;
-                if (loc < n) {
-                    idx = sel4(pc[0], pc[1], pc[2], pc[3], loc);
-                    A.used_wt[idx] = 1;
-                } else {
-                    idx = bnd + (loc - n);
-                }
-                A.faces_aug[row * 3 + j] = idx;
-                if (A.faces_aug_i32) A.faces_aug_i32[row * 3 + j] = (int32_t)idx;
+    // mSDF cut (ref :395-416): group order tri->1, tri->2, quad->1..4; tet order inside a group
+    const int ncut = ntri == 1 ? c_ncut_tri[ci] : c_ncut_quad[ci];
+    if (ncut) {
+        const int g = ntri == 1 ? (ncut - 1) : (1 + ncut);
+        int64_t row = A.gbase[g] + (int64_t)ncut * A.grp_rank[slot];
+        for (int j = 0; j < 3 * ncut; ++j) {
+            const int loc = ntri == 1 ? c_cut_tri[ci][j] : c_cut_quad[ci][j];
+            int64_t idx;
+            if (loc < n) {
+                idx = sel4(pc[0], pc[1], pc[2], pc[3], loc);
+                A.used_wt[idx] = 1;
+            } else {
+                idx = bnd + (loc - n);
             }
+            A.faces_aug[row * 3 + j] = idx;
+            if (A.faces_aug_i32) A.faces_aug_i32[row * 3 + j] = (int32_t)idx;
         }
     }
 }
@@ -606,21 +648,26 @@ extern "C" int gs_mtets_count(gs_mtets_topo* t, const float* pos, const float* s
         for (int k = 0; k < GS_MTETS_NCOUNTS; ++k) counts_host[k] = t->last_counts[k] = 0;
         return 0;
     }
-    k_occ_bits<<<gs::cdiv(t->N, 256), 256, 0, stream>>>(sdf, t->N, t->occ_bits);
-    k_edge_cross<<<t->nb_e, 256, 0, stream>>>((const int2*)t->edges, t->E, t->nchunks, t->occ_bits, t->edge_mask, t->edge_blk);
-    k_classify<<<t->nb_t, 256, 0, stream>>>((const int4*)t->tet, t->F, t->occ_bits, sdf, msdf, t->tet_code, t->tet_blk);
-    k_scan<<<1, 1024, 0, stream>>>(t->tet_blk, t->nb_t, t->edge_blk, t->nb_e, t->counts_dev);
+    unsigned long long* cnt = (unsigned long long*)t->counts_dev;
+    k_occ_bits<<<gs::cdiv(t->N, 256), 256, 0, stream>>>(sdf, t->N, t->occ_bits, cnt);
+    k_edge_cross<<<t->nb_e, 256, 0, stream>>>((const int2*)t->edges, t->E, t->nchunks, t->occ_bits, t->edge_mask, t->edge_blk, cnt);
+    k_classify<<<t->nb_t, 256, 0, stream>>>((const int4*)t->tet, t->F, t->occ_bits, sdf, msdf, t->tet_code, t->tet_blk, cnt);
     GS_LAUNCH_CHECK();
     GS_HIP_CHECK(hipMemcpyAsync(t->counts_host, t->counts_dev, sizeof(int64_t) * GS_MTETS_NCOUNTS, hipMemcpyDeviceToHost, stream));
     GS_HIP_CHECK(hipStreamSynchronize(stream));
-    for (int k = 0; k < GS_MTETS_NCOUNTS; ++k) counts_host[k] = t->last_counts[k] = t->counts_host[k];
+    int64_t* c = t->last_counts;
+    for (int k = 0; k < 9; ++k) c[k] = t->counts_host[k];
+    c[9] = c[3] + 2 * c[4] + c[5] + 2 * c[6] + 3 * c[7] + 4 * c[8];   // T
+    c[10] = c[0] + 3 * c[1] + 4 * c[2];                               // V_aug
+    for (int k = 11; k < GS_MTETS_NCOUNTS; ++k) c[k] = 0;
+    for (int k = 0; k < GS_MTETS_NCOUNTS; ++k) counts_host[k] = c[k];
     return 0;
 }
 
 extern "C" int gs_mtets_fill(gs_mtets_topo* t, const float* pos, const float* sdf, const float* msdf, float* verts_aug,
                              float* msdf_aug, float* verts_wt, int64_t* faces_wt, int64_t* faces_aug, int32_t* faces_aug_i32,
                              int32_t* vert_ab, uint8_t* used_wt, int32_t* poly, uint8_t* cut_code, int32_t* tet_id,
-                             gs_stream_t stream_) {
+                             uint8_t* sign_code, int32_t* grp_rank, gs_stream_t stream_) {
     GS_REQUIRE(t && pos && sdf && msdf, "gs_mtets_fill: null argument");
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t* c = t->last_counts;
@@ -632,19 +679,21 @@ extern "C" int gs_mtets_fill(gs_mtets_topo* t, const float* pos, const float* sd
     GS_HIP_CHECK(hipMemsetAsync(used_wt, 0, (size_t)V, stream));
     k_vertices<<<t->nb_e, 256, 0, stream>>>((const int2*)t->edges, t->nchunks, t->edge_mask, t->edge_blk, t->chunk_base, pos, sdf,
                                             msdf, verts_wt, msdf_aug, vert_ab);
+    GS_REQUIRE(grp_rank && sign_code, "gs_mtets_fill: null scratch");
+    k_compact<<<gs::cdiv(t->nb_t, MT_COMPACT_SPAN), 256, 0, stream>>>(t->tet_code, t->F, t->tet_blk, M1, tet_id, cut_code, sign_code, grp_rank);
     FillArgs A;
-    A.F = t->F; A.V = V; A.M1 = M1; A.M2 = M2;
+    A.V = V; A.M1 = M1; A.M2 = M2;
     A.gbase[0] = 0;
     A.gbase[1] = A.gbase[0] + c[3];
     A.gbase[2] = A.gbase[1] + 2 * c[4];
     A.gbase[3] = A.gbase[2] + c[5];
     A.gbase[4] = A.gbase[3] + 2 * c[6];
     A.gbase[5] = A.gbase[4] + 3 * c[7];
-    A.code = t->tet_code; A.tet_blk = t->tet_blk; A.tet_edge = t->tet_edge; A.chunk_base = t->chunk_base;
-    A.edge_mask = t->edge_mask; A.verts_wt = verts_wt; A.verts_aug = verts_aug; A.msdf_aug = msdf_aug;
-    A.faces_wt = faces_wt; A.faces_aug = faces_aug; A.faces_aug_i32 = faces_aug_i32; A.used_wt = used_wt;
-    A.poly = poly; A.cut_code = cut_code; A.tet_id = tet_id;
-    k_faces<<<t->nb_t, 256, 0, stream>>>(A);
+    A.tet_edge = t->tet_edge; A.chunk_base = t->chunk_base; A.edge_mask = t->edge_mask; A.verts_wt = verts_wt;
+    A.tet_id = tet_id; A.cut_code = cut_code; A.sign_code = sign_code; A.grp_rank = grp_rank;
+    A.verts_aug = verts_aug; A.msdf_aug = msdf_aug; A.faces_wt = faces_wt; A.faces_aug = faces_aug;
+    A.faces_aug_i32 = faces_aug_i32; A.used_wt = used_wt; A.poly = poly;
+    if (M1 + M2 > 0) k_polys<<<gs::cdiv(M1 + M2, 256), 256, 0, stream>>>(A);
     k_mask_wt<<<gs::cdiv(V * 3, 256), 256, 0, stream>>>(V, verts_wt, used_wt, verts_aug);
     GS_LAUNCH_CHECK();
     return 0;

@@ -92,9 +92,11 @@ class _MarchingTetsFn(torch.autograd.Function):
             poly = torch.empty((3 * M1 + 4 * M2,), dtype=torch.int32, device=dev)
             cut_code = torch.empty((M1 + M2,), dtype=torch.uint8, device=dev)
             tet_id = torch.empty((M1 + M2,), dtype=torch.int32, device=dev)
+            sign_code = torch.empty((M1 + M2,), dtype=torch.uint8, device=dev)
+            grp_rank = torch.empty((M1 + M2,), dtype=torch.int32, device=dev)
             check(L.gs_mtets_fill(topo.handle, ptr(pos_c), ptr(sdf_c), ptr(msdf_c), ptr(verts_aug), ptr(msdf_aug), ptr(verts_wt),
                                   ptr(faces_wt), ptr(faces_aug), ptr(faces_i32), ptr(vert_ab), ptr(used_wt), ptr(poly),
-                                  ptr(cut_code), ptr(tet_id), stream()), "gs_mtets_fill")
+                                  ptr(cut_code), ptr(tet_id), ptr(sign_code), ptr(grp_rank), stream()), "gs_mtets_fill")
             v_tng_aug = torch.zeros((V_aug, 3), **f32)
             if want_tangents and V > 0:
                 scratch = torch.empty((V, 7), **f32)

@@ -67,12 +67,14 @@ int gs_mtets_count(gs_mtets_topo* topo, const float* pos_nx3, const float* sdf_n
  * saved for backward (caller-owned):
  *   vert_ab [V,2] i32 grid endpoints of each watertight vertex, used_wt [V] u8,
  *   poly [3 M1 + 4 M2] i32 polygon corner vertex ids, cut_code [M1+M2] u8,
- *   tet_id [M1+M2] i32 source tet of each polygon.                                   */
+ *   tet_id [M1+M2] i32 source tet of each polygon,
+ *   sign_code [M1+M2] u8 SDF sign pattern, grp_rank [M1+M2] i32 rank inside the cut group
+ *   (the last two are scratch the caller may drop after the call).                    */
 int gs_mtets_fill(gs_mtets_topo* topo, const float* pos_nx3, const float* sdf_n,
                   const float* msdf_n, float* verts_aug, float* msdf_aug, float* verts_wt,
                   int64_t* faces_wt, int64_t* faces_aug, int32_t* faces_aug_i32,
                   int32_t* vert_ab, uint8_t* used_wt, int32_t* poly, uint8_t* cut_code,
-                  int32_t* tet_id, gs_stream_t stream);
+                  int32_t* tet_id, uint8_t* sign_code, int32_t* grp_rank, gs_stream_t stream);
 
 /* Backward of the extraction (autograd of gshell_tets.py:277-392).
  *   g_verts_aug [V_aug,3], g_msdf_aug [V_aug], g_verts_wt [V,3] (any may be NULL = 0)
