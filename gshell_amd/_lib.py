@@ -23,12 +23,16 @@ class GShellHipError(RuntimeError):
     pass
 
 
-def declared_symbols():
-    """All `int gs_*(` / `const char* gs_*(` entry points declared in the public header."""
+def declared_prototypes():
+    """{name: return type} of every entry point declared in the public header."""
     with open(HEADER_PATH) as f:
         src = f.read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", src)))
+    return {m.group(2): m.group(1) for m in re.finditer(r"\b(int64_t|int|const char\s*\*)\s+(gs_[a-z0-9_]+)\s*\(", src)}
+
+
+def declared_symbols():
+    return sorted(declared_prototypes())
 
 
 def lib():
@@ -43,10 +47,9 @@ def lib():
         except OSError as e:  # pragma: no cover
             raise GShellHipError(f"failed to load {LIB_PATH}: {e}") from e
         _lib.gs_last_error.restype = ctypes.c_char_p
-        for name in declared_symbols():
+        for name, ret in declared_prototypes().items():
             fn = getattr(_lib, name)          # AttributeError if the .so lacks a declared symbol
-            if name != "gs_last_error":
-                fn.restype = c_int
+            fn.restype = {"int": c_int, "int64_t": c_int64}.get(ret, ctypes.c_char_p)
     return _lib
 
 

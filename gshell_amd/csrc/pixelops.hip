@@ -1,0 +1,438 @@
+// Per-pixel / per-vertex fused ops of the G-Shell render path on gfx950 (fwd + bwd):
+//   prepare_shading_normal  replaces ru.prepare_shading_normal (render/renderutils/ops.py:197-229,
+//                           CUDA render/renderutils/c_src/normal.cu:18-181)
+//   image_loss              replaces ru.image_loss (render/renderutils/ops.py:479-503, c_src/loss.cu:15-210)
+//   auto_normals            replaces mesh.auto_normals (render/mesh.py:212-237: 3 scatter_add_ + normalise)
+//   texture_linear_clamp    replaces dr.texture(..., filter_mode='linear', boundary_mode='clamp') as used for
+//                           the jitter taps (render/render.py:59, :110)
+// All are HBM-streaming kernels: one lane per pixel / face / vertex, float3 rows read as 3 dwords
+// (12-byte rows cannot be vectorised to dwordx4 without re-laying out the reference's [..,3] tensors).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "../../include/gshell_hip.h"
+#include "common.hpp"
+
+namespace {
+
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk(float x, float y, float z) { return {x, y, z}; }
+__device__ __forceinline__ f3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float* p, f3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float sum(f3 a) { return a.x + a.y + a.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ void bwd_cross(f3 a, f3 b, f3& da, f3& db, f3 d) {
+    da.x += d.z * b.y - d.y * b.z;
+    da.y += d.x * b.z - d.z * b.x;
+    da.z += d.y * b.x - d.x * b.y;
+    db.x += d.y * a.z - d.z * a.y;
+    db.y += d.z * a.x - d.x * a.z;
+    db.z += d.x * a.y - d.y * a.x;
+}
+// reference safeNormalize: v / |v| or 0 (render/renderutils/c_src/vec3f.h:90-94)
+__device__ __forceinline__ f3 safe_normalize(f3 v) {
+    float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return l > 0.0f ? v * (1.0f / l) : mk(0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void bwd_safe_normalize(f3 v, f3& dv, f3 d) {
+    float l2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    if (l2 > 0.0f) {
+        float l = sqrtf(l2);
+        float fac = 1.0f / (l2 * l);
+        dv.x += (d.x * (v.y * v.y + v.z * v.z) - d.y * (v.x * v.y) - d.z * (v.x * v.z)) * fac;
+        dv.y += (d.y * (v.x * v.x + v.z * v.z) - d.x * (v.y * v.x) - d.z * (v.y * v.z)) * fac;
+        dv.z += (d.z * (v.x * v.x + v.y * v.y) - d.x * (v.z * v.x) - d.y * (v.z * v.y)) * fac;
+    }
+}
+
+// ---- prepare_shading_normal ---------------------------------------------------------------------
+constexpr float NORMAL_THRESHOLD = 0.1f;
+
+__device__ __forceinline__ f3 perturb_fwd(f3 pn, f3 sn, f3 st, bool opengl, f3& raw, f3& bitng_raw, f3& bitng) {
+    bitng_raw = cross(st, sn);
+    bitng = safe_normalize(bitng_raw);
+    raw = st * pn.x + bitng * ((opengl ? -1.0f : 1.0f) * pn.y) + sn * fmaxf(pn.z, 0.0f);
+    return safe_normalize(raw);
+}
+
+__device__ __forceinline__ f3 bend_fwd(f3 view, f3 sn, f3 gn) {
+    float dp = dot(view, sn);
+    float t = fminf(fmaxf(dp / NORMAL_THRESHOLD, 0.0f), 1.0f);
+    return gn * (1.0f - t) + sn * t;
+}
+
+__device__ __forceinline__ void bend_bwd(f3 view, f3 sn, f3 gn, f3& dview, f3& dsn, f3& dgn, f3 d) {
+    float dp = dot(view, sn);
+    float t = fminf(fmaxf(dp / NORMAL_THRESHOLD, 0.0f), 1.0f);
+    if (dp > NORMAL_THRESHOLD)
+        dsn = dsn + d;
+    else {
+        dgn = dgn + d * (1.0f - t);
+        dsn = dsn + d * t;
+        float dt = sum(d * (sn - gn));
+        float ddp = (dp < 0.0f || dp > NORMAL_THRESHOLD) ? 0.0f : dt / NORMAL_THRESHOLD;
+        dview = dview + sn * ddp;
+        dsn = dsn + view * ddp;
+    }
+}
+
+struct PsnArgs {
+    const float *pos, *view_pos, *perturbed, *nrm, *tng, *gnrm;
+    int64_t n, pix_per_view;  // view_pos index = view_full ? i : i / pix_per_view
+    int view_full, two_sided, opengl;
+    float* out;
+    // bwd
+    const float* g_out;
+    float *g_pos, *g_view, *g_perturbed, *g_nrm, *g_tng, *g_gnrm;
+};
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_shading_normal(PsnArgs a) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    f3 pos = ld3(a.pos + 3 * i);
+    f3 vp = ld3(a.view_pos + 3 * (a.view_full ? i : i / a.pix_per_view));
+    f3 pn = a.perturbed ? ld3(a.perturbed + 3 * i) : mk(0.f, 0.f, 1.f);
+    f3 sn_raw = ld3(a.nrm + 3 * i), st_raw = ld3(a.tng + 3 * i), gn = ld3(a.gnrm + 3 * i);
+    f3 sn = safe_normalize(sn_raw), st = safe_normalize(st_raw);
+    f3 view_raw = vp - pos;
+    f3 view = safe_normalize(view_raw);
+    f3 raw, bitng_raw, bitng;
+    f3 shn = perturb_fwd(pn, sn, st, a.opengl, raw, bitng_raw, bitng);
+    bool flip = a.two_sided && dot(view, gn) < 0.0f;
+    if (!BWD) {
+        st3(a.out + 3 * i, flip ? bend_fwd(view, -shn, -gn) : bend_fwd(view, shn, gn));
+        return;
+    }
+    f3 d = ld3(a.g_out + 3 * i);
+    f3 dview = mk(0, 0, 0), dshn = mk(0, 0, 0), dgn = mk(0, 0, 0);
+    if (flip) {
+        bend_bwd(view, -shn, -gn, dview, dshn, dgn, d);
+        dshn = -dshn;
+        dgn = -dgn;
+    } else
+        bend_bwd(view, shn, gn, dview, dshn, dgn, d);
+    // perturb bwd (normal.cu:28-61)
+    f3 draw = mk(0, 0, 0);
+    bwd_safe_normalize(raw, draw, dshn);
+    f3 dpn = mk(0, 0, 0), dsn = mk(0, 0, 0), dst = mk(0, 0, 0), dbit = mk(0, 0, 0);
+    if (pn.z > 0.0f) {
+        dsn = dsn + draw * pn.z;
+        dpn.z += sum(draw * sn);
+    }
+    float sgn = a.opengl ? -1.0f : 1.0f;
+    dbit = dbit + draw * (sgn * pn.y);
+    dpn.y += sgn * sum(draw * bitng);
+    dst = dst + draw * pn.x;
+    dpn.x += sum(draw * st);
+    f3 dbit_raw = mk(0, 0, 0);
+    bwd_safe_normalize(bitng_raw, dbit_raw, dbit);
+    bwd_cross(st, sn, dst, dsn, dbit_raw);
+    f3 dview_raw = mk(0, 0, 0), dsn_raw = mk(0, 0, 0), dst_raw = mk(0, 0, 0);
+    bwd_safe_normalize(view_raw, dview_raw, dview);
+    bwd_safe_normalize(sn_raw, dsn_raw, dsn);
+    bwd_safe_normalize(st_raw, dst_raw, dst);
+    if (a.g_pos) st3(a.g_pos + 3 * i, -dview_raw);
+    if (a.g_view) st3(a.g_view + 3 * i, dview_raw);
+    if (a.g_perturbed) st3(a.g_perturbed + 3 * i, dpn);
+    if (a.g_nrm) st3(a.g_nrm + 3 * i, dsn_raw);
+    if (a.g_tng) st3(a.g_tng + 3 * i, dst_raw);
+    if (a.g_gnrm) st3(a.g_gnrm + 3 * i, dgn);
+}
+
+// ---- image loss -------------------------------------------------------------------------------------
+enum { LOSS_L1 = 0, LOSS_MSE = 1, LOSS_RELMSE = 2, LOSS_SMAPE = 3 };
+enum { TM_NONE = 0, TM_LOG_SRGB = 1 };
+
+__device__ __forceinline__ float fwd_srgb(float x) {
+    return x > 0.0031308f ? powf(fmaxf(x, 0.0031308f), 1.0f / 2.4f) * 1.055f - 0.055f : 12.92f * fmaxf(x, 0.0f);
+}
+__device__ __forceinline__ float bwd_srgb(float x, float d) {
+    if (x > 0.0031308f) return d * 0.439583f / powf(x, 0.583333f);
+    if (x > 0.0f) return d * 12.92f;
+    return 0.0f;
+}
+__device__ __forceinline__ float tonemap(float x, int tm) {
+    float c = fminf(fmaxf(x, 0.0f), 65535.0f);
+    return tm == TM_LOG_SRGB ? fwd_srgb(logf(c + 1.0f)) : c;
+}
+// d tonemap(x) / dx * d   (torch semantics: the clamp passes gradient on the closed interval for 'none';
+// the reference CUDA kernel zeroes it outside the OPEN interval for log_srgb, loss.cu:50-66)
+__device__ __forceinline__ float tonemap_bwd(float x, int tm, float d) {
+    if (tm == TM_LOG_SRGB) {
+        if (!(x > 0.0f && x < 65535.0f)) return 0.0f;
+        return bwd_srgb(logf(x + 1.0f), d) * (1.0f / (x + 1.0f));
+    }
+    return (x >= 0.0f && x <= 65535.0f) ? d : 0.0f;
+}
+__device__ __forceinline__ float sgnf(float x) { return x == 0.0f ? 0.0f : (x < 0.0f ? -1.0f : 1.0f); }
+
+__device__ __forceinline__ float loss_fwd(float a, float b, int loss) {
+    switch (loss) {
+        case LOSS_MSE: return (a - b) * (a - b);
+        case LOSS_RELMSE: return (a - b) * (a - b) / (a * a + b * b + 0.1f);
+        case LOSS_SMAPE: return fabsf(a - b) / (a + b + 0.01f);
+        default: return fabsf(a - b);
+    }
+}
+__device__ __forceinline__ void loss_bwd(float a, float b, int loss, float d, float& da, float& db) {
+    switch (loss) {
+        case LOSS_MSE:
+            da = d * 2.0f * (a - b);
+            db = -da;
+            break;
+        case LOSS_RELMSE: {
+            float den = b * b + a * a + 0.1f;
+            da = d * 2.0f * (a - b) * (b * (b + a) + 0.1f) / (den * den);
+            db = -d * 2.0f * (a - b) * (a * (b + a) + 0.1f) / (den * den);
+            break;
+        }
+        case LOSS_SMAPE: {
+            float den = b + a + 0.01f;
+            da = d * sgnf(a - b) * (2.0f * b + 0.01f) / (den * den);
+            db = -d * sgnf(a - b) * (2.0f * a + 0.01f) / (den * den);
+            break;
+        }
+        default:
+            da = d * sgnf(a - b);
+            db = -da;
+    }
+}
+
+// partial[blockIdx] = sum over the block's elements (wave64 shuffle reduction, then 4 waves through LDS)
+__global__ void __launch_bounds__(256) k_image_loss_fwd(const float* __restrict__ img, const float* __restrict__ target, int64_t n, int loss,
+                                                        int tm, float* __restrict__ partial) {
+    int64_t i0 = (int64_t)blockIdx.x * 1024;
+    float acc = 0.f;
+    for (int k = 0; k < 4; ++k) {
+        int64_t i = i0 + k * 256 + threadIdx.x;
+        if (i < n) acc += loss_fwd(tonemap(img[i], tm), tonemap(target[i], tm), loss);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    __shared__ float ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+__global__ void __launch_bounds__(256) k_image_loss_bwd(const float* __restrict__ img, const float* __restrict__ target, int64_t n, int loss,
+                                                        int tm, const float* __restrict__ g_scalar, float scale, float* __restrict__ g_img,
+                                                        float* __restrict__ g_target) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float d = g_scalar[0] * scale;
+    float x = img[i], y = target[i];
+    float da, db;
+    loss_bwd(tonemap(x, tm), tonemap(y, tm), loss, d, da, db);
+    if (g_img) g_img[i] = tonemap_bwd(x, tm, da);
+    if (g_target) g_target[i] = tonemap_bwd(y, tm, db);
+}
+
+// ---- auto normals -----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_face_normals_scatter(const float* __restrict__ v, const int32_t* __restrict__ tri, int64_t T,
+                                                              float* __restrict__ acc) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    int64_t i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+    f3 v0 = ld3(v + 3 * i0), v1 = ld3(v + 3 * i1), v2 = ld3(v + 3 * i2);
+    f3 n = cross(v1 - v0, v2 - v0);
+    int64_t idx[3] = {i0, i1, i2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        atomicAdd(&acc[3 * idx[k] + 0], n.x);
+        atomicAdd(&acc[3 * idx[k] + 1], n.y);
+        atomicAdd(&acc[3 * idx[k] + 2], n.z);
+    }
+}
+
+// v_nrm = safe_normalize(where(dot > 1e-20, acc, (0,0,1)));  util.safe_normalize = x / sqrt(max(dot, 1e-20))
+__global__ void __launch_bounds__(256) k_vertex_normalize(const float* __restrict__ acc, int64_t V, float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    f3 a = ld3(acc + 3 * i);
+    float d = dot(a, a);
+    if (!(d > 1e-20f)) {
+        a = mk(0.f, 0.f, 1.f);
+        d = 1.0f;
+    }
+    float l = sqrtf(fmaxf(d, 1e-20f));
+    st3(out + 3 * i, mk(a.x / l, a.y / l, a.z / l));
+}
+
+__global__ void __launch_bounds__(256) k_vertex_normalize_bwd(const float* __restrict__ acc, int64_t V, const float* __restrict__ g_out,
+                                                              float* __restrict__ g_acc) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    f3 a = ld3(acc + 3 * i);
+    float d = dot(a, a);
+    f3 g = mk(0, 0, 0);
+    if (d > 1e-20f) {
+        f3 go = ld3(g_out + 3 * i);
+        float l = sqrtf(d);
+        float il = 1.0f / l;
+        float proj = dot(go, a) * il * il * il;   // d/da (a/|a|) = (I - a a^T / |a|^2) / |a|
+        g = go * il - a * proj;
+    }
+    st3(g_acc + 3 * i, g);
+}
+
+__global__ void __launch_bounds__(256) k_face_normals_bwd(const float* __restrict__ v, const int32_t* __restrict__ tri, int64_t T,
+                                                          const float* __restrict__ g_acc, float* __restrict__ g_v) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    int64_t i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+    f3 v0 = ld3(v + 3 * i0), v1 = ld3(v + 3 * i1), v2 = ld3(v + 3 * i2);
+    f3 gn = ld3(g_acc + 3 * i0) + ld3(g_acc + 3 * i1) + ld3(g_acc + 3 * i2);
+    f3 da = mk(0, 0, 0), db = mk(0, 0, 0);
+    bwd_cross(v1 - v0, v2 - v0, da, db, gn);
+    f3 d0 = -(da + db);
+    atomicAdd(&g_v[3 * i0 + 0], d0.x);
+    atomicAdd(&g_v[3 * i0 + 1], d0.y);
+    atomicAdd(&g_v[3 * i0 + 2], d0.z);
+    atomicAdd(&g_v[3 * i1 + 0], da.x);
+    atomicAdd(&g_v[3 * i1 + 1], da.y);
+    atomicAdd(&g_v[3 * i1 + 2], da.z);
+    atomicAdd(&g_v[3 * i2 + 0], db.x);
+    atomicAdd(&g_v[3 * i2 + 1], db.y);
+    atomicAdd(&g_v[3 * i2 + 2], db.z);
+}
+
+// ---- bilinear texture tap, clamp addressing ----------------------------------------------------------
+// texel centres at (i + .5) / W ;  tex [B,H,W,C], uv [B,h,w,2] -> out [B,h,w,C]
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_texture_linear(const float* __restrict__ tex, int64_t B, int H, int W, int C,
+                                                        const float* __restrict__ uv, int64_t n_per_view, float* __restrict__ out,
+                                                        const float* __restrict__ g_out, float* __restrict__ g_tex) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * n_per_view) return;
+    int64_t b = i / n_per_view;
+    float x = uv[2 * i] * (float)W - 0.5f, y = uv[2 * i + 1] * (float)H - 0.5f;
+    float xf = floorf(x), yf = floorf(y);
+    float fx = x - xf, fy = y - yf;
+    int x0 = min(max((int)xf, 0), W - 1), x1 = min(max((int)xf + 1, 0), W - 1);
+    int y0 = min(max((int)yf, 0), H - 1), y1 = min(max((int)yf + 1, 0), H - 1);
+    float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
+    int64_t base = b * (int64_t)H * W;
+    int64_t o00 = (base + (int64_t)y0 * W + x0) * C, o10 = (base + (int64_t)y0 * W + x1) * C;
+    int64_t o01 = (base + (int64_t)y1 * W + x0) * C, o11 = (base + (int64_t)y1 * W + x1) * C;
+    for (int c = 0; c < C; ++c) {
+        if (!BWD)
+            out[i * C + c] = tex[o00 + c] * w00 + tex[o10 + c] * w10 + tex[o01 + c] * w01 + tex[o11 + c] * w11;
+        else {
+            float g = g_out[i * C + c];
+            if (g != 0.0f) {
+                atomicAdd(&g_tex[o00 + c], g * w00);
+                atomicAdd(&g_tex[o10 + c], g * w10);
+                atomicAdd(&g_tex[o01 + c], g * w01);
+                atomicAdd(&g_tex[o11 + c], g * w11);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gs_shading_normal_fwd(const float* pos, const float* view_pos, int view_full, const float* perturbed_nrm, const float* smooth_nrm,
+                                     const float* smooth_tng, const float* geom_nrm, int64_t B, int64_t pix_per_view, int two_sided, int opengl,
+                                     float* out, gs_stream_t stream) {
+    int64_t n = B * pix_per_view;
+    if (n == 0) return 0;
+    GS_REQUIRE(pos && view_pos && smooth_nrm && smooth_tng && geom_nrm && out, "gs_shading_normal_fwd: null pointer");
+    PsnArgs a{};
+    a.pos = pos; a.view_pos = view_pos; a.perturbed = perturbed_nrm; a.nrm = smooth_nrm; a.tng = smooth_tng; a.gnrm = geom_nrm;
+    a.n = n; a.pix_per_view = pix_per_view; a.view_full = view_full; a.two_sided = two_sided; a.opengl = opengl; a.out = out;
+    hipLaunchKernelGGL(k_shading_normal<false>, dim3((unsigned)gs::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_shading_normal_bwd(const float* pos, const float* view_pos, int view_full, const float* perturbed_nrm, const float* smooth_nrm,
+                                     const float* smooth_tng, const float* geom_nrm, int64_t B, int64_t pix_per_view, int two_sided, int opengl,
+                                     const float* g_out, float* g_pos, float* g_view_pos_full, float* g_perturbed_nrm, float* g_smooth_nrm,
+                                     float* g_smooth_tng, float* g_geom_nrm, gs_stream_t stream) {
+    int64_t n = B * pix_per_view;
+    if (n == 0) return 0;
+    GS_REQUIRE(pos && view_pos && smooth_nrm && smooth_tng && geom_nrm && g_out, "gs_shading_normal_bwd: null pointer");
+    PsnArgs a{};
+    a.pos = pos; a.view_pos = view_pos; a.perturbed = perturbed_nrm; a.nrm = smooth_nrm; a.tng = smooth_tng; a.gnrm = geom_nrm;
+    a.n = n; a.pix_per_view = pix_per_view; a.view_full = view_full; a.two_sided = two_sided; a.opengl = opengl;
+    a.g_out = g_out; a.g_pos = g_pos; a.g_view = g_view_pos_full; a.g_perturbed = g_perturbed_nrm; a.g_nrm = g_smooth_nrm;
+    a.g_tng = g_smooth_tng; a.g_gnrm = g_geom_nrm;
+    hipLaunchKernelGGL(k_shading_normal<true>, dim3((unsigned)gs::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t gs_image_loss_partials(int64_t n) { return gs::cdiv(std::max<int64_t>(n, 1), 1024); }
+
+extern "C" int gs_image_loss_fwd(const float* img, const float* target, int64_t n, int loss, int tonemapper, float* partials,
+                                 gs_stream_t stream) {
+    GS_REQUIRE(loss >= 0 && loss <= 3 && tonemapper >= 0 && tonemapper <= 1, "gs_image_loss_fwd: bad loss / tonemapper id");
+    GS_REQUIRE(partials && (n == 0 || (img && target)), "gs_image_loss_fwd: null pointer");
+    hipLaunchKernelGGL(k_image_loss_fwd, dim3((unsigned)gs_image_loss_partials(n)), dim3(256), 0, (hipStream_t)stream, img, target, n, loss,
+                       tonemapper, partials);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_image_loss_bwd(const float* img, const float* target, int64_t n, int loss, int tonemapper, const float* g_scalar_dev,
+                                 float scale, float* g_img, float* g_target, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_REQUIRE(loss >= 0 && loss <= 3 && tonemapper >= 0 && tonemapper <= 1, "gs_image_loss_bwd: bad loss / tonemapper id");
+    GS_REQUIRE(img && target && g_scalar_dev, "gs_image_loss_bwd: null pointer");
+    hipLaunchKernelGGL(k_image_loss_bwd, dim3((unsigned)gs::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, img, target, n, loss, tonemapper,
+                       g_scalar_dev, scale, g_img, g_target);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_auto_normals_fwd(const float* v_pos, int64_t V, const int32_t* tri, int64_t T, float* acc, float* v_nrm, gs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (V == 0) return 0;
+    GS_REQUIRE(v_pos && acc && v_nrm && (T == 0 || tri), "gs_auto_normals_fwd: null pointer");
+    GS_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)V * 12, stream));
+    if (T > 0) hipLaunchKernelGGL(k_face_normals_scatter, dim3((unsigned)gs::cdiv(T, 256)), dim3(256), 0, stream, v_pos, tri, T, acc);
+    hipLaunchKernelGGL(k_vertex_normalize, dim3((unsigned)gs::cdiv(V, 256)), dim3(256), 0, stream, acc, V, v_nrm);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_auto_normals_bwd(const float* v_pos, int64_t V, const int32_t* tri, int64_t T, const float* acc, const float* g_nrm,
+                                   float* g_acc, float* g_pos, gs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (V == 0) return 0;
+    GS_REQUIRE(v_pos && acc && g_nrm && g_acc && g_pos && (T == 0 || tri), "gs_auto_normals_bwd: null pointer");
+    hipLaunchKernelGGL(k_vertex_normalize_bwd, dim3((unsigned)gs::cdiv(V, 256)), dim3(256), 0, stream, acc, V, g_nrm, g_acc);
+    if (T > 0) hipLaunchKernelGGL(k_face_normals_bwd, dim3((unsigned)gs::cdiv(T, 256)), dim3(256), 0, stream, v_pos, tri, T, g_acc, g_pos);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_texture_linear_fwd(const float* tex, int64_t B, int64_t H, int64_t W, int64_t C, const float* uv, int64_t n_per_view,
+                                     float* out, gs_stream_t stream) {
+    if (B * n_per_view == 0 || C == 0) return 0;
+    GS_REQUIRE(tex && uv && out && H > 0 && W > 0, "gs_texture_linear_fwd: null pointer / empty texture");
+    hipLaunchKernelGGL(k_texture_linear<false>, dim3((unsigned)gs::cdiv(B * n_per_view, 256)), dim3(256), 0, (hipStream_t)stream, tex, B, (int)H,
+                       (int)W, (int)C, uv, n_per_view, out, (const float*)nullptr, (float*)nullptr);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_texture_linear_bwd(int64_t B, int64_t H, int64_t W, int64_t C, const float* uv, int64_t n_per_view, const float* g_out,
+                                     float* g_tex, gs_stream_t stream) {
+    if (B * n_per_view == 0 || C == 0) return 0;
+    GS_REQUIRE(uv && g_out && g_tex, "gs_texture_linear_bwd: null pointer");
+    hipLaunchKernelGGL(k_texture_linear<true>, dim3((unsigned)gs::cdiv(B * n_per_view, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)nullptr, B, (int)H, (int)W, (int)C, uv, n_per_view, (float*)nullptr, g_out, g_tex);
+    GS_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,294 @@
+"""Rasterise / interpolate / antialias / texture ops with the call surface the reference uses from
+`nvdiffrast.torch` (imported as `dr` in render/render.py:13), backed by the HIP kernels in
+gshell_amd/csrc/{raster,antialias,texture}.hip through the C ABI (include/gshell_hip.h).
+
+Covered call sites of the reference (everything the G-Shell training path touches):
+    dr.RasterizeGLContext() / dr.RasterizeCudaContext()          train_gshelltet_*.py:625
+    dr.DepthPeeler(ctx, pos, tri, res).rasterize_next_layer()    render/render.py:377-379 (first layer only)
+    dr.rasterize(ctx, pos, tri, res)                             render/render.py:458
+    dr.interpolate(attr, rast, tri, rast_db=, diff_attrs=)       render/render.py:25-26
+    dr.antialias(color, rast, pos, tri)                          render/render.py:358
+    dr.texture(tex, uv, filter_mode='linear', boundary_mode='clamp')   render/render.py:59, :110
+
+There is no CPU / eager fallback: tensors must live in HBM and the HIP library must load.
+"""
+import torch
+
+from .. import _lib
+from .._lib import c_int64, c_void_p, check, ptr, stream
+
+
+def _scratch(nbytes, device):
+    return torch.empty((max(int(nbytes), 8) + 7) // 8, dtype=torch.int64, device=device)
+
+
+class RasterizeContext:
+    """Stateless stand-in for dr.RasterizeGLContext / dr.RasterizeCudaContext (no GL, no interop)."""
+
+    def __init__(self, output_db=True, mode=None, device=None):
+        self.output_db = output_db
+
+
+RasterizeGLContext = RasterizeContext
+RasterizeCudaContext = RasterizeContext
+
+
+def _check_mesh(pos, tri):
+    if pos.dim() != 3 or pos.shape[-1] != 4:
+        raise _lib.GShellHipError(f"pos must be [B,V,4] clip-space (instanced mode), got {tuple(pos.shape)}")
+    if tri.dim() != 2 or tri.shape[-1] != 3 or tri.dtype != torch.int32:
+        raise _lib.GShellHipError(f"tri must be int32 [T,3], got {tri.dtype} {tuple(tri.shape)}")
+
+
+class _RasterizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, tri, H, W, want_visible):
+        _check_mesh(pos, tri)
+        L = _lib.lib()
+        pos_c = pos.detach().contiguous().float()
+        tri_c = tri.contiguous()
+        B, V, T = pos_c.shape[0], pos_c.shape[1], tri_c.shape[0]
+        dev = pos_c.device
+        with torch.cuda.device(dev):
+            rast = torch.empty((B, H, W, 4), dtype=torch.float32, device=dev)
+            rast_db = torch.empty((B, H, W, 4), dtype=torch.float32, device=dev)
+            vis = torch.zeros((T,), dtype=torch.uint8, device=dev) if want_visible else None
+            scratch = _scratch(L.gs_rasterize_scratch_bytes(c_int64(B), c_int64(T), c_int64(H), c_int64(W)), dev)
+            check(L.gs_rasterize_fwd(ptr(pos_c, torch.float32, "pos"), c_int64(B), c_int64(V), ptr(tri_c, torch.int32, "tri"), c_int64(T),
+                                     c_int64(H), c_int64(W), ptr(scratch), ptr(rast), ptr(rast_db), ptr(vis), stream()), "gs_rasterize_fwd")
+        ctx.save_for_backward(pos_c, tri_c, rast)
+        ctx.dims = (B, V, T, H, W)
+        ctx.mark_non_differentiable(rast_db)
+        if want_visible:
+            ctx.mark_non_differentiable(vis)
+            return rast, rast_db, vis
+        return rast, rast_db
+
+    @staticmethod
+    def backward(ctx, g_rast, *_):
+        pos_c, tri_c, rast = ctx.saved_tensors
+        B, V, T, H, W = ctx.dims
+        g_pos = torch.zeros_like(pos_c)
+        if g_rast is not None and T > 0:
+            g = g_rast.contiguous().float()
+            with torch.cuda.device(pos_c.device):
+                check(_lib.lib().gs_rasterize_bwd(ptr(pos_c), c_int64(B), c_int64(V), ptr(tri_c), c_int64(T), c_int64(H), c_int64(W), ptr(rast),
+                                                  ptr(g), ptr(g_pos), stream()), "gs_rasterize_bwd")
+        return g_pos, None, None, None, None
+
+
+def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True, return_visible=False):
+    """-> (rast [B,H,W,4], rast_db [B,H,W,4]) [, tri_visible [T] uint8]."""
+    if ranges is not None:
+        raise NotImplementedError("range mode is not used by the reference and is not implemented")
+    H, W = int(resolution[0]), int(resolution[1])
+    return _RasterizeFn.apply(pos, tri, H, W, bool(return_visible))
+
+
+class DepthPeeler:
+    """First (nearest) layer only: the reference asserts num_layers == 1 (render/render.py:378)."""
+
+    def __init__(self, glctx, pos, tri, resolution):
+        self._args = (glctx, pos, tri, resolution)
+        self._layer = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def rasterize_next_layer(self):
+        if self._layer > 0:
+            raise NotImplementedError("depth peeling beyond the first layer is not exercised by the reference (render.py:378)")
+        self._layer += 1
+        return rasterize(*self._args)
+
+
+class _InterpolateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, attr, rast, tri, rast_db):
+        L = _lib.lib()
+        if attr.dim() == 2:
+            attr = attr[None]
+        attr_c = attr.detach().contiguous().float()
+        rast_c = rast.detach().contiguous().float()
+        tri_c = tri.contiguous()
+        if tri_c.dtype != torch.int32:
+            raise _lib.GShellHipError("tri must be int32")
+        Ba, V, A = attr_c.shape
+        B, H, W, _ = rast_c.shape
+        T = tri_c.shape[0]
+        dev = rast_c.device
+        with torch.cuda.device(dev):
+            out = torch.empty((B, H, W, A), dtype=torch.float32, device=dev)
+            db_c = rast_db.detach().contiguous().float() if rast_db is not None else None
+            out_da = torch.empty((B, H, W, 2 * A), dtype=torch.float32, device=dev) if rast_db is not None else None
+            check(L.gs_interpolate_fwd(ptr(attr_c, torch.float32, "attr"), c_int64(Ba), c_int64(V), c_int64(A), ptr(rast_c), ptr(db_c),
+                                       ptr(tri_c), c_int64(T), c_int64(B), c_int64(H), c_int64(W), ptr(out), ptr(out_da), stream()),
+                  "gs_interpolate_fwd")
+        ctx.save_for_backward(attr_c, rast_c, tri_c)
+        ctx.attr_shape = attr.shape
+        ctx.need = (attr.requires_grad, rast.requires_grad)
+        if out_da is None:
+            return out
+        ctx.mark_non_differentiable(out_da)
+        return out, out_da
+
+    @staticmethod
+    def backward(ctx, g_out, *_):
+        attr_c, rast_c, tri_c = ctx.saved_tensors
+        Ba, V, A = attr_c.shape
+        B, H, W, _ = rast_c.shape
+        T = tri_c.shape[0]
+        need_attr, need_rast = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_attr = torch.zeros_like(attr_c) if need_attr else None
+        g_rast = torch.empty_like(rast_c) if need_rast else None
+        g = g_out.contiguous().float()
+        with torch.cuda.device(rast_c.device):
+            check(_lib.lib().gs_interpolate_bwd(ptr(attr_c), c_int64(Ba), c_int64(V), c_int64(A), ptr(rast_c), ptr(tri_c), c_int64(T), c_int64(B),
+                                                c_int64(H), c_int64(W), ptr(g), ptr(g_attr), ptr(g_rast), stream()), "gs_interpolate_bwd")
+        if g_attr is not None:
+            g_attr = g_attr.reshape(ctx.attr_shape)
+        return g_attr, g_rast, None, None
+
+
+def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
+    """-> (out [B,H,W,A], out_da [B,H,W,2A] or None); diff_attrs must be None or 'all'."""
+    if diff_attrs not in (None, 'all'):
+        raise NotImplementedError("diff_attrs subsets are not used by the reference")
+    if rast_db is not None and diff_attrs == 'all':
+        out, out_da = _InterpolateFn.apply(attr, rast, tri, rast_db)
+        return out, out_da
+    return _InterpolateFn.apply(attr, rast, tri, None), None
+
+
+# ---- antialias -------------------------------------------------------------------------------------
+
+class AATopology:
+    """Per-mesh triangle adjacency (opposite vertex across each edge); replaces nvdiffrast's
+    per-call topology hash (antialias_construct_topology_hash)."""
+
+    def __init__(self, tri, num_verts):
+        tri = tri.contiguous()
+        T = tri.shape[0]
+        self.opp = torch.empty((T, 3), dtype=torch.int32, device=tri.device)
+        if T > 0:
+            L = _lib.lib()
+            with torch.cuda.device(tri.device):
+                scratch = _scratch(L.gs_tri_adjacency_scratch_bytes(c_int64(T)), tri.device)
+                check(L.gs_tri_adjacency(ptr(tri, torch.int32, "tri"), c_int64(T), c_int64(int(num_verts)), ptr(scratch), ptr(self.opp), stream()),
+                      "gs_tri_adjacency")
+
+
+def aa_analyze(rast, pos, tri, topo):
+    """alpha [B,H,W,2] (no grad; gradients w.r.t. pos flow through `_AntialiasFn`)."""
+    L = _lib.lib()
+    pos_c, rast_c = pos.detach().contiguous().float(), rast.detach().contiguous().float()
+    B, H, W, _ = rast_c.shape
+    alpha = torch.empty((B, H, W, 2), dtype=torch.float32, device=rast_c.device)
+    with torch.cuda.device(rast_c.device):
+        check(L.gs_aa_analyze(ptr(pos_c), c_int64(pos_c.shape[0]), c_int64(pos_c.shape[1]), ptr(tri), c_int64(tri.shape[0]), ptr(topo.opp),
+                              ptr(rast_c), c_int64(H), c_int64(W), ptr(alpha), stream()), "gs_aa_analyze")
+    return alpha
+
+
+class _AntialiasFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, pos, rast, tri, topo, alpha):
+        L = _lib.lib()
+        color_c = color.detach().contiguous().float()
+        B, H, W, C = color_c.shape
+        if alpha is None:
+            alpha = aa_analyze(rast, pos, tri, topo)
+        out = torch.empty_like(color_c)
+        with torch.cuda.device(color_c.device):
+            check(L.gs_aa_apply_fwd(ptr(color_c, torch.float32, "color"), ptr(alpha), c_int64(B), c_int64(H), c_int64(W), c_int64(C), ptr(out),
+                                    stream()), "gs_aa_apply_fwd")
+        ctx.save_for_backward(color_c, alpha, pos.detach().contiguous().float(), rast.detach().contiguous().float(), tri, topo.opp)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        color_c, alpha, pos_c, rast_c, tri, opp = ctx.saved_tensors
+        L = _lib.lib()
+        B, H, W, C = color_c.shape
+        need_color, need_pos = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g = g_out.contiguous().float()
+        g_color = torch.empty_like(color_c) if need_color else None
+        g_alpha = torch.empty_like(alpha) if need_pos else None
+        g_pos = None
+        with torch.cuda.device(color_c.device):
+            check(L.gs_aa_apply_bwd(ptr(color_c), ptr(alpha), c_int64(B), c_int64(H), c_int64(W), c_int64(C), ptr(g), ptr(g_color), ptr(g_alpha),
+                                    stream()), "gs_aa_apply_bwd")
+            if need_pos:
+                g_pos = torch.zeros_like(pos_c)
+                check(L.gs_aa_analyze_bwd(ptr(pos_c), c_int64(pos_c.shape[0]), c_int64(pos_c.shape[1]), ptr(tri), c_int64(tri.shape[0]), ptr(opp),
+                                          ptr(rast_c), c_int64(H), c_int64(W), ptr(alpha), ptr(g_alpha), ptr(g_pos), stream()),
+                      "gs_aa_analyze_bwd")
+        return g_color, g_pos, None, None, None, None
+
+
+_aa_cache = {"key": None, "topo": None, "alpha": None}
+
+
+def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):
+    """dr.antialias drop-in.  The adjacency table and the silhouette analysis are cached across the
+    per-buffer calls of one render (same rast / pos / tri tensors)."""
+    if pos_gradient_boost != 1.0:
+        raise NotImplementedError("pos_gradient_boost is not used by the reference")
+    if tri.shape[0] == 0:
+        return color
+    key = (rast.data_ptr(), rast._version, pos.data_ptr(), pos._version, tri.data_ptr(), tuple(rast.shape), tuple(tri.shape))
+    if _aa_cache["key"] != key:
+        topo = topology_hash if isinstance(topology_hash, AATopology) else AATopology(tri, pos.shape[1])
+        _aa_cache.update(key=key, topo=topo, alpha=aa_analyze(rast, pos, tri, topo))
+    return _AntialiasFn.apply(color, pos, rast, tri, _aa_cache["topo"], _aa_cache["alpha"])
+
+
+def antialias_stacked(colors, rast, pos, tri, topo=None):
+    """Antialias several [B,H,W,Ci] buffers with ONE analysis and ONE apply launch (channels stacked)."""
+    if tri.shape[0] == 0:
+        return list(colors)
+    if topo is None:
+        topo = AATopology(tri, pos.shape[1])
+    sizes = [c.shape[-1] for c in colors]
+    out = _AntialiasFn.apply(torch.cat(colors, dim=-1), pos, rast, tri, topo, None)
+    return list(torch.split(out, sizes, dim=-1))
+
+
+# ---- texture (bilinear, clamp) ----------------------------------------------------------------------
+
+class _TextureLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tex, uv):
+        tex_c, uv_c = tex.detach().contiguous().float(), uv.detach().contiguous().float()
+        B, H, W, C = tex_c.shape
+        if uv_c.shape[0] != B or uv_c.shape[-1] != 2:
+            raise _lib.GShellHipError(f"texture: uv {tuple(uv_c.shape)} does not match tex {tuple(tex_c.shape)}")
+        n = uv_c[0].numel() // 2
+        out = torch.empty(tuple(uv_c.shape[:-1]) + (C,), dtype=torch.float32, device=tex_c.device)
+        with torch.cuda.device(tex_c.device):
+            check(_lib.lib().gs_texture_linear_fwd(ptr(tex_c, torch.float32, "tex"), c_int64(B), c_int64(H), c_int64(W), c_int64(C),
+                                                   ptr(uv_c, torch.float32, "uv"), c_int64(n), ptr(out), stream()), "gs_texture_linear_fwd")
+        ctx.save_for_backward(uv_c)
+        ctx.dims = (B, H, W, C, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (uv_c,) = ctx.saved_tensors
+        B, H, W, C, n = ctx.dims
+        g = g_out.contiguous().float()
+        g_tex = torch.zeros((B, H, W, C), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            check(_lib.lib().gs_texture_linear_bwd(c_int64(B), c_int64(H), c_int64(W), c_int64(C), ptr(uv_c), c_int64(n), ptr(g), ptr(g_tex),
+                                                   stream()), "gs_texture_linear_bwd")
+        return g_tex, None
+
+
+def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='auto', boundary_mode='wrap', max_mip_level=None):
+    """Only the form the G-Shell path uses: bilinear, clamp, no mips (render/render.py:59, :110)."""
+    if filter_mode not in ('linear', 'auto') or boundary_mode != 'clamp' or uv_da is not None or mip is not None:
+        raise NotImplementedError("only filter_mode='linear', boundary_mode='clamp' without mipmaps is used on the G-Shell path")
+    return _TextureLinearFn.apply(tex, uv)

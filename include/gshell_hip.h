@@ -95,6 +95,132 @@ int gs_mtets_tangents(int64_t V, int64_t M1, int64_t M2, int64_t F, const float*
                       const float* lin, int64_t Nuv, float* scratch, float* v_tng_aug,
                       gs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Vertex transform   (replaces ru.xfm_points, render/renderutils/ops.py:518-537;
+ *                     CUDA kernels render/renderutils/c_src/mesh.cu:22-94)
+ *   pts [Bp,V,3] (Bp = 1 or B), mtx [B,4,4] row-major -> out [B,V,4] = [p,1] . M^T
+ *   bwd: g_pts is WRITTEN (summed over views when Bp == 1).
+ * ---------------------------------------------------------------------------------- */
+int gs_xfm_points_fwd(const float* pts, int64_t Bp, const float* mtx, int64_t B, int64_t V,
+                      float* out, gs_stream_t stream);
+int gs_xfm_points_bwd(const float* g_out, int64_t Bp, const float* mtx, int64_t B, int64_t V,
+                      float* g_pts, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Rasterise   (replaces nvdiffrast dr.DepthPeeler(...).rasterize_next_layer() /
+ *              dr.rasterize as called at render/render.py:377-379, :458)
+ *   pos_clip [B,V,4] f32, tri [T,3] i32 -> rast [B,H,W,4] = (u, v, z/w, id+1),
+ *   rast_db [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY) (may be NULL),
+ *   tri_visible [T] u8 (may be NULL; caller zero-fills; set to 1 for ids that own a pixel:
+ *   replaces rast[...,-1].long().unique(), render/render.py:380-383).
+ *   scratch: gs_rasterize_scratch_bytes(B,T,H,W) bytes, caller-owned, contents undefined.
+ *   bwd: g_rast [B,H,W,4] (only u,v components used) -> g_pos [B,V,4] ACCUMULATED.
+ * ---------------------------------------------------------------------------------- */
+int64_t gs_rasterize_scratch_bytes(int64_t B, int64_t T, int64_t H, int64_t W);
+int gs_rasterize_fwd(const float* pos_clip, int64_t B, int64_t V, const int32_t* tri, int64_t T,
+                     int64_t H, int64_t W, void* scratch, float* rast, float* rast_db,
+                     uint8_t* tri_visible, gs_stream_t stream);
+int gs_rasterize_bwd(const float* pos_clip, int64_t B, int64_t V, const int32_t* tri, int64_t T,
+                     int64_t H, int64_t W, const float* rast, const float* g_rast, float* g_pos,
+                     gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Interpolate   (replaces dr.interpolate, render/render.py:25-26 and its call sites
+ *                :240, :248, :263, :275, :306)
+ *   attr [Ba,V,A] (Ba = 1 or B) -> out [B,H,W,A]; out_da [B,H,W,2A] = (d/dX, d/dY) per
+ *   attribute if out_da && rast_db.  bwd: g_attr ACCUMULATED (may be NULL), g_rast WRITTEN
+ *   as (d/du, d/dv, 0, 0) (may be NULL).  out_da carries no gradient (the reference only
+ *   uses it under no_grad, render/render.py:272-279).
+ * ---------------------------------------------------------------------------------- */
+int gs_interpolate_fwd(const float* attr, int64_t Ba, int64_t V, int64_t A, const float* rast,
+                       const float* rast_db, const int32_t* tri, int64_t T, int64_t B, int64_t H,
+                       int64_t W, float* out, float* out_da, gs_stream_t stream);
+int gs_interpolate_bwd(const float* attr, int64_t Ba, int64_t V, int64_t A, const float* rast,
+                       const int32_t* tri, int64_t T, int64_t B, int64_t H, int64_t W,
+                       const float* g_out, float* g_attr, float* g_rast, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Antialias   (replaces dr.antialias, render/render.py:352-359 composite_buffer; the
+ *              reference calls it once per buffer key, :417-433)
+ *   gs_tri_adjacency : opp [T,3] i32 = vertex opposite edge e in the neighbouring triangle
+ *                      (-1 unless exactly two triangles share the edge)
+ *   gs_aa_analyze    : alpha [B,H,W,2] blend factor of the (right, down) pixel pair
+ *   gs_aa_apply_fwd  : out [B,H,W,C] = color + blends (C = any number of stacked channels)
+ *   gs_aa_apply_bwd  : g_color [B,H,W,C] WRITTEN, g_alpha [B,H,W,2] WRITTEN (either may be NULL)
+ *   gs_aa_analyze_bwd: g_pos [B,V,4] ACCUMULATED
+ * ---------------------------------------------------------------------------------- */
+int64_t gs_tri_adjacency_scratch_bytes(int64_t T);
+int gs_tri_adjacency(const int32_t* tri, int64_t T, int64_t V, void* scratch, int32_t* opp,
+                     gs_stream_t stream);
+int gs_aa_analyze(const float* pos_clip, int64_t B, int64_t V, const int32_t* tri, int64_t T,
+                  const int32_t* opp, const float* rast, int64_t H, int64_t W, float* alpha,
+                  gs_stream_t stream);
+int gs_aa_apply_fwd(const float* color, const float* alpha, int64_t B, int64_t H, int64_t W,
+                    int64_t C, float* out, gs_stream_t stream);
+int gs_aa_apply_bwd(const float* color, const float* alpha, int64_t B, int64_t H, int64_t W,
+                    int64_t C, const float* g_out, float* g_color, float* g_alpha,
+                    gs_stream_t stream);
+int gs_aa_analyze_bwd(const float* pos_clip, int64_t B, int64_t V, const int32_t* tri, int64_t T,
+                      const int32_t* opp, const float* rast, int64_t H, int64_t W,
+                      const float* alpha, const float* g_alpha, float* g_pos, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * prepare_shading_normal   (replaces ru.prepare_shading_normal, render/renderutils/ops.py:197-229;
+ *                           CUDA render/renderutils/c_src/normal.cu:18-181)
+ *   all tensors [B*pix_per_view, 3]; view_pos is [B,3] (view_full = 0) or per pixel (view_full = 1);
+ *   perturbed_nrm may be NULL (= (0,0,1), the G-Shell case: material['no_perturbed_nrm']).
+ *   bwd: every g_* pointer may be NULL; all are WRITTEN per pixel (g_view_pos_full is per pixel
+ *   even when view_full = 0: the caller reduces it).
+ * ---------------------------------------------------------------------------------- */
+int gs_shading_normal_fwd(const float* pos, const float* view_pos, int view_full,
+                          const float* perturbed_nrm, const float* smooth_nrm,
+                          const float* smooth_tng, const float* geom_nrm, int64_t B,
+                          int64_t pix_per_view, int two_sided, int opengl, float* out,
+                          gs_stream_t stream);
+int gs_shading_normal_bwd(const float* pos, const float* view_pos, int view_full,
+                          const float* perturbed_nrm, const float* smooth_nrm,
+                          const float* smooth_tng, const float* geom_nrm, int64_t B,
+                          int64_t pix_per_view, int two_sided, int opengl, const float* g_out,
+                          float* g_pos, float* g_view_pos_full, float* g_perturbed_nrm,
+                          float* g_smooth_nrm, float* g_smooth_tng, float* g_geom_nrm,
+                          gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * image_loss   (replaces ru.image_loss, render/renderutils/ops.py:479-503; c_src/loss.cu:15-210)
+ *   img, target: n floats (any shape, same layout).  loss: 0 l1, 1 mse, 2 relmse, 3 smape;
+ *   tonemapper: 0 none, 1 log_srgb.  fwd writes gs_image_loss_partials(n) per-block sums
+ *   (the caller sums them and divides by n, like the reference's partial-sum tensor + torch.sum).
+ *   bwd: g = *g_scalar_dev * scale per element; g_img / g_target WRITTEN (either may be NULL).
+ * ---------------------------------------------------------------------------------- */
+int64_t gs_image_loss_partials(int64_t n);
+int gs_image_loss_fwd(const float* img, const float* target, int64_t n, int loss, int tonemapper,
+                      float* partials, gs_stream_t stream);
+int gs_image_loss_bwd(const float* img, const float* target, int64_t n, int loss, int tonemapper,
+                      const float* g_scalar_dev, float scale, float* g_img, float* g_target,
+                      gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * auto_normals   (replaces mesh.auto_normals, render/mesh.py:212-237)
+ *   acc [V,3] = unnormalised area-weighted normal sums (saved for bwd), v_nrm [V,3].
+ *   bwd: g_acc [V,3] scratch WRITTEN, g_pos [V,3] ACCUMULATED.
+ * ---------------------------------------------------------------------------------- */
+int gs_auto_normals_fwd(const float* v_pos, int64_t V, const int32_t* tri, int64_t T, float* acc,
+                        float* v_nrm, gs_stream_t stream);
+int gs_auto_normals_bwd(const float* v_pos, int64_t V, const int32_t* tri, int64_t T,
+                        const float* acc, const float* g_nrm, float* g_acc, float* g_pos,
+                        gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Bilinear image tap with clamp addressing   (replaces dr.texture(tex, uv, filter_mode='linear',
+ *   boundary_mode='clamp') as used at render/render.py:59, :110)
+ *   tex [B,H,W,C], uv [B,n_per_view,2] in [0,1] (texel centres at (i+.5)/W) -> out [B,n_per_view,C]
+ *   bwd: g_tex [B,H,W,C] ACCUMULATED; uv carries no gradient (it is noise in the reference).
+ * ---------------------------------------------------------------------------------- */
+int gs_texture_linear_fwd(const float* tex, int64_t B, int64_t H, int64_t W, int64_t C,
+                          const float* uv, int64_t n_per_view, float* out, gs_stream_t stream);
+int gs_texture_linear_bwd(int64_t B, int64_t H, int64_t W, int64_t C, const float* uv,
+                          int64_t n_per_view, const float* g_out, float* g_tex, gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,158 @@
+"""Rasterise / interpolate / antialias: HIP path (through the C ABI) vs the CPU oracle.
+Integer outputs (triangle ids, adjacency) bit-exact; floats within the tolerance written at each assert."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import raster_oracle as ro
+from oracle import scenes
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _scene(kind, seed):
+    if kind == "soup":
+        verts, tri = scenes.random_soup(600, seed)
+    elif kind == "sheet":
+        verts, tri = scenes.grid_sheet(14, seed)
+    elif kind == "big":   # two screen-filling triangles behind a sheet: exercises the workgroup-per-triangle path
+        v1, t1 = scenes.grid_sheet(10, seed)
+        v2 = np.array([[-4, -4, -0.6], [4, -4, -0.6], [4, 4, -0.6], [-4, 4, -0.6]], dtype=np.float32)
+        verts = np.concatenate([v1, v2])
+        tri = np.concatenate([t1, np.array([[0, 1, 2], [0, 2, 3]], dtype=np.int32) + len(v1)])
+    elif kind == "empty":
+        verts, tri = np.zeros((3, 3), np.float32), np.zeros((0, 3), np.int32)
+    return verts, tri
+
+
+def _clip(verts, nviews, first=0):
+    mvp, cam = scenes.orbit_views(nviews, first=first)
+    pos = ro.xfm_points(torch.tensor(verts)[None], torch.tensor(mvp))
+    return pos, mvp, cam
+
+
+def test_xfm_points():
+    from gshell_amd.render import renderutils as ru
+    g = torch.Generator().manual_seed(0)
+    for Bp in (1, 3):
+        pts = torch.rand(Bp, 1000, 3, generator=g)
+        mtx = torch.rand(3, 4, 4, generator=g)
+        w = torch.rand(3, 1000, 4, generator=g)
+        p_ref = pts.clone().requires_grad_(True)
+        out_ref = ro.xfm_points(p_ref, mtx)
+        (out_ref * w).sum().backward()
+        p = pts.to(DEV).requires_grad_(True)
+        out = ru.xfm_points(p, mtx.to(DEV))
+        (out * w.to(DEV)).sum().backward()
+        assert torch.allclose(out.cpu(), out_ref, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(p.grad.cpu(), p_ref.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind,res", [("soup", (64, 64)), ("sheet", (96, 80)), ("big", (128, 128)), ("empty", (16, 16))])
+def test_rasterize_forward(kind, res):
+    from gshell_amd.render import rast as dr
+    verts, tri = _scene(kind, 1)
+    pos, _, _ = _clip(verts, 2)
+    H, W = res
+    ids_ref = ro.rasterize_ids(pos.numpy(), tri, H, W)
+    rast, db, vis = dr.rasterize(dr.RasterizeGLContext(), pos.to(DEV), torch.tensor(tri, device=DEV), (H, W), return_visible=True)
+    ids = rast[..., 3].long().cpu().numpy() - 1
+    np.testing.assert_array_equal(ids, ids_ref)                      # visibility: bit exact
+    if tri.shape[0]:
+        rast_ref, db_ref = ro.rast_from_ids(pos, torch.tensor(tri).long(), torch.tensor(ids_ref))
+        assert torch.allclose(rast.cpu(), rast_ref, rtol=1e-4, atol=2e-5)   # u, v, z/w
+        assert torch.allclose(db.cpu(), db_ref, rtol=1e-3, atol=1e-4)
+        want = np.zeros(tri.shape[0], np.uint8)
+        want[np.unique(ids_ref[ids_ref >= 0])] = 1
+        np.testing.assert_array_equal(vis.cpu().numpy(), want)
+    else:
+        assert (rast == 0).all() and (db == 0).all()
+
+
+@pytest.mark.parametrize("kind", ["soup", "sheet", "big"])
+def test_rasterize_backward(kind):
+    from gshell_amd.render import rast as dr
+    verts, tri = _scene(kind, 2)
+    pos, _, _ = _clip(verts, 2, first=3)
+    H, W = 72, 72
+    ids_ref = torch.tensor(ro.rasterize_ids(pos.numpy(), tri, H, W))
+    wgt = torch.rand(2, H, W, 2, generator=torch.Generator().manual_seed(1))
+    p_ref = pos.clone().requires_grad_(True)
+    rast_ref, _ = ro.rast_from_ids(p_ref, torch.tensor(tri).long(), ids_ref)
+    (rast_ref[..., :2] * wgt).sum().backward()
+    p = pos.to(DEV).requires_grad_(True)
+    rast, _ = dr.rasterize(None, p, torch.tensor(tri, device=DEV), (H, W))
+    (rast[..., :2] * wgt.to(DEV)).sum().backward()
+    g, g_ref = p.grad.cpu(), p_ref.grad
+    assert g_ref.abs().max() > 0
+    # float atomics: summation order differs -> relative to the gradient scale
+    assert (g - g_ref).abs().max() <= 1e-4 * g_ref.abs().max() + 1e-5
+    assert (g[..., 2] == 0).all()
+
+
+@pytest.mark.parametrize("A,Ba", [(1, 1), (3, 1), (4, 2), (7, 1)])
+def test_interpolate(A, Ba):
+    from gshell_amd.render import rast as dr
+    verts, tri = _scene("sheet", 3)
+    pos, _, _ = _clip(verts, 2)
+    H, W = 64, 64
+    tri_l = torch.tensor(tri).long()
+    ids = torch.tensor(ro.rasterize_ids(pos.numpy(), tri, H, W))
+    rast_ref, db_ref = ro.rast_from_ids(pos, tri_l, ids)
+    g = torch.Generator().manual_seed(5)
+    attr = torch.rand(Ba, verts.shape[0], A, generator=g)
+    wgt = torch.rand(2, H, W, A, generator=g)
+    a_ref, r_ref = attr.clone().requires_grad_(True), rast_ref.clone().requires_grad_(True)
+    out_ref, da_ref = ro.interpolate(a_ref, r_ref, tri_l, db_ref)
+    (out_ref * wgt).sum().backward()
+    a, r = attr.to(DEV).requires_grad_(True), rast_ref.to(DEV).requires_grad_(True)
+    out, da = dr.interpolate(a, r, torch.tensor(tri, device=DEV), rast_db=db_ref.to(DEV), diff_attrs='all')
+    (out * wgt.to(DEV)).sum().backward()
+    assert torch.allclose(out.cpu(), out_ref, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(da.cpu(), da_ref, rtol=1e-4, atol=1e-5)
+    assert (a.grad.cpu() - a_ref.grad).abs().max() <= 1e-4 * a_ref.grad.abs().max()
+    assert torch.allclose(r.grad.cpu()[..., :2], r_ref.grad[..., :2], rtol=1e-4, atol=1e-5)
+    out2, none = dr.interpolate(a, r, torch.tensor(tri, device=DEV))
+    assert none is None and torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("kind", ["soup", "sheet", "big"])
+def test_antialias(kind):
+    from gshell_amd.render import rast as dr
+    verts, tri = _scene(kind, 4)
+    pos, _, _ = _clip(verts, 2, first=1)
+    H, W = 80, 80
+    tri_l = torch.tensor(tri).long()
+    tri_d = torch.tensor(tri, device=DEV)
+    ids = torch.tensor(ro.rasterize_ids(pos.numpy(), tri, H, W))
+    rast_ref, _ = ro.rast_from_ids(pos, tri_l, ids)
+    opp_ref = ro.tri_adjacency(tri)
+    topo = dr.AATopology(tri_d, verts.shape[0])
+    np.testing.assert_array_equal(topo.opp.cpu().numpy(), opp_ref)                 # adjacency: bit exact
+    g = torch.Generator().manual_seed(7)
+    color = torch.rand(2, H, W, 5, generator=g)
+    wgt = torch.rand(2, H, W, 5, generator=g)
+    p_ref, c_ref = pos.clone().requires_grad_(True), color.clone().requires_grad_(True)
+    alpha_ref = ro.aa_alpha(rast_ref, p_ref, tri_l, torch.tensor(opp_ref))
+    out_ref = ro.aa_apply(c_ref, alpha_ref)
+    (out_ref * wgt).sum().backward()
+    assert (alpha_ref != 0).sum() > 20
+    p, c = pos.to(DEV).requires_grad_(True), color.to(DEV).requires_grad_(True)
+    rast_d = rast_ref.to(DEV)
+    alpha = dr.aa_analyze(rast_d, p, tri_d, topo)
+    # the silhouette decision is a float comparison: allow a handful of pairs to flip, none to drift
+    a, ar = alpha.cpu(), alpha_ref.detach()
+    mism = ((a - ar).abs() > 1e-4)
+    assert mism.float().mean() < 1e-3, f"{int(mism.sum())} alpha entries differ"
+    out = dr.antialias(c, rast_d, p, tri_d)
+    (out * wgt.to(DEV)).sum().backward()
+    ok = ~(mism.any(-1))
+    ok = ok & torch.roll(ok, 1, 1) & torch.roll(ok, 1, 2)
+    assert torch.allclose(out.cpu()[ok], out_ref.detach()[ok], rtol=1e-5, atol=1e-5)
+    if not mism.any():
+        assert torch.allclose(c.grad.cpu(), c_ref.grad, rtol=1e-4, atol=1e-5)
+        assert (p.grad.cpu() - p_ref.grad).abs().max() <= 2e-4 * p_ref.grad.abs().max() + 1e-6
+    # stacked form == per-buffer form
+    o1, o2 = dr.antialias_stacked([c[..., :2], c[..., 2:]], rast_d, p, tri_d, topo)
+    assert torch.equal(torch.cat([o1, o2], -1), out)
