@@ -1,0 +1,679 @@
+// Monte-Carlo environment-light shading with shadow rays on gfx950 (fwd + bwd), and the bilateral denoiser.
+//
+// Replaces ou.optix_env_shade (render/optixutils/ops.py:81-108, :141-143; OptiX raygen program
+// render/optixutils/c_src/envsampling/kernel.cu:463-541, BSDF math c_src/bsdf.h:21-275, helpers
+// c_src/math_utils.h:80-163) and ou.bilateral_denoiser (ops.py:110-123, :145-147; c_src/denoising.cu:14-130).
+//
+// The reference runs one OptiX thread per pixel that loops over n^2 stratified (light sample, BSDF sample)
+// pairs and traces one hardware any-hit ray per sample.  On CDNA4 the loop is turned sideways:
+//   * a GROUP of G = min(64, pow2 <= n^2) lanes shades one pixel; lane j takes samples j, j+G, ...
+//     With the headline n = 8 a whole wave64 shades one pixel, 2 rays per lane, and the per-pixel
+//     sums are wave reductions (DPP shuffles) instead of a 128-iteration serial loop.
+//   * the per-pixel PCG stream of the reference is reproduced exactly by LCG jump-ahead
+//     (sample i consumes draws 2+5i .. 6+5i), so results do not depend on the lane mapping.
+//   * masked (background) pixels retire whole waves immediately -- no compaction pass needed.
+//   * shadow rays walk the implicit 4-ary BVH of bvh.hpp with an LDS stack.
+//   * backward re-traces with identical sampling (like the reference's params.backward pass);
+//     per-pixel gradients are group-reduced and written once, the light gradient is one float
+//     atomicAdd per sample and channel into the [Hl,Wl,3] probe (as kernel.cu:203-211 does).
+// This stage is ALU / latency bound (ray traversal), not HBM bound: bytes per pixel are ~100.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "../../include/gshell_hip.h"
+#include "bvh.hpp"
+#include "common.hpp"
+
+namespace {
+
+constexpr float PI_F = 3.14159265358979323846f;
+constexpr float SPECULAR_EPSILON = 1e-4f;
+constexpr float MIN_ROUGHNESS = 0.08f;
+
+struct v3 {
+    float x, y, z;
+};
+__device__ __forceinline__ v3 V3(float x, float y, float z) { return {x, y, z}; }
+__device__ __forceinline__ v3 V3(float a) { return {a, a, a}; }
+__device__ __forceinline__ v3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ v3 operator-(v3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ v3 operator*(v3 a, v3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ v3 operator*(v3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ v3 operator*(float s, v3 a) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ v3 operator/(v3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ v3& operator+=(v3& a, v3 b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
+__device__ __forceinline__ v3& operator-=(v3& a, v3 b) { a.x -= b.x; a.y -= b.y; a.z -= b.z; return a; }
+__device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float sum(v3 a) { return a.x + a.y + a.z; }
+__device__ __forceinline__ v3 cross(v3 a, v3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ float luminance(v3 c) { return dot(c, V3(0.2126f, 0.7152f, 0.0722f)); }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+__device__ __forceinline__ v3 safe_normalize(v3 v) {
+    float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return l > 0.0f ? v / l : V3(0.f);
+}
+__device__ __forceinline__ void bwd_dot(v3 a, v3 b, v3& da, v3& db, float d) {
+    da += b * d;
+    db += a * d;
+}
+__device__ __forceinline__ void bwd_safe_normalize(v3 v, v3& dv, v3 d) {
+    float l2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    if (l2 > 0.0f) {
+        float fac = 1.0f / (l2 * sqrtf(l2));
+        dv.x += (d.x * (v.y * v.y + v.z * v.z) - d.y * (v.x * v.y) - d.z * (v.x * v.z)) * fac;
+        dv.y += (d.y * (v.x * v.x + v.z * v.z) - d.x * (v.y * v.x) - d.z * (v.y * v.z)) * fac;
+        dv.z += (d.z * (v.x * v.x + v.y * v.y) - d.x * (v.z * v.x) - d.y * (v.z * v.y)) * fac;
+    }
+}
+// Pixar orthonormal basis (math_utils.h:155-162)
+__device__ __forceinline__ void onb(v3 n, v3& b1, v3& b2) {
+    float sign = copysignf(1.0f, n.z);
+    float a = -1.0f / (sign + n.z);
+    float b = n.x * n.y * a;
+    b1 = V3(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
+    b2 = V3(b, sign + n.y * n.y * a, -n.y);
+}
+__device__ __forceinline__ v3 tolocal(v3 a, v3 u, v3 v, v3 w) { return V3(dot(a, u), dot(a, v), dot(a, w)); }
+__device__ __forceinline__ v3 toworld(v3 a, v3 u, v3 v, v3 w) { return u * a.x + v * a.y + w * a.z; }
+
+// ---- PCG hash / LCG stream (kernel.cu:30-45) ------------------------------------------------------
+__device__ __forceinline__ uint32_t pcg_out(uint32_t s) {
+    uint32_t word = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+constexpr uint32_t LCG_A = 747796405u, LCG_C = 2891336453u;
+__device__ __forceinline__ uint32_t lcg_next(uint32_t s) { return s * LCG_A + LCG_C; }
+__device__ __forceinline__ uint32_t lcg_jump(uint32_t s, uint32_t k) {  // state after k steps
+    uint32_t a = LCG_A, c = LCG_C, A = 1u, C = 0u;
+    while (k) {
+        if (k & 1u) {
+            A *= a;
+            C = C * a + c;
+        }
+        c = (a + 1u) * c;
+        a *= a;
+        k >>= 1;
+    }
+    return A * s + C;
+}
+__device__ __forceinline__ float u01(uint32_t s) { return (float)(pcg_out(s) & 0xFFFFFFu) / (float)0x1000000; }
+
+// ---- BSDF (bsdf.h) ----------------------------------------------------------------------------------
+__device__ __forceinline__ float fwd_lambert(v3 n, v3 wi) { return fmaxf(dot(n, wi) / PI_F, 0.0f); }
+__device__ __forceinline__ v3 fwd_fresnel(v3 f0, v3 f90, float c) {
+    float cc = clampf(c, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
+    float scale = powf(1.0f - cc, 5.0f);
+    return f0 * (1.0f - scale) + f90 * scale;
+}
+__device__ __forceinline__ float fwd_ndf(float a2, float c) {
+    float cc = clampf(c, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
+    float d = (cc * a2 - cc) * cc + 1.0f;
+    return a2 / (d * d * PI_F);
+}
+__device__ __forceinline__ float fwd_lambda(float a2, float c) {
+    float cc = clampf(c, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
+    float c2 = cc * cc;
+    float t2 = (1.0f - c2) / c2;
+    return 0.5f * (sqrtf(1.0f + a2 * t2) - 1.0f);
+}
+__device__ __forceinline__ void bwd_lambda(float a2, float c, float& da2, float& dc, float d) {
+    float cc = clampf(c, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
+    float c2 = cc * cc;
+    float t2 = (1.0f - c2) / c2;
+    da2 += d * (0.25f * t2) / sqrtf(a2 * t2 + 1.0f);
+    if (c > SPECULAR_EPSILON && c < 1.0f - SPECULAR_EPSILON) dc += d * -(0.5f * a2) / (cc * cc * cc * sqrtf(a2 / c2 - a2 + 1.0f));
+}
+__device__ __forceinline__ float fwd_smith(float a2, float ci, float co) { return 1.0f / (1.0f + fwd_lambda(a2, ci) + fwd_lambda(a2, co)); }
+
+__device__ __forceinline__ v3 fwd_pbr_specular(v3 col, v3 nrm, v3 wo, v3 wi, float alpha, float min_rough) {
+    float al = clampf(alpha, min_rough * min_rough, 1.0f);
+    float a2 = al * al;
+    v3 h = safe_normalize(wo + wi);
+    float woN = dot(wo, nrm), wiN = dot(wi, nrm), woH = dot(wo, h), nH = dot(nrm, h);
+    float D = fwd_ndf(a2, nH), G = fwd_smith(a2, woN, wiN);
+    v3 F = fwd_fresnel(col, V3(1.0f), woH);
+    v3 w = F * (D * G * 0.25f / woN);
+    bool front = (woN > SPECULAR_EPSILON) & (wiN > SPECULAR_EPSILON);
+    return front ? w : V3(0.f);
+}
+
+__device__ __forceinline__ void bwd_pbr_specular(v3 col, v3 nrm, v3 wo, v3 wi, float alpha, float min_rough, v3& d_col, v3& d_nrm, v3& d_wo,
+                                                 v3& d_wi, float& d_alpha, v3 d_out) {
+    float al = clampf(alpha, min_rough * min_rough, 1.0f);
+    float a2 = al * al;
+    v3 hsum = wo + wi;
+    v3 h = safe_normalize(hsum);
+    float woN = dot(wo, nrm), wiN = dot(wi, nrm), woH = dot(wo, h), nH = dot(nrm, h);
+    float D = fwd_ndf(a2, nH), G = fwd_smith(a2, woN, wiN);
+    v3 F = fwd_fresnel(col, V3(1.0f), woH);
+    bool front = (woN > SPECULAR_EPSILON) & (wiN > SPECULAR_EPSILON);
+    if (!front) return;
+    v3 dF = d_out * (D * G * 0.25f / woN);
+    float dD = sum(d_out * F) * (G * 0.25f / woN);
+    float dG = sum(d_out * F) * (D * 0.25f / woN);
+    float d_woN = -sum(d_out * F) * (D * G * 0.25f / (woN * woN));
+    float d_woH = 0.f, d_wiN = 0.f, d_nH = 0.f, d_a2 = 0.f;
+    {  // Fresnel bwd (f90 == 1)
+        float cc = clampf(woH, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
+        float scale = powf(fmaxf(1.0f - cc, 0.0f), 5.0f);
+        d_col += dF * (1.0f - scale);
+        if (woH >= SPECULAR_EPSILON && woH < 1.0f - SPECULAR_EPSILON) d_woH += sum(dF * (V3(1.0f) - col)) * -5.0f * powf(1.0f - woH, 4.0f);
+    }
+    {  // Smith bwd
+        float li = fwd_lambda(a2, woN), lo = fwd_lambda(a2, wiN);
+        float dl = -dG / ((1.0f + li + lo) * (1.0f + li + lo));
+        bwd_lambda(a2, woN, d_a2, d_woN, dl);
+        bwd_lambda(a2, wiN, d_a2, d_wiN, dl);
+    }
+    {  // NDF bwd
+        float cc = clampf(nH, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
+        float c2 = cc * cc;
+        float den = (a2 - 1.0f) * c2 + 1.0f;
+        float den3 = den * den * den;
+        d_a2 += dD * (1.0f - (a2 + 1.0f) * c2) / (PI_F * den3);
+        if (nH > SPECULAR_EPSILON && nH < 1.0f - SPECULAR_EPSILON) d_nH += dD * -(4.0f * (a2 - 1.0f) * a2 * nH) / (PI_F * den3);
+    }
+    v3 d_h = V3(0.f);
+    bwd_dot(nrm, h, d_nrm, d_h, d_nH);
+    bwd_dot(wo, h, d_wo, d_h, d_woH);
+    bwd_dot(wi, nrm, d_wi, d_nrm, d_wiN);
+    bwd_dot(wo, nrm, d_wo, d_nrm, d_woN);
+    v3 d_hsum = V3(0.f);
+    bwd_safe_normalize(hsum, d_hsum, d_h);
+    d_wo += d_hsum;
+    d_wi += d_hsum;
+    if (alpha > min_rough * min_rough) d_alpha += d_a2 * 2.0f * alpha;
+}
+
+// ---- sampling pdfs (kernel.cu:218-400); constants w.r.t. differentiation ----------------------------
+__device__ __forceinline__ float ndf_ggx(float alpha, float c) {
+    float a2 = alpha * alpha;
+    float d = ((c * a2 - c) * c + 1.0f);
+    return a2 / (d * d * PI_F);
+}
+__device__ __forceinline__ float g1_ggx(float a2, float c) {
+    if (c <= 0.0f) return 0.0f;
+    float c2 = c * c;
+    float t2 = fmaxf(1.0f - c2, 0.0f) / c2;
+    return 2.0f / (1.0f + sqrtf(1.0f + a2 * t2));
+}
+__device__ __forceinline__ float ggx_pdf(v3 N, v3 wo, v3 wi, float alpha) {
+    v3 W = safe_normalize(N), U, Vv;
+    onb(W, U, Vv);
+    v3 wo_l = tolocal(wo, U, Vv, W), wi_l = tolocal(wi, U, Vv, W);
+    float pdf = 0.0f;
+    if (wo_l.z > 0.0f && wi_l.z > 0.0f) {
+        v3 m = safe_normalize(wi_l + wo_l);
+        float woH = dot(m, wo_l);
+        float D = ndf_ggx(alpha, m.z);
+        float G1 = g1_ggx(alpha * alpha, wo_l.z);
+        pdf = G1 * D * fmaxf(0.0f, dot(wo_l, m)) / wo_l.z;
+        pdf /= (4.0f * woH);
+    }
+    return pdf;
+}
+__device__ __forceinline__ void update_pdf(float& pdf, float opdf, float b) {
+    if (b > 0.000001f) pdf += opdf * b;
+}
+__device__ __forceinline__ float bsdf_pdf(float pD, float pS, v3 N, v3 wo, v3 wi, float alpha) {
+    float NdotL = dot(N, wi), NdotV = dot(N, wo);
+    if (fminf(NdotV, NdotL) < 1e-6f) return 1.0f;
+    float pdf = 0.0f;
+    if (pD > 0.0f) update_pdf(pdf, fmaxf(dot(N, wi), 0.0f) / PI_F, pD);
+    if (pS > 0.0f) update_pdf(pdf, ggx_pdf(N, wo, wi, alpha), 1.0f - pD);
+    return pdf;
+}
+__device__ __forceinline__ v3 cosine_sample(v3 N, float u, float v, float& pdf) {
+    N = safe_normalize(N);
+    v3 dx, dy;
+    onb(N, dx, dy);
+    float phi = 2.0f * PI_F * u;
+    float ct = sqrtf(v), st = sqrtf(1.0f - v);
+    float sp, cp;
+    sincosf(phi, &sp, &cp);
+    pdf = fmaxf(0.000001f, ct / PI_F);
+    return safe_normalize(dx * (cp * st) + dy * (sp * st) + N * ct);
+}
+__device__ __forceinline__ v3 sample_vndf(float alpha, v3 wo, float ux, float uy, float& pdf) {
+    v3 Vh = safe_normalize(V3(alpha * wo.x, alpha * wo.y, wo.z));
+    v3 T1 = (Vh.z < 0.9999f) ? safe_normalize(cross(V3(0.f, 0.f, 1.f), Vh)) : V3(1.f, 0.f, 0.f);
+    v3 T2 = cross(Vh, T1);
+    float r = sqrtf(ux), phi = (2.0f * PI_F) * uy;
+    float sp, cp;
+    sincosf(phi, &sp, &cp);
+    float t1 = r * cp, t2 = r * sp;
+    float s = 0.5f * (1.0f + Vh.z);
+    t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
+    v3 Nh = T1 * t1 + T2 * t2 + Vh * sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2));
+    v3 h = safe_normalize(V3(alpha * Nh.x, alpha * Nh.y, fmaxf(0.0f, Nh.z)));
+    pdf = g1_ggx(alpha * alpha, wo.z) * ndf_ggx(alpha, h.z) * fmaxf(0.0f, dot(wo, h)) / wo.z;
+    return h;
+}
+__device__ __forceinline__ v3 ggx_sample(v3 N, v3 wo, float u, float v, float alpha, float& pdf) {
+    v3 W = safe_normalize(N), U, Vv;
+    onb(W, U, Vv);
+    v3 wo_l = safe_normalize(tolocal(wo, U, Vv, W));
+    if (!(wo_l.z > 0.0f)) {
+        pdf = 0.0f;
+        return V3(0.f);
+    }
+    v3 h = sample_vndf(alpha, wo_l, u, v, pdf);
+    float woH = dot(wo_l, h);
+    v3 wi_l = h * (woH * 2.0f) - wo_l;
+    pdf /= (4.0f * woH);
+    return safe_normalize(toworld(wi_l, U, Vv, W));
+}
+__device__ __forceinline__ v3 bsdf_sample(float pD, float pS, v3 N, v3 wo, float sx, float sy, float sz, float alpha, float& pdf) {
+    pdf = 0.0f;
+    v3 wi;
+    if (sz < pD) {
+        if (pD < 0.0001f) {
+            pdf = 1.0f;
+            return N;
+        }
+        wi = cosine_sample(N, sx, sy, pdf);
+        pdf *= pD;
+        if (pS > 0.0f) update_pdf(pdf, ggx_pdf(N, wo, wi, alpha), 1.0f - pD);
+    } else {
+        wi = ggx_sample(N, wo, sx, sy, alpha, pdf);
+        pdf *= 1.0f - pD;
+        if (pD > 0.0f) update_pdf(pdf, fmaxf(dot(N, wi), 0.0f) / PI_F, pD);
+    }
+    return wi;
+}
+
+// ---- light probe (kernel.cu:123-211) ------------------------------------------------------------------
+struct Probe {
+    const float* light;  // [Hl,Wl,3]
+    const float* pdf;    // [Hl,Wl]
+    const float* rows;   // [Hl]
+    const float* cols;   // [Hl,Wl]
+    int Hl, Wl;
+    int iters_rows, iters_cols;
+};
+__device__ __forceinline__ void dir_to_tc(v3 d, float& u, float& v) {
+    u = atan2f(d.x, -d.z) / (2.0f * PI_F) + 0.5f;
+    v = acosf(clampf(d.y, -1.0f, 1.0f)) / PI_F;
+}
+__device__ __forceinline__ v3 tc_to_dir(float u, float v) {
+    float sphi, cphi, sth, cth;
+    sincosf((u * 2.0f - 1.0f) * PI_F, &sphi, &cphi);
+    sincosf(v * PI_F, &sth, &cth);
+    return V3(sth * sphi, cth, -sth * cphi);
+}
+__device__ __forceinline__ float sample_cdf(const float* __restrict__ cdf, int size, int iters, float x, int& idx, float& pdf) {
+    x = fminf(x, 0.99999994f);
+    unsigned lo = 0, hi = (unsigned)size - 1;
+    for (int i = 0; i < iters; ++i) {
+        unsigned mid = (lo + hi) / 2;
+        float c = cdf[mid];
+        lo = x >= c ? mid : lo;
+        hi = x < c ? mid : hi;
+    }
+    idx = (int)hi;
+    float sample;
+    if (idx == 0) {
+        pdf = cdf[0];
+        sample = x;
+    } else {
+        float d0 = cdf[idx], d1 = cdf[idx - 1];
+        pdf = d0 - d1;
+        sample = x - d1;
+    }
+    return fminf(sample / pdf, 0.99999994f);
+}
+__device__ __forceinline__ float light_pdf(const Probe& P, v3 dir) {
+    float u, v;
+    dir_to_tc(dir, u, v);
+    int x = min(max((int)(u * (float)P.Wl), 0), P.Wl - 1);
+    int y = min(max((int)(v * (float)P.Hl), 0), P.Hl - 1);
+    float w = (float)P.Hl * (float)P.Wl / (2.0f * PI_F * PI_F * fmaxf(sinf(v * PI_F), 0.0001f));
+    return P.pdf[y * P.Wl + x] * w;
+}
+__device__ __forceinline__ v3 light_sample(const Probe& P, float u, float v, float& pdf) {
+    float row_pdf, col_pdf;
+    int x, y;
+    float ry = sample_cdf(P.rows, P.Hl, P.iters_rows, v, y, row_pdf);
+    float rx = sample_cdf(P.cols + (int64_t)y * P.Wl, P.Wl, P.iters_cols, u, x, col_pdf);
+    v3 d = tc_to_dir(((float)x + rx) / (float)P.Wl, ((float)y + ry) / (float)P.Hl);
+    pdf = light_pdf(P, d);
+    return d;
+}
+
+struct ShadeArgs {
+    BvhView bvh;
+    Probe probe;
+    const float *mask, *ro, *pos, *nrm, *view_pos, *kd, *ks;  // view_pos [B,3]
+    const int32_t* perms;                                     // [P, n*n]
+    int P;
+    int64_t B, HW;
+    int W;
+    int bsdf, n, G;  // G lanes per pixel
+    uint32_t seed;
+    float shadow_scale;
+    float *diff, *spec;                                  // fwd outputs [B,H,W,3]
+    const float *g_diff, *g_spec;                        // bwd inputs
+    float *g_pos, *g_nrm, *g_kd, *g_ks, *g_light;        // bwd outputs
+};
+
+struct PixelCtx {
+    v3 ro, pos, nrm, view, kd, ks, wo;
+    float alpha, pD, pS;
+};
+
+struct SampleOut {
+    v3 diff, spec;
+};
+
+template <bool BWD>
+__device__ __forceinline__ SampleOut process_sample(const ShadeArgs& A, const PixelCtx& c, v3 dir, float pdf_sum, float weight, v3 g_diff, v3 g_spec,
+                                                    int32_t* stack, int tid, v3& a_pos, v3& a_nrm, v3& a_kd, v3& a_ks) {
+    float u, v;
+    dir_to_tc(dir, u, v);
+    int lx = min(max((int)(u * (float)A.probe.Wl), 0), A.probe.Wl - 1);
+    int ly = min(max((int)(v * (float)A.probe.Hl), 0), A.probe.Hl - 1);
+    const float* lp = A.probe.light + ((int64_t)ly * A.probe.Wl + lx) * 3;
+    v3 light_col = ld3(lp);
+    float mis = 1.0f / fmaxf(pdf_sum, 0.0001f);
+    v3 d_ = V3(0.f), s_ = V3(0.f);
+    v3 spec_col = V3(0.f);
+    if (A.bsdf == 1 || A.bsdf == 2)
+        d_ = V3(fwd_lambert(c.nrm, dir));
+    else {
+        spec_col = (V3(0.04f) * (1.0f - c.ks.z) + c.kd * c.ks.z) * (1.0f - c.ks.x);
+        d_ = V3(fwd_lambert(c.nrm, dir));
+        s_ = fwd_pbr_specular(spec_col, c.nrm, c.wo, dir, c.alpha, MIN_ROUGHNESS);
+    }
+    bool occluded = bvh_any_hit(A.bvh, c.ro.x, c.ro.y, c.ro.z, dir.x, dir.y, dir.z, stack, tid, 256);
+    float Vis = (occluded ? 0.0f : 1.0f) * A.shadow_scale + (1.0f - A.shadow_scale);
+    float k = Vis * mis * weight;
+    if (BWD) {
+        v3 lg = (g_diff * d_ + g_spec * s_) * k;
+        float* gl = A.g_light + ((int64_t)ly * A.probe.Wl + lx) * 3;
+        if (lg.x != 0.f) atomicAdd(&gl[0], lg.x);
+        if (lg.y != 0.f) atomicAdd(&gl[1], lg.y);
+        if (lg.z != 0.f) atomicAdd(&gl[2], lg.z);
+        v3 dd = g_diff * light_col * k, ds = g_spec * light_col * k;
+        v3 d_nrm = V3(0.f);
+        if (A.bsdf == 1 || A.bsdf == 2) {
+            if (dot(c.nrm, dir) > 0.0f) d_nrm += dir * (sum(dd) / PI_F);
+        } else {
+            v3 d_spec_col = V3(0.f), d_wo = V3(0.f), d_wi = V3(0.f);
+            float d_alpha = 0.f;
+            bwd_pbr_specular(spec_col, c.nrm, c.wo, dir, c.alpha, MIN_ROUGHNESS, d_spec_col, d_nrm, d_wo, d_wi, d_alpha, ds);
+            if (dot(c.nrm, dir) > 0.0f) d_nrm += dir * (sum(dd) / PI_F);
+            // spec_col = (0.04 (1 - ks.z) + kd ks.z) (1 - ks.x)
+            a_kd -= d_spec_col * ((c.ks.x - 1.0f) * c.ks.z);
+            a_ks.x += sum(d_spec_col * ((V3(0.04f) - c.kd) * c.ks.z - V3(0.04f)));
+            a_ks.z -= sum(d_spec_col * (c.kd - V3(0.04f))) * (c.ks.x - 1.0f);
+            a_ks.y += d_alpha * 2.0f * c.ks.y;
+            v3 d_wo_raw = V3(0.f);
+            bwd_safe_normalize(c.view - c.pos, d_wo_raw, d_wo);
+            a_pos -= d_wo_raw;
+        }
+        a_nrm += d_nrm;
+    }
+    SampleOut o;
+    o.diff = d_ * light_col * k;
+    o.spec = s_ * light_col * k;
+    return o;
+}
+
+__device__ __forceinline__ float group_sum(float v, int G) {
+    for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ v3 group_sum(v3 v, int G) { return V3(group_sum(v.x, G), group_sum(v.y, G), group_sum(v.z, G)); }
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_env_shade(ShadeArgs A) {
+    __shared__ int32_t stack[BVH_STACK * 256];
+    const int tid = threadIdx.x;
+    const int G = A.G;
+    int64_t gid = ((int64_t)blockIdx.x * 256 + tid) / G;
+    int j = tid & (G - 1);
+    int64_t npix = A.B * A.HW;
+    if (gid >= npix) return;  // whole groups retire together (G divides 64)
+    float mask = A.mask[gid];
+    if (!(mask > 0.0f)) return;
+    PixelCtx c;
+    int64_t b = gid / A.HW;
+    c.ro = ld3(A.ro + 3 * gid);
+    c.pos = ld3(A.pos + 3 * gid);
+    c.nrm = ld3(A.nrm + 3 * gid);
+    c.view = ld3(A.view_pos + 3 * b);
+    c.kd = ld3(A.kd + 3 * gid);
+    c.ks = ld3(A.ks + 3 * gid);
+    v3 g_diff = V3(0.f), g_spec = V3(0.f);
+    if (BWD) {
+        g_diff = ld3(A.g_diff + 3 * gid);
+        g_spec = ld3(A.g_spec + 3 * gid);
+    }
+    const int n = A.n, S = n * n;
+    float strata = 1.0f / (float)n, sample_frac = 1.0f / (float)(n * n);
+    c.alpha = c.ks.y * c.ks.y;
+    c.wo = safe_normalize(c.view - c.pos);
+    float metallic = c.ks.z;
+    v3 spec_color = V3(0.04f) * (1.0f - metallic) + c.kd * metallic;
+    float diffuse_w = (1.0f - metallic) * luminance(c.kd);
+    float specular_w;
+    {  // albedo() (kernel.cu:82-95)
+        v3 W = safe_normalize(c.nrm), U, Vv;
+        onb(W, U, Vv);
+        v3 wo_l = safe_normalize(tolocal(c.wo, U, Vv, W));
+        float cosNO = wo_l.z;
+        specular_w = (cosNO > 0.0f) ? luminance(fwd_fresnel(spec_color, V3(1.0f), cosNO)) : 0.0f;
+    }
+    c.pD = (diffuse_w + specular_w) > 0.0f ? diffuse_w / (diffuse_w + specular_w) : 1.0f;
+    c.pS = 1.0f - c.pD;
+
+    uint32_t s_seed = A.seed, s_pix = (uint32_t)gid;  // pixel linear index (z*H + y)*W + x == gid
+    uint32_t rng0 = pcg_out(s_seed) ^ pcg_out(s_pix);
+    uint32_t light_idx = pcg_out(rng0) % (uint32_t)A.P;
+    uint32_t bsdf_idx = pcg_out(lcg_next(rng0)) % (uint32_t)A.P;
+    const int32_t* perm_l = A.perms + (int64_t)light_idx * S;
+    const int32_t* perm_b = A.perms + (int64_t)bsdf_idx * S;
+
+    v3 acc_d = V3(0.f), acc_s = V3(0.f);
+    v3 a_pos = V3(0.f), a_nrm = V3(0.f), a_kd = V3(0.f), a_ks = V3(0.f);
+    for (int i = j; i < S; i += G) {
+        uint32_t st = lcg_jump(rng0, 2u + 5u * (uint32_t)i);
+        float r0 = u01(st); st = lcg_next(st);
+        float r1 = u01(st); st = lcg_next(st);
+        float r2 = u01(st); st = lcg_next(st);
+        float r3 = u01(st); st = lcg_next(st);
+        float r4 = u01(st);
+        // light importance sample
+        int pl = perm_l[i];
+        float sx = ((float)(pl % n) + r0) * strata, sy = ((float)(pl / n) + r1) * strata;
+        float pdf_light, pdf_b;
+        v3 dir = light_sample(A.probe, sx, sy, pdf_light);
+        pdf_b = bsdf_pdf(c.pD, c.pS, c.nrm, c.wo, dir, c.alpha);
+        SampleOut o = process_sample<BWD>(A, c, dir, pdf_light + pdf_b, sample_frac, g_diff, g_spec, stack, tid, a_pos, a_nrm, a_kd, a_ks);
+        acc_d += o.diff;
+        acc_s += o.spec;
+        // BSDF sample
+        int pb = perm_b[i];
+        sx = ((float)(pb % n) + r2) * strata;
+        sy = ((float)(pb / n) + r3) * strata;
+        dir = bsdf_sample(c.pD, c.pS, c.nrm, c.wo, sx, sy, r4, c.alpha, pdf_b);
+        pdf_light = light_pdf(A.probe, dir);
+        o = process_sample<BWD>(A, c, dir, pdf_light + pdf_b, sample_frac, g_diff, g_spec, stack, tid, a_pos, a_nrm, a_kd, a_ks);
+        acc_d += o.diff;
+        acc_s += o.spec;
+    }
+    if (!BWD) {
+        acc_d = group_sum(acc_d, G);
+        acc_s = group_sum(acc_s, G);
+        if (j == 0) {
+            float* od = A.diff + 3 * gid;
+            float* os = A.spec + 3 * gid;
+            od[0] = acc_d.x; od[1] = acc_d.y; od[2] = acc_d.z;
+            os[0] = acc_s.x; os[1] = acc_s.y; os[2] = acc_s.z;
+        }
+    } else {
+        a_pos = group_sum(a_pos, G);
+        a_nrm = group_sum(a_nrm, G);
+        a_kd = group_sum(a_kd, G);
+        a_ks = group_sum(a_ks, G);
+        if (j == 0) {
+            float* p;
+            p = A.g_pos + 3 * gid; p[0] = a_pos.x; p[1] = a_pos.y; p[2] = a_pos.z;
+            p = A.g_nrm + 3 * gid; p[0] = a_nrm.x; p[1] = a_nrm.y; p[2] = a_nrm.z;
+            p = A.g_kd + 3 * gid;  p[0] = a_kd.x;  p[1] = a_kd.y;  p[2] = a_kd.z;
+            p = A.g_ks + 3 * gid;  p[0] = a_ks.x;  p[1] = a_ks.y;  p[2] = a_ks.z;
+        }
+    }
+}
+
+int cdf_iters(int size) { return (int)std::ceil(std::log2((float)(size - 1))) + 1; }
+
+int fill_args(ShadeArgs& A, const gs_bvh* bvh, const float* mask, const float* ro, const float* pos, const float* nrm, const float* view_pos,
+              const float* kd, const float* ks, const float* light, const float* pdf, const float* rows, const float* cols, int64_t Hl, int64_t Wl,
+              const int32_t* perms, int64_t P, int64_t B, int64_t H, int64_t W, int bsdf, int n, uint32_t seed, float shadow_scale) {
+    GS_REQUIRE(bvh != nullptr, "env_shade: bvh is null");
+    GS_REQUIRE(mask && ro && pos && nrm && view_pos && kd && ks && light && pdf && rows && cols && perms, "env_shade: null pointer");
+    GS_REQUIRE(bsdf >= 0 && bsdf <= 2, "env_shade: BSDF id must be 0 (pbr), 1 (diffuse) or 2 (white)");
+    GS_REQUIRE(n >= 1 && n <= 64 && P >= 1 && Hl >= 2 && Wl >= 2, "env_shade: bad sample / probe configuration");
+    GS_REQUIRE(B * H * W < (1ll << 32), "env_shade: too many pixels for the 32-bit pixel hash");
+    A.bvh = bvh_view(bvh);
+    A.probe = {light, pdf, rows, cols, (int)Hl, (int)Wl, cdf_iters((int)Hl), cdf_iters((int)Wl)};
+    A.mask = mask; A.ro = ro; A.pos = pos; A.nrm = nrm; A.view_pos = view_pos; A.kd = kd; A.ks = ks;
+    A.perms = perms; A.P = (int)P; A.B = B; A.HW = H * W; A.W = (int)W; A.bsdf = bsdf; A.n = n;
+    int G = 1;
+    while (G * 2 <= std::min(n * n, 64)) G *= 2;
+    A.G = G;
+    A.seed = seed; A.shadow_scale = shadow_scale;
+    return 0;
+}
+
+// ---- bilateral denoiser (denoising.cu:14-130) ---------------------------------------------------------
+constexpr float FLT_EPS_D = 0.0001f;
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_bilateral(const float* __restrict__ col, const float* __restrict__ nrm, const float* __restrict__ zdz,
+                                                   int64_t B, int H, int W, float sigma, int rad, float* __restrict__ out,
+                                                   const float* __restrict__ g_out, float* __restrict__ g_col) {
+    int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    int64_t b = blockIdx.z;
+    if (x >= W || y >= H) return;
+    int64_t base = b * (int64_t)H * W;
+    int64_t ci = base + (int64_t)y * W + x;
+    float cnx = nrm[3 * ci], cny = nrm[3 * ci + 1], cnz = nrm[3 * ci + 2];
+    float cz = zdz[2 * ci], cdz = zdz[2 * ci + 1];
+    float variance = sigma * sigma;
+    float acc_w = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    for (int fy = -rad; fy <= rad; ++fy) {
+        int yy = y + fy;
+        if (yy < 0 || yy >= H) continue;
+        for (int fx = -rad; fx <= rad; ++fx) {
+            int xx = x + fx;
+            if (xx < 0 || xx >= W) continue;
+            int64_t ti = base + (int64_t)yy * W + xx;
+            float tnx = nrm[3 * ti], tny = nrm[3 * ti + 1], tnz = nrm[3 * ti + 2];
+            float tz = zdz[2 * ti], tdz = zdz[2 * ti + 1];
+            float dist_sqr = (float)(fx * fx + fy * fy);
+            float dist = sqrtf(dist_sqr);
+            float w_xy = expf(-dist_sqr / (2.0f * variance));
+            float w_normal = powf(fminf(fmaxf(tnx * cnx + tny * cny + tnz * cnz, FLT_EPS_D), 1.0f), 128.0f);
+            // the reference's backward uses the TAP's dz in the depth weight (denoising.cu:118); replicated
+            float w_depth = expf(-(fabsf(tz - cz) / fmaxf((BWD ? tdz : cdz) * dist, FLT_EPS_D)));
+            float w = w_xy * w_normal * w_depth;
+            if (!BWD) {
+                ax += col[3 * ti] * w;
+                ay += col[3 * ti + 1] * w;
+                az += col[3 * ti + 2] * w;
+                acc_w += w;
+            } else {
+                ax += w * g_out[4 * ti];
+                ay += w * g_out[4 * ti + 1];
+                az += w * g_out[4 * ti + 2];
+            }
+        }
+    }
+    if (!BWD) {
+        out[4 * ci] = ax;
+        out[4 * ci + 1] = ay;
+        out[4 * ci + 2] = az;
+        out[4 * ci + 3] = fmaxf(acc_w, 0.0001f);
+    } else {
+        g_col[3 * ci] = ax;
+        g_col[3 * ci + 1] = ay;
+        g_col[3 * ci + 2] = az;
+    }
+}
+
+}  // namespace
+
+extern "C" int gs_env_shade_fwd(const gs_bvh* bvh, const float* mask, const float* ro, const float* gb_pos, const float* gb_normal,
+                                const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
+                                const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
+                                int64_t H, int64_t W, int bsdf, int n_samples_x, uint32_t rnd_seed, float shadow_scale, float* diff, float* spec,
+                                gs_stream_t stream) {
+    if (B * H * W == 0) return 0;
+    GS_REQUIRE(diff && spec, "gs_env_shade_fwd: null output");
+    ShadeArgs A{};
+    int rc = fill_args(A, bvh, mask, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl, perms, P, B, H, W, bsdf,
+                       n_samples_x, rnd_seed, shadow_scale);
+    if (rc) return rc;
+    A.diff = diff;
+    A.spec = spec;
+    GS_HIP_CHECK(hipMemsetAsync(diff, 0, (size_t)B * H * W * 12, (hipStream_t)stream));
+    GS_HIP_CHECK(hipMemsetAsync(spec, 0, (size_t)B * H * W * 12, (hipStream_t)stream));
+    int64_t lanes = B * H * W * A.G;
+    hipLaunchKernelGGL(k_env_shade<false>, dim3((unsigned)gs::cdiv(lanes, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_env_shade_bwd(const gs_bvh* bvh, const float* mask, const float* ro, const float* gb_pos, const float* gb_normal,
+                                const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
+                                const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
+                                int64_t H, int64_t W, int bsdf, int n_samples_x, uint32_t rnd_seed, float shadow_scale, const float* g_diff,
+                                const float* g_spec, float* g_pos, float* g_normal, float* g_kd, float* g_ks, float* g_light,
+                                gs_stream_t stream) {
+    if (B * H * W == 0) return 0;
+    GS_REQUIRE(g_diff && g_spec && g_pos && g_normal && g_kd && g_ks && g_light, "gs_env_shade_bwd: null pointer");
+    ShadeArgs A{};
+    int rc = fill_args(A, bvh, mask, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl, perms, P, B, H, W, bsdf,
+                       n_samples_x, rnd_seed, shadow_scale);
+    if (rc) return rc;
+    A.g_diff = g_diff; A.g_spec = g_spec; A.g_pos = g_pos; A.g_nrm = g_normal; A.g_kd = g_kd; A.g_ks = g_ks; A.g_light = g_light;
+    size_t nb = (size_t)B * H * W * 12;
+    GS_HIP_CHECK(hipMemsetAsync(g_pos, 0, nb, (hipStream_t)stream));
+    GS_HIP_CHECK(hipMemsetAsync(g_normal, 0, nb, (hipStream_t)stream));
+    GS_HIP_CHECK(hipMemsetAsync(g_kd, 0, nb, (hipStream_t)stream));
+    GS_HIP_CHECK(hipMemsetAsync(g_ks, 0, nb, (hipStream_t)stream));
+    int64_t lanes = B * H * W * A.G;
+    hipLaunchKernelGGL(k_env_shade<true>, dim3((unsigned)gs::cdiv(lanes, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+static int bilateral_radius(float sigma) { return 2 * (int)std::ceil(sigma * 2.5f) + 1; }
+
+extern "C" int gs_bilateral_fwd(const float* col, const float* nrm, const float* zdz, int64_t B, int64_t H, int64_t W, float sigma, float* out,
+                                gs_stream_t stream) {
+    if (B * H * W == 0) return 0;
+    GS_REQUIRE(col && nrm && zdz && out && sigma > 0.f, "gs_bilateral_fwd: null pointer / sigma <= 0");
+    dim3 grid((unsigned)gs::cdiv(W, 16), (unsigned)gs::cdiv(H, 16), (unsigned)B);
+    hipLaunchKernelGGL(k_bilateral<false>, grid, dim3(256), 0, (hipStream_t)stream, col, nrm, zdz, B, (int)H, (int)W, sigma, bilateral_radius(sigma),
+                       out, (const float*)nullptr, (float*)nullptr);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_bilateral_bwd(const float* nrm, const float* zdz, int64_t B, int64_t H, int64_t W, float sigma, const float* g_out, float* g_col,
+                                gs_stream_t stream) {
+    if (B * H * W == 0) return 0;
+    GS_REQUIRE(nrm && zdz && g_out && g_col && sigma > 0.f, "gs_bilateral_bwd: null pointer / sigma <= 0");
+    dim3 grid((unsigned)gs::cdiv(W, 16), (unsigned)gs::cdiv(H, 16), (unsigned)B);
+    hipLaunchKernelGGL(k_bilateral<true>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, nrm, zdz, B, (int)H, (int)W, sigma,
+                       bilateral_radius(sigma), (float*)nullptr, g_out, g_col);
+    GS_LAUNCH_CHECK();
+    return 0;
+}

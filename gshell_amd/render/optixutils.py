@@ -1,0 +1,172 @@
+"""`render.optixutils` surface of the reference (render/optixutils/ops.py:128-147) on MI355X:
+software BVH + Monte-Carlo environment shading with shadow rays + bilateral denoiser, all HIP
+(gshell_amd/csrc/{bvh,envshade}.hip) behind the C ABI.  No OptiX, no NVRTC, nothing compiled at import."""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import c_float, c_int, c_int64, c_void_p, check, ptr, stream
+
+c_uint32 = ctypes.c_uint32
+PERM_ROWS = 32768          # rows of the stratification permutation table (ops.py:89)
+_BSDF_IDS = ['pbr', 'diffuse', 'white']   # ordering must match the kernel (ops.py:142)
+
+
+class OptiXContext:
+    """Holds the shadow-ray acceleration structure of the current mesh (name kept for drop-in use;
+    there is no OptiX here).  One context per device."""
+
+    def __init__(self):
+        self._h = c_void_p(0)
+        check(_lib.lib().gs_bvh_create(ctypes.byref(self._h)), "gs_bvh_create")
+        self.num_tris = 0
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        T, d, l, b = c_int64(), c_int64(), c_int64(), c_int64()
+        check(_lib.lib().gs_bvh_info(self._h, ctypes.byref(T), ctypes.byref(d), ctypes.byref(l), ctypes.byref(b)))
+        return dict(T=T.value, depth=d.value, leaf_size=l.value, bytes=b.value)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().gs_bvh_destroy(self._h)
+                self._h = c_void_p(0)
+        except Exception:
+            pass
+
+
+def optix_build_bvh(optix_ctx, verts, tris, rebuild):
+    """verts [V,3] f32, tris [T,3] i32; empty meshes are legal (ops.py:133-139).  `rebuild` is accepted
+    for signature compatibility; the structure is always rebuilt (the reference passes rebuild=1)."""
+    verts = verts.detach().reshape(-1, 3).contiguous().float()
+    tris = tris.reshape(-1, 3).contiguous()
+    if tris.dtype != torch.int32:
+        tris = tris.int()
+    with torch.cuda.device(verts.device):
+        check(_lib.lib().gs_bvh_build(optix_ctx.handle, ptr(verts, torch.float32, "verts"), c_int64(verts.shape[0]), ptr(tris, torch.int32, "tris"),
+                                      c_int64(tris.shape[0]), stream()), "gs_bvh_build")
+    optix_ctx.num_tris = int(tris.shape[0])
+
+
+def any_hit(optix_ctx, origins, dirs):
+    """Stand-alone shadow query: uint8 [n], 1 = occluded."""
+    o, d = origins.detach().reshape(-1, 3).contiguous().float(), dirs.detach().reshape(-1, 3).contiguous().float()
+    hit = torch.empty((o.shape[0],), dtype=torch.uint8, device=o.device)
+    with torch.cuda.device(o.device):
+        check(_lib.lib().gs_bvh_any_hit(optix_ctx.handle, ptr(o), ptr(d), c_int64(o.shape[0]), ptr(hit), stream()), "gs_bvh_any_hit")
+    return hit
+
+
+_random_perm = {}
+
+
+def random_perm(n_samples_x, device):
+    """[32768, n^2] int32 table of random permutations that decorrelates the light / BSDF strata
+    (ops.py:86-89).  Seeded, so every rank of a view-sharded job holds the same table."""
+    key = (n_samples_x, str(device))
+    if key not in _random_perm:
+        g = torch.Generator(device="cpu").manual_seed(0x6553 + n_samples_x)
+        _random_perm[key] = torch.argsort(torch.rand(PERM_ROWS, n_samples_x * n_samples_x, generator=g), dim=-1).int().to(device)
+    return _random_perm[key]
+
+
+def set_random_perm(n_samples_x, table):
+    _random_perm[(n_samples_x, str(table.device))] = table.int().contiguous()
+
+
+class _optix_env_shade_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, BSDF, n_samples_x, rnd_seed,
+                shadow_scale):
+        _rnd_seed = int(np.random.randint(2 ** 31)) if rnd_seed is None else int(rnd_seed)
+        B, H, W, _ = gb_pos.shape
+        dev = gb_pos.device
+        full = (B, H, W, 3)
+
+        def c3(t):
+            return t.detach().expand(full).contiguous().float()
+        t_mask = mask.detach().expand(B, H, W).contiguous().float()
+        t = dict(ro=c3(ro), pos=c3(gb_pos), nrm=c3(gb_normal), kd=c3(gb_kd), ks=c3(gb_ks))
+        if tuple(gb_view_pos.shape) not in ((B, 1, 1, 3), (1, 1, 1, 3)):
+            raise _lib.GShellHipError(f"gb_view_pos must be [B,1,1,3] (one eye per view), got {tuple(gb_view_pos.shape)}")
+        view = gb_view_pos.detach().expand(B, 1, 1, 3).reshape(B, 3).contiguous().float()
+        lgt, t_pdf, t_rows, t_cols = (x.detach().contiguous().float() for x in (light, pdf, rows, cols))
+        perms = random_perm(n_samples_x, dev)
+        diff = torch.empty(full, dtype=torch.float32, device=dev)
+        spec = torch.empty(full, dtype=torch.float32, device=dev)
+        ctx.args = (optix_ctx, t_mask, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, rnd_seed, _rnd_seed, shadow_scale)
+        with torch.cuda.device(dev):
+            check(_lib.lib().gs_env_shade_fwd(optix_ctx.handle, ptr(t_mask), ptr(t["ro"]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view), ptr(t["kd"]),
+                                              ptr(t["ks"]), ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]),
+                                              c_int64(lgt.shape[1]), ptr(perms, torch.int32), c_int64(perms.shape[0]), c_int64(B), c_int64(H),
+                                              c_int64(W), c_int(BSDF), c_int(n_samples_x), c_uint32(_rnd_seed & 0xFFFFFFFF), c_float(shadow_scale),
+                                              ptr(diff), ptr(spec), stream()), "gs_env_shade_fwd")
+        ctx.shapes = (gb_pos.shape, gb_normal.shape, gb_kd.shape, gb_ks.shape, light.shape)
+        return diff, spec
+
+    @staticmethod
+    def backward(ctx, diff_grad, spec_grad):
+        optix_ctx, t_mask, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, rnd_seed, _fwd_seed, shadow_scale = ctx.args
+        # like the reference (ops.py:100): a None seed ("decorrelated") draws a fresh seed for the backward pass
+        _rnd_seed = int(np.random.randint(2 ** 31)) if rnd_seed is None else _fwd_seed
+        B, H, W, _ = t["pos"].shape
+        dev = t["pos"].device
+        gd, gs = diff_grad.contiguous().float(), spec_grad.contiguous().float()
+        g_pos, g_nrm, g_kd, g_ks = (torch.empty((B, H, W, 3), dtype=torch.float32, device=dev) for _ in range(4))
+        g_light = torch.zeros_like(lgt)
+        with torch.cuda.device(dev):
+            check(_lib.lib().gs_env_shade_bwd(optix_ctx.handle, ptr(t_mask), ptr(t["ro"]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view), ptr(t["kd"]),
+                                              ptr(t["ks"]), ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]),
+                                              c_int64(lgt.shape[1]), ptr(perms), c_int64(perms.shape[0]), c_int64(B), c_int64(H), c_int64(W),
+                                              c_int(BSDF), c_int(n_samples_x), c_uint32(_rnd_seed & 0xFFFFFFFF), c_float(shadow_scale), ptr(gd),
+                                              ptr(gs), ptr(g_pos), ptr(g_nrm), ptr(g_kd), ptr(g_ks), ptr(g_light), stream()), "gs_env_shade_bwd")
+        s = ctx.shapes
+
+        def red(g, shape):
+            return g if tuple(shape) == tuple(g.shape) else g.sum_to_size(shape)
+        return (None, None, None, red(g_pos, s[0]), red(g_nrm, s[1]), None, red(g_kd, s[2]), red(g_ks, s[3]), g_light, None, None, None, None, None,
+                None, None)
+
+
+def optix_env_shade(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, BSDF='pbr', n_samples_x=8,
+                    rnd_seed=None, shadow_scale=1.0):
+    """-> (diffuse [B,H,W,3], specular [B,H,W,3]) demodulated radiance (ops.py:141-143)."""
+    iBSDF = _BSDF_IDS.index(BSDF)
+    return _optix_env_shade_func.apply(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, iBSDF,
+                                       n_samples_x, rnd_seed, shadow_scale)
+
+
+class _bilateral_denoiser_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, col, nrm, zdz, sigma):
+        col_c, nrm_c, zdz_c = (x.detach().contiguous().float() for x in (col, nrm, zdz))
+        B, H, W, _ = col_c.shape
+        out = torch.empty((B, H, W, 4), dtype=torch.float32, device=col_c.device)
+        with torch.cuda.device(col_c.device):
+            check(_lib.lib().gs_bilateral_fwd(ptr(col_c, torch.float32, "col"), ptr(nrm_c), ptr(zdz_c), c_int64(B), c_int64(H), c_int64(W),
+                                              c_float(sigma), ptr(out), stream()), "gs_bilateral_fwd")
+        ctx.save_for_backward(nrm_c, zdz_c)
+        ctx.sigma = sigma
+        return out
+
+    @staticmethod
+    def backward(ctx, out_grad):
+        nrm_c, zdz_c = ctx.saved_tensors
+        B, H, W, _ = nrm_c.shape
+        g = out_grad.contiguous().float()
+        g_col = torch.empty((B, H, W, 3), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            check(_lib.lib().gs_bilateral_bwd(ptr(nrm_c), ptr(zdz_c), c_int64(B), c_int64(H), c_int64(W), c_float(ctx.sigma), ptr(g), ptr(g_col),
+                                              stream()), "gs_bilateral_bwd")
+        return g_col, None, None, None
+
+
+def bilateral_denoiser(col, nrm, zdz, sigma):
+    col_w = _bilateral_denoiser_func.apply(col, nrm, zdz, sigma)
+    return col_w[..., 0:3] / col_w[..., 3:4]

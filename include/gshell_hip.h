@@ -221,6 +221,57 @@ int gs_texture_linear_fwd(const float* tex, int64_t B, int64_t H, int64_t W, int
 int gs_texture_linear_bwd(int64_t B, int64_t H, int64_t W, int64_t C, const float* uv,
                           int64_t n_per_view, const float* g_out, float* g_tex, gs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Shadow-ray acceleration structure   (replaces ou.OptiXContext / ou.optix_build_bvh,
+ *   render/optixutils/ops.py:128-139 -> c_src/torch_bindings.cpp:37-116; rebuilt every
+ *   iteration by geometry/gshell_tets_geometry.py:211)
+ *   The object owns its device buffers (grown on demand); verts [V,3] f32, tris [T,3] i32.
+ *   T == 0 is legal (every ray is unoccluded).  gs_bvh_any_hit: hit[i] = 1 if ray
+ *   (origins[i], dirs[i]) meets any triangle at t in (0, 1e16)  (kernel.cu:101-117).
+ * ---------------------------------------------------------------------------------- */
+typedef struct gs_bvh gs_bvh;
+int gs_bvh_create(gs_bvh** out);
+int gs_bvh_destroy(gs_bvh* bvh);
+int gs_bvh_build(gs_bvh* bvh, const float* verts, int64_t V, const int32_t* tris, int64_t T,
+                 gs_stream_t stream);
+int gs_bvh_info(const gs_bvh* bvh, int64_t* T, int64_t* depth, int64_t* leaf_size, int64_t* bytes);
+int gs_bvh_any_hit(const gs_bvh* bvh, const float* origins, const float* dirs, int64_t n,
+                   uint8_t* hit, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Monte-Carlo environment shading   (replaces ou.optix_env_shade, render/optixutils/ops.py:81-108,
+ *   :141-143; raygen program c_src/envsampling/kernel.cu:463-541; BSDF c_src/bsdf.h)
+ *   mask [B,H,W]; ro, gb_pos, gb_normal, gb_kd, gb_ks [B,H,W,3]; view_pos [B,3];
+ *   light [Hl,Wl,3], pdf [Hl,Wl], rows [Hl], cols [Hl,Wl]; perms [P, n^2] i32;
+ *   bsdf 0 'pbr' / 1 'diffuse' / 2 'white'; rays per pixel and pass = 2 n^2.
+ *   fwd: diff, spec [B,H,W,3] WRITTEN.  bwd re-traces with the same sampling:
+ *   g_pos, g_normal, g_kd, g_ks [B,H,W,3] WRITTEN; g_light [Hl,Wl,3] ACCUMULATED (atomics).
+ *   ro and view_pos receive no gradient, as in the reference (ops.py:108).
+ * ---------------------------------------------------------------------------------- */
+int gs_env_shade_fwd(const gs_bvh* bvh, const float* mask, const float* ro, const float* gb_pos,
+                     const float* gb_normal, const float* view_pos, const float* gb_kd,
+                     const float* gb_ks, const float* light, const float* pdf, const float* rows,
+                     const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P,
+                     int64_t B, int64_t H, int64_t W, int bsdf, int n_samples_x, uint32_t rnd_seed,
+                     float shadow_scale, float* diff, float* spec, gs_stream_t stream);
+int gs_env_shade_bwd(const gs_bvh* bvh, const float* mask, const float* ro, const float* gb_pos,
+                     const float* gb_normal, const float* view_pos, const float* gb_kd,
+                     const float* gb_ks, const float* light, const float* pdf, const float* rows,
+                     const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P,
+                     int64_t B, int64_t H, int64_t W, int bsdf, int n_samples_x, uint32_t rnd_seed,
+                     float shadow_scale, const float* g_diff, const float* g_spec, float* g_pos,
+                     float* g_normal, float* g_kd, float* g_ks, float* g_light, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Bilateral denoiser   (replaces ou.bilateral_denoiser, render/optixutils/ops.py:110-123, :145-147;
+ *   c_src/denoising.cu:14-130).  col, nrm [B,H,W,3], zdz [B,H,W,2] -> out [B,H,W,4] = (sum w c, max(sum w, 1e-4));
+ *   bwd: g_out [B,H,W,4] -> g_col [B,H,W,3] WRITTEN (the reference's non-adjoint depth weight is kept).
+ * ---------------------------------------------------------------------------------- */
+int gs_bilateral_fwd(const float* col, const float* nrm, const float* zdz, int64_t B, int64_t H,
+                     int64_t W, float sigma, float* out, gs_stream_t stream);
+int gs_bilateral_bwd(const float* nrm, const float* zdz, int64_t B, int64_t H, int64_t W, float sigma,
+                     const float* g_out, float* g_col, gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
