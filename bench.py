@@ -1,0 +1,144 @@
+"""Benchmark of the G-Shell training iteration on MI355X (contract: see the round prompt).
+
+    python bench.py [--gpus N --steps K --warmup W]           # N>1: launched by torch.distributed.run, one rank per GPU
+
+One "step" = one full optimisation iteration (train_gshelltet_deepfashion.py:395-478 bracket): zero_grad, lgt.update_pdf,
+geometry.tick (SDF MLP over the whole tet grid -> G-MarchingTets extraction -> BVH rebuild -> rasterise -> interpolate ->
+hash-grid texture -> Monte-Carlo env shading with shadow rays -> bilateral denoise -> composite + antialias -> losses),
+backward, 3 Adam steps, clamps -- on synthetic inputs of BASELINE.json configs[2]: tet-res256, 4 views of 512x512 per GPU,
+n_samples = 8 (128 shadow rays / covered pixel / pass).  Views are sharded across ranks (weak scaling: 4 views per GPU);
+geometry is replicated; one RCCL all-reduce of the flat gradient per iteration.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--res", type=int, default=256, help="tet grid resolution (64/128/256)")
+    ap.add_argument("--views", type=int, default=4, help="views per GPU")
+    ap.add_argument("--train-res", type=int, default=512)
+    ap.add_argument("--n-samples", type=int, default=8)
+    ap.add_argument("--fit-steps", type=int, default=400)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--op-times", action="store_true", help="also print per-op HIP-event times (adds sync points)")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from gshell_amd import _lib, workload
+    from gshell_amd.train import ViewShard
+    _lib.lib()                                     # fail loudly if the HIP library is missing
+    shard = ViewShard(rank, world)
+    B_local, B_global = a.views, a.views * world
+    H = W = a.train_res
+    trainer = workload.build(res=a.res, n_samples=a.n_samples, batch=B_global, train_res=(H, W), shard=shard, fit_steps=a.fit_steps)
+    # this rank's views of every global batch: ids [it*B + r, it*B + r + world, ...]
+    n_iters = a.warmup + a.steps
+    targets = [workload.make_targets(trainer, [(it * B_global + v) % 72 for v in shard.local_views(B_global)], (H, W)) for it in range(min(n_iters, 4))]
+    _lib.enable_op_timing(True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for it in range(a.warmup):
+        trainer.step(targets[it % len(targets)], global_batch=B_global)
+    barrier()
+    _lib.reset_op_timing()
+    t0 = time.perf_counter()
+    for it in range(a.steps):
+        trainer.step(targets[(a.warmup + it) % len(targets)], global_batch=B_global)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    op_times = _lib.op_timing_summary()
+    if rank == 0:
+        g = trainer.geometry
+        with torch.no_grad():
+            d = g.getMesh(trainer.mat)
+        N, Ftets = g.verts.shape[0], g.indices.shape[0]
+        V_aug, T = d['imesh'].v_pos.shape[0], d['imesh'].t_pos_idx.shape[0]
+        ms = dt / a.steps * 1e3
+        mpix = B_global * H * W * a.steps / dt / 1e6
+        out = {
+            "metric": "train iters/sec + rendered Mpixels/sec, tet-res256 @512², batch=4",
+            "value": round(mpix, 4), "unit": "Mpixels/s", "iters_per_sec": round(a.steps / dt, 4),
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"tet-res{a.res} (BCC {N} verts / {Ftets} tets), {B_local} views/GPU x {H}x{W}, n_samples={a.n_samples} "
+                                   f"({2 * a.n_samples ** 2} shadow rays/px/pass), full train iteration fwd+bwd+3xAdam",
+                       "global_batch": B_global, "mesh": {"V_aug": V_aug, "T": T}, "parallelism": f"view-shard dp{world}, geometry replicated"},
+        }
+        roof = roofline(op_times, N, Ftets, V_aug, T, B_local, H, W, a.n_samples)
+        if roof:
+            out["roofline"] = roof
+        if a.op_times:
+            out["op_ms"] = {k: round(v["ms"], 4) for k, v in sorted(op_times.items(), key=lambda kv: -kv[1]["ms"] * kv[1]["n"])}
+            out["op_calls_per_step"] = {k: v["n"] / a.steps for k, v in op_times.items()}
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def roofline(op_times, N, Ftets, V_aug, T, B, H, W, n):
+    """Roofline of the dominant hand-written kernel family of the iteration (HIP events around its C-ABI launch)."""
+    if not op_times:
+        return None
+    name, rec = max(op_times.items(), key=lambda kv: kv[1]["ms"] * kv[1]["n"])
+    npix = B * H * W
+    # algorithmic HBM bytes per launch (DESIGN.md "Kernels"): inputs read once + outputs written once
+    alg = {
+        "gs_env_shade_fwd": npix * (4 + 6 * 12 + 24),
+        "gs_env_shade_bwd": npix * (4 + 6 * 12 + 24 + 48),
+        "gs_mtets_count": 16 * Ftets + 20 * N, "gs_mtets_fill": 16 * Ftets + 20 * N + 20 * V_aug + 12 * T,
+        "gs_bilateral_fwd": npix * (12 + 12 + 8 + 16), "gs_bilateral_bwd": npix * (12 + 8 + 16 + 12),
+        "gs_hashgrid_fwd": npix * (12 + 4 + 128), "gs_hashgrid_bwd": npix * (12 + 4 + 128 + 12 * 16),
+        "gs_rasterize_fwd": B * (16 * V_aug + 12 * T) + npix * 40, "gs_aa_apply_fwd": npix * 8 * 45, "gs_aa_apply_bwd": npix * 12 * 45,
+    }.get(name)
+    if alg is None:
+        return {"kernel": name, "bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
+                "avg_launch_ms": round(rec["ms"], 4)}
+    gbps = alg / (rec["ms"] * 1e-3) / 1e9
+    return {"kernel": name, "bound": "hbm", "achieved": round(gbps, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 5), "traffic": None,
+            "avg_launch_ms": round(rec["ms"], 4), "algorithmic_bytes": int(alg),
+            "note": "ray-traversal kernels are latency/ALU bound; rays/s reported in DESIGN.md"}
+
+
+def cpu_baseline():
+    try:
+        from oracle import pipeline_oracle
+    except Exception as e:           # pragma: no cover
+        return {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+    return pipeline_oracle.timed_sample()
+
+
+if __name__ == "__main__":
+    main()

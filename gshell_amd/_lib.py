@@ -75,3 +75,58 @@ def ptr(t, dtype=None, name="tensor"):
 
 def stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---- optional per-op timing (bench.py): HIP events recorded on the launch stream around each C-ABI call -------------
+_timing = {"on": False, "pending": [], "done": {}}
+
+
+class _TimedLib:
+    """Proxy over the ctypes library that brackets every gs_* launch with torch.cuda events on the current stream
+    (the stream the kernels are launched on).  Only used when bench.py enables it."""
+
+    def __init__(self, real):
+        object.__setattr__(self, "_real", real)
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if not _timing["on"] or not name.startswith("gs_") or name.endswith(("_bytes", "_partials", "_params", "_info", "_create", "_destroy", "last_error", "version")):
+            return fn
+
+        def timed(*args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            _timing["pending"].append((name, e0, e1))
+            return rc
+        return timed
+
+
+_real_lib_fn = lib
+
+
+def lib():      # noqa: F811  (wraps the loader defined above)
+    real = _real_lib_fn()
+    return _TimedLib(real) if _timing["on"] else real
+
+
+def enable_op_timing(flag):
+    _timing["on"] = bool(flag)
+
+
+def reset_op_timing():
+    torch.cuda.synchronize()
+    _timing["pending"].clear()
+    _timing["done"].clear()
+
+
+def op_timing_summary():
+    """{op: {"ms": mean launch-to-completion ms, "n": launches}} since the last reset."""
+    torch.cuda.synchronize()
+    for name, e0, e1 in _timing["pending"]:
+        rec = _timing["done"].setdefault(name, {"ms": 0.0, "n": 0})
+        rec["ms"] += e0.elapsed_time(e1)
+        rec["n"] += 1
+    _timing["pending"].clear()
+    return {k: {"ms": v["ms"] / max(v["n"], 1), "n": v["n"]} for k, v in _timing["done"].items()}

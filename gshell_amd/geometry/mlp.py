@@ -1,0 +1,49 @@
+"""SDF network of G-Shell (reference geometry/mlp.py:7-40 + geometry/embedding.py:4-39):
+positional encoding (x, sin(2^k x), cos(2^k x))_{k<n_freq} -> Linear+Softplus(beta=100) stack with an optional
+skip-concatenation of the encoding -> Linear(d_hidden, d_out).  Module / parameter names match the reference so that
+`state_dict()` round-trips ("sdf_net.net.<i>.weight").
+
+This file is the plain-torch (rocBLAS) formulation; the fused MFMA kernel path is gshell_amd/csrc/mlp.hip."""
+import torch
+import torch.nn as nn
+
+
+class Embedding(nn.Module):
+    def __init__(self, in_channels, N_freqs, logscale=True):
+        super().__init__()
+        self.N_freqs, self.in_channels = N_freqs, in_channels
+        self.out_channels = in_channels * (2 * N_freqs + 1)
+        if logscale:
+            self.freq_bands = [2.0 ** k for k in range(N_freqs)]
+        else:
+            self.freq_bands = torch.linspace(1, 2 ** (N_freqs - 1), N_freqs).tolist()
+
+    def forward(self, x):
+        feats = [x]
+        for f in self.freq_bands:
+            fx = f * x
+            feats += [torch.sin(fx), torch.cos(fx)]
+        return torch.cat(feats, -1)
+
+
+class MLP(nn.Module):
+    def __init__(self, n_freq=6, d_hidden=128, d_out=1, n_hidden=3, skip_in=[], use_float16=False):
+        super().__init__()
+        self.emb = Embedding(3, n_freq)
+        layers = [nn.Linear(self.emb.out_channels, d_hidden), nn.Softplus(beta=100)]
+        self.skip_count, self.skip_in = [], skip_in
+        for i in range(n_hidden):
+            wide = i in skip_in
+            if wide:
+                self.skip_count.append(len(layers))
+            layers += [nn.Linear(d_hidden + (self.emb.out_channels if wide else 0), d_hidden), nn.Softplus(beta=100)]
+        layers.append(nn.Linear(d_hidden, d_out))
+        self.net = nn.ModuleList(layers)
+        self.use_float16 = use_float16
+
+    def forward(self, x):
+        emb = self.emb(x)
+        h = emb
+        for i, module in enumerate(self.net):
+            h = module(torch.cat([h, emb], dim=-1) if i in self.skip_count else h)
+        return h

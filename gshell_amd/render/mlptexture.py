@@ -1,0 +1,130 @@
+"""MLPTexture3D with the reference's surface (render/mlptexture.py:18-106): multiresolution hash-grid
+encoding (HIP, gshell_amd/csrc/hashgrid.hip) + a 32-wide bias-free ReLU MLP + sigmoid range mapping."""
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import c_float, c_int, c_int64, check, ptr, stream
+
+
+class _HashGridFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, params, mask, cfg):
+        L = _lib.lib()
+        x_c = x.detach().contiguous().float()
+        p_c = params.detach().contiguous().float()
+        m_c = None if mask is None else mask.detach().reshape(-1).contiguous().float()
+        N = x_c.shape[0]
+        out = torch.empty((N, cfg[0] * cfg[1]), dtype=torch.float32, device=x_c.device)
+        with torch.cuda.device(x_c.device):
+            check(L.gs_hashgrid_fwd(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4]), ptr(x_c, torch.float32, "x"),
+                                    ptr(m_c), c_int64(N), ptr(p_c, torch.float32, "params"), ptr(out), stream()), "gs_hashgrid_fwd")
+        ctx.save_for_backward(x_c, p_c, m_c)
+        ctx.cfg = cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x_c, p_c, m_c = ctx.saved_tensors
+        cfg = ctx.cfg
+        N = x_c.shape[0]
+        g = g_out.contiguous().float()
+        need_x, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_params = torch.zeros_like(p_c) if need_p else None
+        g_xl = torch.empty((cfg[0], N, 3), dtype=torch.float32, device=g.device) if need_x else None
+        with torch.cuda.device(g.device):
+            check(_lib.lib().gs_hashgrid_bwd(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4]), ptr(x_c), ptr(m_c), c_int64(N),
+                                             ptr(p_c), ptr(g), ptr(g_params), ptr(g_xl), stream()), "gs_hashgrid_bwd")
+        return (g_xl.sum(0) if need_x else None), g_params, None, None
+
+
+class _ScaleGrad(torch.autograd.Function):
+    """identity forward, gradient * s backward (the reference does this with module backward hooks,
+    render/mlptexture.py:31, :74)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.s, None
+
+
+class HashGridEncoding(torch.nn.Module):
+    """Stand-in for `tcnn.Encoding(3, {"otype": "HashGrid", ...})`: same config keys, `.params`,
+    `.n_output_dims`; parameters are fp32 and initialised U(-1e-4, 1e-4) like tiny-cuda-nn."""
+
+    def __init__(self, n_input_dims, encoding_config, seed=1337):
+        super().__init__()
+        if n_input_dims != 3 or encoding_config.get("otype") != "HashGrid":
+            raise NotImplementedError("only the 3-D HashGrid encoding used by MLPTexture3D is implemented")
+        c = encoding_config
+        self.cfg = (int(c["n_levels"]), int(c["n_features_per_level"]), int(c["log2_hashmap_size"]), int(c["base_resolution"]),
+                    float(c["per_level_scale"]))
+        self.n_output_dims = self.cfg[0] * self.cfg[1]
+        n = _lib.lib().gs_hashgrid_num_params(c_int(self.cfg[0]), c_int(self.cfg[1]), c_int(self.cfg[2]), c_int(self.cfg[3]), c_float(self.cfg[4]))
+        if n < 0:
+            raise _lib.GShellHipError(_lib.lib().gs_last_error().decode())
+        g = torch.Generator().manual_seed(seed)
+        self.params = torch.nn.Parameter((torch.rand(n, generator=g) * 2e-4 - 1e-4).cuda())
+
+    def forward(self, x, mask=None):
+        return _HashGridFn.apply(x, self.params, mask, self.cfg)
+
+
+class _MLP(torch.nn.Module):
+    """32-wide bias-free ReLU MLP (render/mlptexture.py:18-44)."""
+
+    def __init__(self, cfg, loss_scale=1.0):
+        super().__init__()
+        self.loss_scale = loss_scale
+        net = (torch.nn.Linear(cfg['n_input_dims'], cfg['n_neurons'], bias=False), torch.nn.ReLU())
+        for _ in range(cfg['n_hidden_layers'] - 1):
+            net = net + (torch.nn.Linear(cfg['n_neurons'], cfg['n_neurons'], bias=False), torch.nn.ReLU())
+        net = net + (torch.nn.Linear(cfg['n_neurons'], cfg['n_output_dims'], bias=False),)
+        self.net = torch.nn.Sequential(*net).cuda()
+        self.net.apply(self._init_weights)
+
+    def forward(self, x):
+        # reference: full-backward hook scaling the gradient w.r.t. the MLP input by loss_scale (:31)
+        return self.net(_ScaleGrad.apply(x.to(torch.float32), self.loss_scale))
+
+    @staticmethod
+    def _init_weights(m):
+        if type(m) == torch.nn.Linear:
+            torch.nn.init.kaiming_uniform_(m.weight, nonlinearity='relu')
+
+
+class MLPTexture3D(torch.nn.Module):
+    def __init__(self, AABB, channels=3, internal_dims=32, hidden=2, min_max=None, use_float16=False):
+        super().__init__()
+        self.channels, self.internal_dims, self.AABB, self.min_max, self.use_float16 = channels, internal_dims, AABB, min_max, use_float16
+        desired_resolution, base_grid_resolution, num_levels = 4096, 16, 16
+        per_level_scale = np.exp(np.log(desired_resolution / base_grid_resolution) / (num_levels - 1))
+        enc_cfg = {"otype": "HashGrid", "n_levels": num_levels, "n_features_per_level": 2, "log2_hashmap_size": 19,
+                   "base_resolution": base_grid_resolution, "per_level_scale": per_level_scale}
+        gradient_scaling = 128.0
+        self.gradient_scaling = gradient_scaling
+        self.encoder = HashGridEncoding(3, enc_cfg)
+        mlp_cfg = {"n_input_dims": self.encoder.n_output_dims, "n_output_dims": self.channels, "n_hidden_layers": hidden,
+                   "n_neurons": self.internal_dims}
+        self.net = _MLP(mlp_cfg, gradient_scaling)
+
+    def sample(self, texc, mask=None):
+        """texc [...,3] world positions -> [..., channels].  `mask` (optional, [...]) skips rows whose value cannot
+        reach any output (background pixels); the reference evaluates them and then discards them."""
+        _texc = (texc.view(-1, 3) - self.AABB[0][None, ...]) / (self.AABB[1][None, ...] - self.AABB[0][None, ...])
+        _texc = torch.clamp(_texc, min=0, max=1)
+        # reference: encoder backward hook divides the gradient w.r.t. the encoder input by 128 (:74)
+        p_enc = self.encoder(_ScaleGrad.apply(_texc.contiguous(), 1.0 / self.gradient_scaling), mask)
+        out = self.net.forward(p_enc)
+        out = torch.sigmoid(out) * (self.min_max[1][None, :] - self.min_max[0][None, :]) + self.min_max[0][None, :]
+        return out.view(*texc.shape[:-1], self.channels)
+
+    def clamp_(self):
+        pass
+
+    def cleanup(self):
+        pass

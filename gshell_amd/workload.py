@@ -1,0 +1,107 @@
+"""Synthetic G-Shell reconstruction workload (no datasets / tet grids / env maps ship with the build box).
+
+  grid     : BCC lattice standing in for data/tets/{res}_tets.npz (gshell_amd/grid.py), res 64/128/256 <-> 26/52/104 cells
+  state    : "mid-training" garment-like state: the SDF network is fitted to a capped-cone "skirt", the mSDF is a smooth
+             field that opens the top, deform ~ U(-0.3, 0.3) of its clamp range
+  cameras  : perspective fovy 60 deg (dataset/dataset_deepfashion.py:69-72), eye on a sphere, mvp = proj @ lookAt
+  targets  : images rendered once by this renderer from a perturbed state + alpha, random backgrounds
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import grid as gridlib
+from .render import util
+
+
+def look_at(eye, at=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0)):
+    eye, at, up = (np.asarray(v, dtype=np.float64) for v in (eye, at, up))
+    w = eye - at
+    w /= np.linalg.norm(w)
+    u = np.cross(up, w)
+    u /= np.linalg.norm(u)
+    v = np.cross(w, u)
+    m = np.eye(4)
+    m[0, :3], m[1, :3], m[2, :3] = u, v, w
+    m[:3, 3] = -m[:3, :3] @ eye
+    return m
+
+
+def camera(k, radius=2.2, fovy_deg=60.0):
+    """k-th pose of a fixed 72-pose orbit (golden-ratio azimuth, +-25 deg elevation)."""
+    k = k % 72
+    az = 2 * math.pi * ((k * 0.61803398875) % 1.0)
+    el = math.radians(-25.0 + 50.0 * ((k * 0.41421356237 + 0.25) % 1.0))
+    eye = radius * np.array([math.cos(el) * math.sin(az), math.sin(el), math.cos(el) * math.cos(az)])
+    proj = util.perspective(math.radians(fovy_deg), 1.0, 0.1, 1000.0).numpy().astype(np.float64)
+    return (proj @ look_at(eye)).astype(np.float32), eye.astype(np.float32)
+
+
+def views(indices, device, radius=2.2):
+    cams = [camera(k, radius) for k in indices]
+    return torch.tensor(np.stack([c[0] for c in cams]), device=device), torch.tensor(np.stack([c[1] for c in cams]), device=device)
+
+
+def skirt_sdf(x):
+    """Signed field whose zero set is a capped cone; sign convention of the reference's sphere init (positive outside)."""
+    r = torch.sqrt(x[:, 0] ** 2 + x[:, 2] ** 2)
+    inside = torch.minimum(0.42 - 0.22 * x[:, 1] - r, 0.5 - x[:, 1].abs())
+    return -inside
+
+
+def fit_sdf_net(geometry, steps=400, batch=65536, seed=0):
+    """Fit geometry.sdf_net to `skirt_sdf` on random grid-vertex subsets (stands in for the reference's 1000-step
+    full-grid sphere pre-training, gshell_tets_geometry.py:98-105, at a fraction of the start-up cost)."""
+    g = torch.Generator(device=geometry.verts.device).manual_seed(seed)
+    opt = torch.optim.Adam(geometry.sdf_net.parameters(), lr=1e-3)
+    N = geometry.verts.shape[0]
+    for _ in range(steps):
+        idx = torch.randint(0, N, (min(batch, N),), device=geometry.verts.device, generator=g)
+        x = geometry.verts[idx]
+        loss = (geometry.sdf_net(x)[:, 0] - skirt_sdf(x)).pow(2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    return float(loss)
+
+
+def set_mid_training_state(geometry, seed=0):
+    g = torch.Generator(device=geometry.verts.device).manual_seed(seed + 1)
+    v = geometry.verts
+    with torch.no_grad():
+        geometry.msdf.copy_((0.32 - v[:, 1] + 0.05 * torch.sin(8.0 * v[:, 0])).clamp(-2, 2))
+        geometry.deform.copy_((torch.rand(v.shape, device=v.device, generator=g) * 2 - 1) * 0.3)
+
+
+def make_targets(trainer, view_ids, res, seed=1):
+    """Reference images for the given views: this renderer's own output from a perturbed light, used as a fixed target."""
+    dev = trainer.geometry.verts.device
+    H, W = res
+    mvp, campos = views(view_ids, dev)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    B = len(view_ids)
+    bg = torch.rand(B, 1, 1, 3, device=dev, generator=g).expand(B, H, W, 3).contiguous()
+    target = {'mvp': mvp, 'campos': campos, 'resolution': [H, W], 'spp': 1, 'background': bg}
+    with torch.no_grad():
+        base = trainer.lgt.base.detach().clone()
+        trainer.lgt.base.data.mul_(1.6)
+        trainer.lgt.update_pdf()
+        buf = trainer.geometry.render(trainer.glctx, target, trainer.lgt, trainer.mat, denoiser=None, shadow_scale=1.0)['buffers']
+        trainer.lgt.base.data.copy_(base)
+        trainer.lgt.update_pdf()
+    target['img'] = torch.cat((buf['shaded'][..., 0:3].clamp(0, 4), (buf['shaded'][..., 3:4] > 0.5).float()), dim=-1).detach()
+    return target
+
+
+def build(res=256, n_samples=8, batch=4, train_res=(512, 512), shard=None, fit_steps=400, seed=0, **flag_overrides):
+    from .train import Trainer, default_flags
+    dev = torch.device("cuda", torch.cuda.current_device())
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    verts, tets = gridlib.grid_for_res(res, device=dev)
+    flags = default_flags(gshell_grid=res, n_samples=n_samples, batch=batch, train_res=list(train_res), sdf_mlp_pretrain_steps=0, **flag_overrides)
+    trainer = Trainer(flags, tet_grid=(verts, tets), shard=shard)
+    fit_sdf_net(trainer.geometry, steps=fit_steps, seed=seed)
+    set_mid_training_state(trainer.geometry, seed)
+    return trainer

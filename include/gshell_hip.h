@@ -272,6 +272,22 @@ int gs_bilateral_fwd(const float* col, const float* nrm, const float* zdz, int64
 int gs_bilateral_bwd(const float* nrm, const float* zdz, int64_t B, int64_t H, int64_t W, float sigma,
                      const float* g_out, float* g_col, gs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Multiresolution hash-grid encoding   (replaces tinycudann.Encoding(3, HashGrid cfg) as configured by
+ *   render/mlptexture.py:57-73 and sampled at render/render.py:68,70)
+ *   x [N,3] in [0,1], mask [N] (NULL = all rows; rows with mask <= 0 produce zeros),
+ *   params [gs_hashgrid_num_params] f32, out [N, n_levels*F].
+ *   bwd: g_params ACCUMULATED (atomics; may be NULL), g_x_levels [n_levels,N,3] WRITTEN per level
+ *   (the caller sums over levels; may be NULL).
+ * ---------------------------------------------------------------------------------- */
+int64_t gs_hashgrid_num_params(int n_levels, int F, int log2_T, int base_res, float per_level_scale);
+int gs_hashgrid_fwd(int n_levels, int F, int log2_T, int base_res, float per_level_scale,
+                    const float* x, const float* mask, int64_t N, const float* params, float* out,
+                    gs_stream_t stream);
+int gs_hashgrid_bwd(int n_levels, int F, int log2_T, int base_res, float per_level_scale,
+                    const float* x, const float* mask, int64_t N, const float* params,
+                    const float* g_out, float* g_params, float* g_x_levels, gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

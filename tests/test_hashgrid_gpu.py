@@ -1,0 +1,60 @@
+"""Hash-grid encoding: HIP path vs the CPU oracle (fwd, d/dparams, d/dx, masked rows)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hashgrid_oracle as ho
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+PLS = float(np.exp(np.log(4096 / 16) / 15))
+
+
+@pytest.mark.parametrize("cfg", [(16, 2, 19, 16, PLS), (4, 2, 10, 4, 1.7), (3, 4, 12, 8, 2.0)])
+def test_hashgrid_matches_oracle(cfg):
+    from gshell_amd.render.mlptexture import HashGridEncoding, _HashGridFn
+    gen = torch.Generator().manual_seed(0)
+    N = 3000
+    x = torch.rand(N, 3, generator=gen)
+    x[:7] = torch.tensor([[0, 0, 0], [1, 1, 1], [1, 0, 0.5], [0, 1, 1], [0.5, 0.5, 0.5], [1, 1, 0], [0.25, 1, 0]])
+    _, total = ho.level_meta(*cfg)
+    params = (torch.rand(total, generator=gen) - 0.5)
+    w = torch.randn(N, cfg[0] * cfg[1], generator=gen)
+    x_ref, p_ref = x.clone().requires_grad_(True), params.clone().requires_grad_(True)
+    out_ref = ho.encode(x_ref, p_ref, *cfg)
+    (out_ref * w).sum().backward()
+    enc = HashGridEncoding(3, {"otype": "HashGrid", "n_levels": cfg[0], "n_features_per_level": cfg[1], "log2_hashmap_size": cfg[2],
+                               "base_resolution": cfg[3], "per_level_scale": cfg[4]})
+    assert enc.params.numel() == total and enc.n_output_dims == cfg[0] * cfg[1]
+    assert float(enc.params.abs().max()) <= 1e-4
+    xd, pd = x.to(DEV).requires_grad_(True), params.to(DEV).requires_grad_(True)
+    out = _HashGridFn.apply(xd, pd, None, enc.cfg)
+    (out * w.to(DEV)).sum().backward()
+    # a 1-ulp difference in the level scale can move a point across a cell boundary at the finest levels: compare robustly
+    ok = ((out.cpu() - out_ref.detach()).abs() <= 1e-4 * out_ref.detach().abs() + 1e-5)
+    assert ok.float().mean() > 0.999
+    assert (pd.grad.cpu() - p_ref.grad).abs().max() <= 1e-3 * p_ref.grad.abs().max()
+    okx = ((xd.grad.cpu() - x_ref.grad).abs() <= 1e-3 * x_ref.grad.abs() + 1e-3 * x_ref.grad.abs().max())
+    assert okx.float().mean() > 0.995
+    # masked rows produce zeros and no gradient
+    mask = (torch.arange(N) % 3 != 0).float().to(DEV)
+    xm, pm = x.to(DEV).requires_grad_(True), params.to(DEV).requires_grad_(True)
+    om = _HashGridFn.apply(xm, pm, mask, enc.cfg)
+    assert (om[mask == 0] == 0).all() and torch.equal(om[mask > 0], out.detach()[mask > 0])
+    om.sum().backward()
+    assert (xm.grad[mask == 0] == 0).all()
+
+
+def test_mlptexture_sample_shapes_and_grads():
+    from gshell_amd.render.mlptexture import MLPTexture3D
+    aabb = (torch.tensor([-1.0, -1, -1], device=DEV), torch.tensor([1.0, 1, 1], device=DEV))
+    mn = torch.tensor([0, 0, 0, 0, 0.08, 0], dtype=torch.float32, device=DEV)
+    mx = torch.tensor([1, 1, 1, 0.3, 1, 1], dtype=torch.float32, device=DEV)
+    tex = MLPTexture3D(aabb, channels=6, min_max=[mn, mx])
+    pos = (torch.rand(2, 8, 9, 3, device=DEV) * 2 - 1).requires_grad_(True)
+    out = tex.sample(pos)
+    assert out.shape == (2, 8, 9, 6)
+    assert (out >= mn - 1e-6).all() and (out <= mx + 1e-6).all()
+    out.sum().backward()
+    assert tex.encoder.params.grad is not None and torch.isfinite(tex.encoder.params.grad).all()
+    assert pos.grad is not None and torch.isfinite(pos.grad).all()
