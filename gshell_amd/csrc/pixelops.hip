@@ -436,3 +436,82 @@ extern "C" int gs_texture_linear_bwd(int64_t B, int64_t H, int64_t W, int64_t C,
     GS_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- SDF sign-consistency regulariser over the static grid edges ------------------------------------------
+// Replaces compute_sdf_reg_loss (geometry/gshell_tets_geometry.py:33-39): for every grid edge (a,b) whose end
+// points differ in torch.sign(), BCE-with-logits(s_a, s_b > 0) + BCE-with-logits(s_b, s_a > 0), each averaged over
+// the crossing edges.  The reference gathers 2E values, builds a boolean mask, compacts (host sync) and lets
+// autograd scatter back (index_put backward = a device-wide sort): ~260 ms per iteration at tet-res 256.  Here it
+// is one streaming pass over the [E,2] int32 edge list (8 B / edge) with block-level partial sums, and a backward
+// pass that touches only the ~2 % crossing edges.
+namespace {
+
+__device__ __forceinline__ float sgn3(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+__device__ __forceinline__ float bce_logits(float x, float t) { return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void __launch_bounds__(256) k_sdf_reg_fwd(const float* __restrict__ sdf, const int2* __restrict__ edges, int64_t E,
+                                                     float* __restrict__ part_loss, float* __restrict__ part_cnt) {
+    float acc = 0.f, cnt = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        int2 ab = edges[e];
+        float sa = sdf[ab.x], sb = sdf[ab.y];
+        if (sgn3(sa) != sgn3(sb)) {
+            acc += bce_logits(sa, sb > 0.f ? 1.f : 0.f) + bce_logits(sb, sa > 0.f ? 1.f : 0.f);
+            cnt += 1.f;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_xor(acc, o, 64);
+        cnt += __shfl_xor(cnt, o, 64);
+    }
+    __shared__ float wa[4], wc[4];
+    if ((threadIdx.x & 63) == 0) {
+        wa[threadIdx.x >> 6] = acc;
+        wc[threadIdx.x >> 6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part_loss[blockIdx.x] = (wa[0] + wa[1]) + (wa[2] + wa[3]);
+        part_cnt[blockIdx.x] = (wc[0] + wc[1]) + (wc[2] + wc[3]);
+    }
+}
+
+// g_sdf += g * d/ds [ (sum_e l_e) / K ],  K = *count_dev (number of crossing edges)
+__global__ void __launch_bounds__(256) k_sdf_reg_bwd(const float* __restrict__ sdf, const int2* __restrict__ edges, int64_t E,
+                                                     const float* __restrict__ g_scalar, const float* __restrict__ count_dev,
+                                                     float* __restrict__ g_sdf) {
+    float K = count_dev[0];
+    if (!(K > 0.f)) return;
+    float g = g_scalar[0] / K;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        int2 ab = edges[e];
+        float sa = sdf[ab.x], sb = sdf[ab.y];
+        if (sgn3(sa) != sgn3(sb)) {
+            atomicAdd(&g_sdf[ab.x], g * (sigmoidf(sa) - (sb > 0.f ? 1.f : 0.f)));
+            atomicAdd(&g_sdf[ab.y], g * (sigmoidf(sb) - (sa > 0.f ? 1.f : 0.f)));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t gs_sdf_reg_partials(int64_t E) { return std::min<int64_t>(std::max<int64_t>(gs::cdiv(E, 256 * 8), 1), 4096); }
+
+extern "C" int gs_sdf_reg_fwd(const float* sdf, const int32_t* edges, int64_t E, float* part_loss, float* part_count, gs_stream_t stream) {
+    GS_REQUIRE(part_loss && part_count && (E == 0 || (sdf && edges)), "gs_sdf_reg_fwd: null pointer");
+    hipLaunchKernelGGL(k_sdf_reg_fwd, dim3((unsigned)gs_sdf_reg_partials(E)), dim3(256), 0, (hipStream_t)stream, sdf, (const int2*)edges, E, part_loss,
+                       part_count);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_sdf_reg_bwd(const float* sdf, const int32_t* edges, int64_t E, const float* g_scalar_dev, const float* count_dev, float* g_sdf,
+                              gs_stream_t stream) {
+    if (E == 0) return 0;
+    GS_REQUIRE(sdf && edges && g_scalar_dev && count_dev && g_sdf, "gs_sdf_reg_bwd: null pointer");
+    hipLaunchKernelGGL(k_sdf_reg_bwd, dim3((unsigned)gs_sdf_reg_partials(E)), dim3(256), 0, (hipStream_t)stream, sdf, (const int2*)edges, E, g_scalar_dev,
+                       count_dev, g_sdf);
+    GS_LAUNCH_CHECK();
+    return 0;
+}

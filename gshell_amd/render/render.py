@@ -20,6 +20,16 @@ from . import util
 
 rnd_seed = 0
 
+# Test hook: the reference draws three noise tensors from the global torch RNG (render/render.py:55, :68, :265).
+# Parity tests inject the same tensors on both sides through this table {name: tensor}; None = draw fresh noise.
+noise_override = None
+
+
+def _noise(name, draw):
+    if noise_override is not None and name in noise_override:
+        return noise_override[name]
+    return draw()
+
 
 def interpolate(attr, rast, attr_idx, rast_db=None):
     return dr.interpolate(attr.contiguous(), rast, attr_idx, rast_db=rast_db, diff_attrs=None if rast_db is None else 'all')
@@ -40,7 +50,7 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
           mesh, bsdf, denoiser, shadow_scale, use_uv=True, finetune_normal=True, xfm_lgt=None, shade_data=False):
     dev = gb_pos.device
     B, H, W = gb_depth.shape[0], gb_depth.shape[1], gb_depth.shape[2]
-    offset = torch.normal(mean=0, std=0.005, size=(B, H, W, 2), device=dev)
+    offset = _noise('jitter', lambda: torch.normal(mean=0, std=0.005, size=(B, H, W, 2), device=dev))
     jitter = (util.pixel_grid(W, H, device=dev)[None, ...] + offset).contiguous()
 
     mask = (rast[..., -1:] > 0).float()
@@ -50,7 +60,7 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
     # ---- texture lookups ------------------------------------------------------------------------
     perturbed_nrm = None
     if 'kd_ks' in material:
-        noise = torch.normal(mean=0, std=0.01, size=gb_pos.shape, device=dev)
+        noise = _noise('texture', lambda: torch.normal(mean=0, std=0.01, size=gb_pos.shape, device=dev))
         all_tex_jitter = _sample_texture(material['kd_ks'], gb_pos + noise, mask)
         all_tex = _sample_texture(material['kd_ks'], gb_pos, mask)
         assert all_tex.shape[-1] == 6, "Combined kd_ks must be 6 channels"
@@ -162,7 +172,7 @@ def render_layer(FLAGS, v_pos_clip, rast, rast_deriv, mesh, view_pos, lgt, resol
         gb_geometric_normal = torch.zeros_like(gb_pos)
 
     with torch.no_grad():
-        noise = torch.randn_like(gb_normal)
+        noise = _noise('tangent', lambda: torch.randn_like(gb_normal))
         noise = noise / noise.norm(dim=-1, keepdim=True)
     gb_tangent = torch.cross(noise, gb_normal, dim=-1)       # only used to add isotropic noise (no uv maps)
     gb_texc, gb_texc_deriv = None, None

@@ -288,6 +288,20 @@ int gs_hashgrid_bwd(int n_levels, int F, int log2_T, int base_res, float per_lev
                     const float* x, const float* mask, int64_t N, const float* params,
                     const float* g_out, float* g_params, float* g_x_levels, gs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * SDF sign-consistency regulariser   (replaces compute_sdf_reg_loss,
+ *   geometry/gshell_tets_geometry.py:33-39, evaluated over ALL grid edges every iteration :361-362)
+ *   sdf [N] f32, edges [E,2] i32 (the static sorted edge list of gs_mtets_topo).
+ *   fwd: gs_sdf_reg_partials(E) per-block partial sums of the loss and of the crossing-edge count;
+ *        loss = sum(part_loss) / sum(part_count)   (0 crossing edges -> the caller returns 0).
+ *   bwd: g_sdf [N] ACCUMULATED with g_scalar * d loss / d sdf; count_dev = device scalar sum(part_count).
+ * ---------------------------------------------------------------------------------- */
+int64_t gs_sdf_reg_partials(int64_t E);
+int gs_sdf_reg_fwd(const float* sdf, const int32_t* edges, int64_t E, float* part_loss,
+                   float* part_count, gs_stream_t stream);
+int gs_sdf_reg_bwd(const float* sdf, const int32_t* edges, int64_t E, const float* g_scalar_dev,
+                   const float* count_dev, float* g_sdf, gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,3 +123,12 @@ def texture_linear_clamp(tex, uv):
     """tex [B,H,W,C], uv [B,h,w,2] in [0,1] -> [B,h,w,C]."""
     out = torch.nn.functional.grid_sample(tex.permute(0, 3, 1, 2), uv * 2 - 1, mode='bilinear', padding_mode='border', align_corners=False)
     return out.permute(0, 2, 3, 1)
+
+
+def sdf_reg_loss(sdf, all_edges):
+    """compute_sdf_reg_loss, literal restatement of geometry/gshell_tets_geometry.py:33-39."""
+    pair = sdf[all_edges.reshape(-1)].reshape(-1, 2)
+    mask = torch.sign(pair[..., 0]) != torch.sign(pair[..., 1])
+    pair = pair[mask]
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    return bce(pair[..., 0], (pair[..., 1] > 0).float()) + bce(pair[..., 1], (pair[..., 0] > 0).float())

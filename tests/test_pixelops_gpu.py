@@ -110,3 +110,28 @@ def test_texture_linear_clamp():
     (out * w.to(DEV)).sum().backward()
     assert torch.allclose(out.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
     assert torch.allclose(t.grad.cpu(), t_ref.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_sdf_reg_loss():
+    from gshell_amd import grid
+    from gshell_amd.geometry.gshell_tets import GShell_Tets
+    from gshell_amd.geometry.gshell_tets_geometry import compute_sdf_reg_loss
+    verts, tets = grid.bcc_grid(10)
+    topo = GShell_Tets().topology(tets.to(DEV), verts.shape[0])
+    edges = topo.edges()
+    gen = torch.Generator().manual_seed(0)
+    sdf = (verts.norm(dim=1) - 0.3 + 0.05 * torch.randn(verts.shape[0], generator=gen))[:, None]   # [N,1] like the MLP output
+    sdf[:5] = 0.0                                                                                   # sign(0) == 0 counts as crossing
+    s_ref = sdf.clone().requires_grad_(True)
+    l_ref = po.sdf_reg_loss(s_ref, edges.cpu().long())
+    l_ref.backward()
+    s = sdf.to(DEV).requires_grad_(True)
+    l = compute_sdf_reg_loss(s, edges)
+    (l * 1.0).backward()
+    assert abs(float(l) - float(l_ref)) <= 1e-5 * abs(float(l_ref))
+    assert (s.grad.cpu() - s_ref.grad).abs().max() <= 1e-4 * s_ref.grad.abs().max()
+    # no crossing edge: loss 0, zero gradient, no NaN
+    s2 = torch.ones(verts.shape[0], device=DEV, requires_grad=True)
+    l2 = compute_sdf_reg_loss(s2, edges)
+    l2.backward()
+    assert float(l2) == 0.0 and float(s2.grad.abs().max()) == 0.0
