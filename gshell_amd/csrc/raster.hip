@@ -398,6 +398,69 @@ __global__ void __launch_bounds__(256) k_interp_bwd(const float* __restrict__ at
     if (g_rast) g_rast[pix] = make_float4(gb0, gb1, 0.f, 0.f);
 }
 
+
+// ---- per-pixel geometric (face) normal ---------------------------------------------------------------
+// The reference interpolates a per-face constant with index [[i,i,i]] (render/render.py:243-248), i.e. a gather by
+// triangle id.  n = cross(v1-v0, v2-v0) / sqrt(max(|.|^2, 1e-20))  (util.safe_normalize).
+__global__ void __launch_bounds__(256) k_face_normal_fwd(const float* __restrict__ v, const int32_t* __restrict__ tri, int64_t T,
+                                                         const float4* __restrict__ rast, int64_t npix, float* __restrict__ out) {
+    int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npix) return;
+    int32_t t = (int32_t)rast[pix].w - 1;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (t >= 0 && t < T) {
+        const float* a = v + 3 * (int64_t)tri[3 * (int64_t)t];
+        const float* b = v + 3 * (int64_t)tri[3 * (int64_t)t + 1];
+        const float* c = v + 3 * (int64_t)tri[3 * (int64_t)t + 2];
+        float e1x = b[0] - a[0], e1y = b[1] - a[1], e1z = b[2] - a[2];
+        float e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
+        float cx = e1y * e2z - e1z * e2y, cy = e1z * e2x - e1x * e2z, cz = e1x * e2y - e1y * e2x;
+        float l = sqrtf(fmaxf(cx * cx + cy * cy + cz * cz, 1e-20f));
+        nx = cx / l;
+        ny = cy / l;
+        nz = cz / l;
+    }
+    out[3 * pix] = nx;
+    out[3 * pix + 1] = ny;
+    out[3 * pix + 2] = nz;
+}
+
+__global__ void __launch_bounds__(256) k_face_normal_bwd(const float* __restrict__ v, const int32_t* __restrict__ tri, int64_t T,
+                                                         const float4* __restrict__ rast, int64_t npix, const float* __restrict__ g_out,
+                                                         float* __restrict__ g_v) {
+    int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npix) return;
+    int32_t t = (int32_t)rast[pix].w - 1;
+    if (t < 0 || t >= T) return;
+    float gx = g_out[3 * pix], gy = g_out[3 * pix + 1], gz = g_out[3 * pix + 2];
+    if (gx == 0.f && gy == 0.f && gz == 0.f) return;
+    int64_t i0 = tri[3 * (int64_t)t], i1 = tri[3 * (int64_t)t + 1], i2 = tri[3 * (int64_t)t + 2];
+    const float *a = v + 3 * i0, *b = v + 3 * i1, *c = v + 3 * i2;
+    float e1x = b[0] - a[0], e1y = b[1] - a[1], e1z = b[2] - a[2];
+    float e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
+    float cx = e1y * e2z - e1z * e2y, cy = e1z * e2x - e1x * e2z, cz = e1x * e2y - e1y * e2x;
+    float l2 = cx * cx + cy * cy + cz * cz;
+    float dcx, dcy, dcz;
+    if (l2 > 1e-20f) {  // d (c/|c|) = (g - n (n.g)) / |c|
+        float l = sqrtf(l2), il = 1.0f / l;
+        float nx = cx * il, ny = cy * il, nz = cz * il;
+        float ng = nx * gx + ny * gy + nz * gz;
+        dcx = (gx - nx * ng) * il;
+        dcy = (gy - ny * ng) * il;
+        dcz = (gz - nz * ng) * il;
+    } else {  // clamped length: n = c / 1e-10
+        dcx = gx * 1e10f;
+        dcy = gy * 1e10f;
+        dcz = gz * 1e10f;
+    }
+    // c = e1 x e2:  d e1 = e2 x dc,  d e2 = dc x e1
+    float d1x = e2y * dcz - e2z * dcy, d1y = e2z * dcx - e2x * dcz, d1z = e2x * dcy - e2y * dcx;
+    float d2x = dcy * e1z - dcz * e1y, d2y = dcz * e1x - dcx * e1z, d2z = dcx * e1y - dcy * e1x;
+    atomicAdd(&g_v[3 * i1], d1x); atomicAdd(&g_v[3 * i1 + 1], d1y); atomicAdd(&g_v[3 * i1 + 2], d1z);
+    atomicAdd(&g_v[3 * i2], d2x); atomicAdd(&g_v[3 * i2 + 1], d2y); atomicAdd(&g_v[3 * i2 + 2], d2z);
+    atomicAdd(&g_v[3 * i0], -(d1x + d2x)); atomicAdd(&g_v[3 * i0 + 1], -(d1y + d2y)); atomicAdd(&g_v[3 * i0 + 2], -(d1z + d2z));
+}
+
 }  // namespace
 
 extern "C" int gs_xfm_points_fwd(const float* pts, int64_t Bp, const float* mtx, int64_t B, int64_t V, float* out, gs_stream_t stream) {
@@ -495,6 +558,28 @@ extern "C" int gs_interpolate_bwd(const float* attr, int64_t Ba, int64_t V, int6
     GS_REQUIRE(T == 0 || (attr && tri), "gs_interpolate_bwd: null mesh pointer");
     hipLaunchKernelGGL(k_interp_bwd, dim3((unsigned)gs::cdiv(npix, 256)), dim3(256), 0, (hipStream_t)stream, attr, Ba, V, (int)A,
                        (const float4*)rast, tri, T, B, H * W, g_out, g_attr, (float4*)g_rast);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_face_normal_fwd(const float* v_pos, int64_t V, const int32_t* tri, int64_t T, const float* rast, int64_t B, int64_t H, int64_t W,
+                                  float* out, gs_stream_t stream) {
+    int64_t npix = B * H * W;
+    if (npix == 0) return 0;
+    GS_REQUIRE(rast && out && (T == 0 || (v_pos && tri)), "gs_face_normal_fwd: null pointer");
+    hipLaunchKernelGGL(k_face_normal_fwd, dim3((unsigned)gs::cdiv(npix, 256)), dim3(256), 0, (hipStream_t)stream, v_pos, tri, T, (const float4*)rast, npix,
+                       out);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_face_normal_bwd(const float* v_pos, int64_t V, const int32_t* tri, int64_t T, const float* rast, int64_t B, int64_t H, int64_t W,
+                                  const float* g_out, float* g_v_pos, gs_stream_t stream) {
+    int64_t npix = B * H * W;
+    if (npix == 0 || T == 0) return 0;
+    GS_REQUIRE(rast && g_out && g_v_pos && v_pos && tri, "gs_face_normal_bwd: null pointer");
+    hipLaunchKernelGGL(k_face_normal_bwd, dim3((unsigned)gs::cdiv(npix, 256)), dim3(256), 0, (hipStream_t)stream, v_pos, tri, T, (const float4*)rast, npix,
+                       g_out, g_v_pos);
     GS_LAUNCH_CHECK();
     return 0;
 }

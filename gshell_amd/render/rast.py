@@ -163,6 +163,37 @@ def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
     return _InterpolateFn.apply(attr, rast, tri, None), None
 
 
+class _FaceNormalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v_pos, tri, rast):
+        v = v_pos.detach().contiguous().float()
+        r = rast.detach().contiguous().float()
+        B, H, W, _ = r.shape
+        out = torch.empty((B, H, W, 3), dtype=torch.float32, device=r.device)
+        with torch.cuda.device(r.device):
+            check(_lib.lib().gs_face_normal_fwd(ptr(v, torch.float32, "v_pos"), c_int64(v.shape[0]), ptr(tri, torch.int32, "tri"), c_int64(tri.shape[0]),
+                                                ptr(r), c_int64(B), c_int64(H), c_int64(W), ptr(out), stream()), "gs_face_normal_fwd")
+        ctx.save_for_backward(v, tri, r)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        v, tri, r = ctx.saved_tensors
+        B, H, W, _ = r.shape
+        g = g_out.contiguous().float()
+        g_v = torch.zeros_like(v)
+        with torch.cuda.device(r.device):
+            check(_lib.lib().gs_face_normal_bwd(ptr(v), c_int64(v.shape[0]), ptr(tri), c_int64(tri.shape[0]), ptr(r), c_int64(B), c_int64(H), c_int64(W),
+                                                ptr(g), ptr(g_v), stream()), "gs_face_normal_bwd")
+        return g_v, None, None
+
+
+def face_normals(v_pos, tri, rast):
+    """Per-pixel geometric normal of the covering triangle, [B,H,W,3] (what the reference obtains by interpolating
+    a per-face attribute with index [[i,i,i]], render/render.py:243-248)."""
+    return _FaceNormalFn.apply(v_pos, tri, rast)
+
+
 # ---- antialias -------------------------------------------------------------------------------------
 
 class AATopology:

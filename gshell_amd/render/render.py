@@ -160,16 +160,9 @@ def render_layer(FLAGS, v_pos_clip, rast, rast_deriv, mesh, view_pos, lgt, resol
     gb, _ = interpolate(torch.cat(stack, dim=-1)[None, ...], rast_out_s, tri)
     gb_pos, gb_normal = gb[..., 0:3], gb[..., 3:6]
 
-    # geometric (face) normal: gather by triangle id
-    fidx = mesh.t_pos_idx
-    v0, v1, v2 = mesh.v_pos[fidx[:, 0], :], mesh.v_pos[fidx[:, 1], :], mesh.v_pos[fidx[:, 2], :]
-    face_normals = util.safe_normalize(torch.cross(v1 - v0, v2 - v0, dim=-1))
-    tid = rast_out_s[..., 3].long() - 1
-    covered = (tid >= 0)[..., None]
-    if face_normals.shape[0] > 0:
-        gb_geometric_normal = torch.where(covered, face_normals[tid.clamp(min=0)], torch.zeros((), device=gb.device))
-    else:
-        gb_geometric_normal = torch.zeros_like(gb_pos)
+    # geometric (face) normal of the covering triangle (fused gather + normalise; a torch gather here would
+    # back-propagate through index_put with ~1e6 duplicate indices: 260 ms at 4 x 512^2)
+    gb_geometric_normal = dr.face_normals(mesh.v_pos, tri, rast_out_s)
 
     with torch.no_grad():
         noise = _noise('tangent', lambda: torch.randn_like(gb_normal))

@@ -302,6 +302,18 @@ int gs_sdf_reg_fwd(const float* sdf, const int32_t* edges, int64_t E, float* par
 int gs_sdf_reg_bwd(const float* sdf, const int32_t* edges, int64_t E, const float* g_scalar_dev,
                    const float* count_dev, float* g_sdf, gs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Per-pixel geometric normal   (replaces the face-normal interpolation of render/render.py:243-248:
+ *   dr.interpolate(face_normals, rast, [[i,i,i]]) == gather of normalize(cross(v1-v0, v2-v0)) by triangle id)
+ *   v_pos [V,3], tri [T,3] i32, rast [B,H,W,4] -> out [B,H,W,3] (0 where empty).
+ *   bwd: g_v_pos [V,3] ACCUMULATED.
+ * ---------------------------------------------------------------------------------- */
+int gs_face_normal_fwd(const float* v_pos, int64_t V, const int32_t* tri, int64_t T, const float* rast,
+                       int64_t B, int64_t H, int64_t W, float* out, gs_stream_t stream);
+int gs_face_normal_bwd(const float* v_pos, int64_t V, const int32_t* tri, int64_t T, const float* rast,
+                       int64_t B, int64_t H, int64_t W, const float* g_out, float* g_v_pos,
+                       gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,3 +156,25 @@ def test_antialias(kind):
     # stacked form == per-buffer form
     o1, o2 = dr.antialias_stacked([c[..., :2], c[..., 2:]], rast_d, p, tri_d, topo)
     assert torch.equal(torch.cat([o1, o2], -1), out)
+
+
+def test_face_normals():
+    from gshell_amd.render import rast as dr
+    verts, tri = _scene("sheet", 6)
+    pos, _, _ = _clip(verts, 2)
+    H, W = 56, 56
+    tri_l = torch.tensor(tri).long()
+    ids = torch.tensor(ro.rasterize_ids(pos.numpy(), tri, H, W))
+    rast_ref, _ = ro.rast_from_ids(pos, tri_l, ids)
+    w = torch.randn(2, H, W, 3, generator=torch.Generator().manual_seed(2))
+    v_ref = torch.tensor(verts).requires_grad_(True)
+    v0, v1, v2 = v_ref[tri_l[:, 0]], v_ref[tri_l[:, 1]], v_ref[tri_l[:, 2]]
+    c = torch.cross(v1 - v0, v2 - v0, dim=-1)
+    fn = c / torch.sqrt(torch.clamp((c * c).sum(-1, keepdim=True), min=1e-20))
+    ref = torch.where((ids >= 0)[..., None], fn[ids.clamp(min=0)], torch.zeros(()))
+    (ref * w).sum().backward()
+    v = torch.tensor(verts, device=DEV).requires_grad_(True)
+    out = dr.face_normals(v, torch.tensor(tri, device=DEV), rast_ref.to(DEV))
+    (out * w.to(DEV)).sum().backward()
+    assert torch.allclose(out.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    assert (v.grad.cpu() - v_ref.grad).abs().max() <= 1e-4 * v_ref.grad.abs().max()
