@@ -43,7 +43,7 @@ struct BvhView {  // passed by value to kernels
 
 static inline BvhView bvh_view(const gs_bvh* b) { return {b->groups, b->tris, b->T, b->n_internal, b->n_leaf, b->leaf}; }
 
-constexpr int BVH_STACK = 40;  // entries per lane
+constexpr int BVH_STACK = 32;  // entries per lane: a 4-ary heap pushes <= 3 siblings per level, depth <= 10 for T <= 4M
 
 __device__ __forceinline__ bool tri_hit(const float4* __restrict__ tp, float ox, float oy, float oz, float dx, float dy, float dz) {
     float4 v0 = tp[0], e1 = tp[1], e2 = tp[2];

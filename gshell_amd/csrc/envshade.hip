@@ -11,11 +11,18 @@
 //     sums are wave reductions (DPP shuffles) instead of a 128-iteration serial loop.
 //   * the per-pixel PCG stream of the reference is reproduced exactly by LCG jump-ahead
 //     (sample i consumes draws 2+5i .. 6+5i), so results do not depend on the lane mapping.
-//   * masked (background) pixels retire whole waves immediately -- no compaction pass needed.
-//   * shadow rays walk the implicit 4-ary BVH of bvh.hpp with an LDS stack.
-//   * backward re-traces with identical sampling (like the reference's params.backward pass);
-//     per-pixel gradients are group-reduced and written once, the light gradient is one float
-//     atomicAdd per sample and channel into the [Hl,Wl,3] probe (as kernel.cu:203-211 does).
+//   * the work is split "wavefront" style into three launches so that the ray traversal runs in a lean kernel:
+//       k_shade_samples<false>  sampling + BSDF/light/MIS evaluation -> ray directions + unshadowed contributions
+//       k_shade_trace           one lane per shadow ray through the implicit 4-ary BVH of bvh.hpp (LDS stack),
+//                               64 visibility bits per wave by ballot
+//       k_shade_accumulate      per-pixel sum of V * contribution
+//     (a single fused kernel needed 200-244 VGPRs = 2 waves/SIMD and ran the traversal latency-starved).
+//   * visibility is CACHED: 1 bit per ray (2.5 MB for 20 M rays).  The backward pass re-runs the identical sampling
+//     (same PCG stream) but reads V from the cache instead of re-tracing -- exactly the values the reference's
+//     second trace would produce, since it uses the same seed (ops.py:99-104) -- so backward costs no rays at all.
+//     Per-pixel gradients are group-reduced and written once; the light gradient is one float atomicAdd per
+//     sample and channel into the [Hl,Wl,3] probe (as kernel.cu:203-211 does).
+//   * only COVERED pixels are launched (compact pixel list from the caller).
 // This stage is ALU / latency bound (ray traversal), not HBM bound: bytes per pixel are ~100.
 #include <hip/hip_runtime.h>
 
@@ -347,80 +354,76 @@ __device__ __forceinline__ v3 light_sample(const Probe& P, float u, float v, flo
 struct ShadeArgs {
     BvhView bvh;
     Probe probe;
-    const float *mask, *ro, *pos, *nrm, *view_pos, *kd, *ks;  // view_pos [B,3]
-    const int32_t* perms;                                     // [P, n*n]
+    const float *ro, *pos, *nrm, *view_pos, *kd, *ks;  // image tensors [B,H,W,3]; view_pos [B,3]
+    const int32_t* pix;                                // [n_cov] linear indices of the covered pixels
+    int64_t n_cov;
+    const int32_t* perms;                              // [P, n*n]
     int P;
-    int64_t B, HW;
-    int W;
+    int64_t HW;
     int bsdf, n, G;  // G lanes per pixel
     uint32_t seed;
     float shadow_scale;
+    // ray buffers, slot r = k*2S + which*S + i  (which: 0 light sample, 1 BSDF sample)
+    float* ray_dir;            // [n_cov*2S, 3]
+    float* ray_contrib;        // [n_cov*2S, 6]  unshadowed (diff rgb, spec rgb) contribution
+    uint64_t* vis_bits;        // [ceil(n_cov*2S / 64)]  bit = 1 -> unoccluded
     float *diff, *spec;                                  // fwd outputs [B,H,W,3]
     const float *g_diff, *g_spec;                        // bwd inputs
     float *g_pos, *g_nrm, *g_kd, *g_ks, *g_light;        // bwd outputs
 };
 
 struct PixelCtx {
-    v3 ro, pos, nrm, view, kd, ks, wo;
+    v3 pos, nrm, view, kd, ks, wo;
     float alpha, pD, pS;
 };
 
-struct SampleOut {
-    v3 diff, spec;
-};
-
+// BSDF * light * MIS * weight of one sample, WITHOUT the visibility factor (which is linear and applied later).
+// BWD: accumulates the gradient terms, already multiplied by `vis` (= V of this ray, cached by the forward pass).
 template <bool BWD>
-__device__ __forceinline__ SampleOut process_sample(const ShadeArgs& A, const PixelCtx& c, v3 dir, float pdf_sum, float weight, v3 g_diff, v3 g_spec,
-                                                    int32_t* stack, int tid, v3& a_pos, v3& a_nrm, v3& a_kd, v3& a_ks) {
+__device__ __forceinline__ void eval_sample(const ShadeArgs& A, const PixelCtx& c, v3 dir, float pdf_sum, float weight, float vis, v3 g_diff, v3 g_spec,
+                                            v3& out_d, v3& out_s, v3& a_pos, v3& a_nrm, v3& a_kd, v3& a_ks) {
     float u, v;
     dir_to_tc(dir, u, v);
     int lx = min(max((int)(u * (float)A.probe.Wl), 0), A.probe.Wl - 1);
     int ly = min(max((int)(v * (float)A.probe.Hl), 0), A.probe.Hl - 1);
-    const float* lp = A.probe.light + ((int64_t)ly * A.probe.Wl + lx) * 3;
-    v3 light_col = ld3(lp);
+    v3 light_col = ld3(A.probe.light + ((int64_t)ly * A.probe.Wl + lx) * 3);
     float mis = 1.0f / fmaxf(pdf_sum, 0.0001f);
-    v3 d_ = V3(0.f), s_ = V3(0.f);
+    v3 d_ = V3(fwd_lambert(c.nrm, dir)), s_ = V3(0.f);
     v3 spec_col = V3(0.f);
-    if (A.bsdf == 1 || A.bsdf == 2)
-        d_ = V3(fwd_lambert(c.nrm, dir));
-    else {
+    if (A.bsdf == 0) {
         spec_col = (V3(0.04f) * (1.0f - c.ks.z) + c.kd * c.ks.z) * (1.0f - c.ks.x);
-        d_ = V3(fwd_lambert(c.nrm, dir));
         s_ = fwd_pbr_specular(spec_col, c.nrm, c.wo, dir, c.alpha, MIN_ROUGHNESS);
     }
-    bool occluded = bvh_any_hit(A.bvh, c.ro.x, c.ro.y, c.ro.z, dir.x, dir.y, dir.z, stack, tid, 256);
-    float Vis = (occluded ? 0.0f : 1.0f) * A.shadow_scale + (1.0f - A.shadow_scale);
-    float k = Vis * mis * weight;
-    if (BWD) {
-        v3 lg = (g_diff * d_ + g_spec * s_) * k;
-        float* gl = A.g_light + ((int64_t)ly * A.probe.Wl + lx) * 3;
-        if (lg.x != 0.f) atomicAdd(&gl[0], lg.x);
-        if (lg.y != 0.f) atomicAdd(&gl[1], lg.y);
-        if (lg.z != 0.f) atomicAdd(&gl[2], lg.z);
-        v3 dd = g_diff * light_col * k, ds = g_spec * light_col * k;
-        v3 d_nrm = V3(0.f);
-        if (A.bsdf == 1 || A.bsdf == 2) {
-            if (dot(c.nrm, dir) > 0.0f) d_nrm += dir * (sum(dd) / PI_F);
-        } else {
-            v3 d_spec_col = V3(0.f), d_wo = V3(0.f), d_wi = V3(0.f);
-            float d_alpha = 0.f;
-            bwd_pbr_specular(spec_col, c.nrm, c.wo, dir, c.alpha, MIN_ROUGHNESS, d_spec_col, d_nrm, d_wo, d_wi, d_alpha, ds);
-            if (dot(c.nrm, dir) > 0.0f) d_nrm += dir * (sum(dd) / PI_F);
-            // spec_col = (0.04 (1 - ks.z) + kd ks.z) (1 - ks.x)
-            a_kd -= d_spec_col * ((c.ks.x - 1.0f) * c.ks.z);
-            a_ks.x += sum(d_spec_col * ((V3(0.04f) - c.kd) * c.ks.z - V3(0.04f)));
-            a_ks.z -= sum(d_spec_col * (c.kd - V3(0.04f))) * (c.ks.x - 1.0f);
-            a_ks.y += d_alpha * 2.0f * c.ks.y;
-            v3 d_wo_raw = V3(0.f);
-            bwd_safe_normalize(c.view - c.pos, d_wo_raw, d_wo);
-            a_pos -= d_wo_raw;
-        }
-        a_nrm += d_nrm;
+    float k = mis * weight;
+    if (!BWD) {
+        out_d = d_ * light_col * k;
+        out_s = s_ * light_col * k;
+        return;
     }
-    SampleOut o;
-    o.diff = d_ * light_col * k;
-    o.spec = s_ * light_col * k;
-    return o;
+    k *= vis;
+    if (k == 0.f) return;
+    v3 lg = (g_diff * d_ + g_spec * s_) * k;
+    float* gl = A.g_light + ((int64_t)ly * A.probe.Wl + lx) * 3;
+    if (lg.x != 0.f) atomicAdd(&gl[0], lg.x);
+    if (lg.y != 0.f) atomicAdd(&gl[1], lg.y);
+    if (lg.z != 0.f) atomicAdd(&gl[2], lg.z);
+    v3 dd = g_diff * light_col * k, ds = g_spec * light_col * k;
+    v3 d_nrm = V3(0.f);
+    if (A.bsdf == 0) {
+        v3 d_spec_col = V3(0.f), d_wo = V3(0.f), d_wi = V3(0.f);
+        float d_alpha = 0.f;
+        bwd_pbr_specular(spec_col, c.nrm, c.wo, dir, c.alpha, MIN_ROUGHNESS, d_spec_col, d_nrm, d_wo, d_wi, d_alpha, ds);
+        // spec_col = (0.04 (1 - ks.z) + kd ks.z) (1 - ks.x)
+        a_kd -= d_spec_col * ((c.ks.x - 1.0f) * c.ks.z);
+        a_ks.x += sum(d_spec_col * ((V3(0.04f) - c.kd) * c.ks.z - V3(0.04f)));
+        a_ks.z -= sum(d_spec_col * (c.kd - V3(0.04f))) * (c.ks.x - 1.0f);
+        a_ks.y += d_alpha * 2.0f * c.ks.y;
+        v3 d_wo_raw = V3(0.f);
+        bwd_safe_normalize(c.view - c.pos, d_wo_raw, d_wo);
+        a_pos -= d_wo_raw;
+    }
+    if (dot(c.nrm, dir) > 0.0f) d_nrm += dir * (sum(dd) / PI_F);
+    a_nrm += d_nrm;
 }
 
 __device__ __forceinline__ float group_sum(float v, int G) {
@@ -429,20 +432,22 @@ __device__ __forceinline__ float group_sum(float v, int G) {
 }
 __device__ __forceinline__ v3 group_sum(v3 v, int G) { return V3(group_sum(v.x, G), group_sum(v.y, G), group_sum(v.z, G)); }
 
+__device__ __forceinline__ float vis_of(const ShadeArgs& A, int64_t r) {
+    bool visible = (A.vis_bits[r >> 6] >> (r & 63)) & 1ull;
+    return (visible ? 1.0f : 0.0f) * A.shadow_scale + (1.0f - A.shadow_scale);
+}
+
+// Pass 1 (fwd): sample generation.  Pass 3 (bwd): the same sampling with the cached visibility -> gradients.
 template <bool BWD>
-__global__ void __launch_bounds__(256) k_env_shade(ShadeArgs A) {
-    __shared__ int32_t stack[BVH_STACK * 256];
+__global__ void __launch_bounds__(256) k_shade_samples(ShadeArgs A) {
     const int tid = threadIdx.x;
     const int G = A.G;
-    int64_t gid = ((int64_t)blockIdx.x * 256 + tid) / G;
+    int64_t k = ((int64_t)blockIdx.x * 256 + tid) / G;   // covered-pixel slot
     int j = tid & (G - 1);
-    int64_t npix = A.B * A.HW;
-    if (gid >= npix) return;  // whole groups retire together (G divides 64)
-    float mask = A.mask[gid];
-    if (!(mask > 0.0f)) return;
+    if (k >= A.n_cov) return;  // whole groups retire together (G divides 64)
+    int64_t gid = A.pix[k];
     PixelCtx c;
     int64_t b = gid / A.HW;
-    c.ro = ld3(A.ro + 3 * gid);
     c.pos = ld3(A.pos + 3 * gid);
     c.nrm = ld3(A.nrm + 3 * gid);
     c.view = ld3(A.view_pos + 3 * b);
@@ -471,51 +476,52 @@ __global__ void __launch_bounds__(256) k_env_shade(ShadeArgs A) {
     c.pD = (diffuse_w + specular_w) > 0.0f ? diffuse_w / (diffuse_w + specular_w) : 1.0f;
     c.pS = 1.0f - c.pD;
 
-    uint32_t s_seed = A.seed, s_pix = (uint32_t)gid;  // pixel linear index (z*H + y)*W + x == gid
-    uint32_t rng0 = pcg_out(s_seed) ^ pcg_out(s_pix);
+    uint32_t rng0 = pcg_out(A.seed) ^ pcg_out((uint32_t)gid);   // pixel linear index (z*H + y)*W + x == gid
     uint32_t light_idx = pcg_out(rng0) % (uint32_t)A.P;
     uint32_t bsdf_idx = pcg_out(lcg_next(rng0)) % (uint32_t)A.P;
     const int32_t* perm_l = A.perms + (int64_t)light_idx * S;
     const int32_t* perm_b = A.perms + (int64_t)bsdf_idx * S;
 
-    v3 acc_d = V3(0.f), acc_s = V3(0.f);
     v3 a_pos = V3(0.f), a_nrm = V3(0.f), a_kd = V3(0.f), a_ks = V3(0.f);
+    const int64_t r0 = k * 2 * S;
     for (int i = j; i < S; i += G) {
         uint32_t st = lcg_jump(rng0, 2u + 5u * (uint32_t)i);
-        float r0 = u01(st); st = lcg_next(st);
+        float r0f = u01(st); st = lcg_next(st);
         float r1 = u01(st); st = lcg_next(st);
         float r2 = u01(st); st = lcg_next(st);
         float r3 = u01(st); st = lcg_next(st);
         float r4 = u01(st);
+        v3 od, os;
         // light importance sample
         int pl = perm_l[i];
-        float sx = ((float)(pl % n) + r0) * strata, sy = ((float)(pl / n) + r1) * strata;
+        float sx = ((float)(pl % n) + r0f) * strata, sy = ((float)(pl / n) + r1) * strata;
         float pdf_light, pdf_b;
         v3 dir = light_sample(A.probe, sx, sy, pdf_light);
         pdf_b = bsdf_pdf(c.pD, c.pS, c.nrm, c.wo, dir, c.alpha);
-        SampleOut o = process_sample<BWD>(A, c, dir, pdf_light + pdf_b, sample_frac, g_diff, g_spec, stack, tid, a_pos, a_nrm, a_kd, a_ks);
-        acc_d += o.diff;
-        acc_s += o.spec;
+        int64_t r = r0 + i;
+        eval_sample<BWD>(A, c, dir, pdf_light + pdf_b, sample_frac, BWD ? vis_of(A, r) : 0.f, g_diff, g_spec, od, os, a_pos, a_nrm, a_kd, a_ks);
+        if (!BWD) {
+            float* rd = A.ray_dir + 3 * r;
+            rd[0] = dir.x; rd[1] = dir.y; rd[2] = dir.z;
+            float* rc = A.ray_contrib + 6 * r;
+            rc[0] = od.x; rc[1] = od.y; rc[2] = od.z; rc[3] = os.x; rc[4] = os.y; rc[5] = os.z;
+        }
         // BSDF sample
         int pb = perm_b[i];
         sx = ((float)(pb % n) + r2) * strata;
         sy = ((float)(pb / n) + r3) * strata;
         dir = bsdf_sample(c.pD, c.pS, c.nrm, c.wo, sx, sy, r4, c.alpha, pdf_b);
         pdf_light = light_pdf(A.probe, dir);
-        o = process_sample<BWD>(A, c, dir, pdf_light + pdf_b, sample_frac, g_diff, g_spec, stack, tid, a_pos, a_nrm, a_kd, a_ks);
-        acc_d += o.diff;
-        acc_s += o.spec;
-    }
-    if (!BWD) {
-        acc_d = group_sum(acc_d, G);
-        acc_s = group_sum(acc_s, G);
-        if (j == 0) {
-            float* od = A.diff + 3 * gid;
-            float* os = A.spec + 3 * gid;
-            od[0] = acc_d.x; od[1] = acc_d.y; od[2] = acc_d.z;
-            os[0] = acc_s.x; os[1] = acc_s.y; os[2] = acc_s.z;
+        r = r0 + S + i;
+        eval_sample<BWD>(A, c, dir, pdf_light + pdf_b, sample_frac, BWD ? vis_of(A, r) : 0.f, g_diff, g_spec, od, os, a_pos, a_nrm, a_kd, a_ks);
+        if (!BWD) {
+            float* rd = A.ray_dir + 3 * r;
+            rd[0] = dir.x; rd[1] = dir.y; rd[2] = dir.z;
+            float* rc = A.ray_contrib + 6 * r;
+            rc[0] = od.x; rc[1] = od.y; rc[2] = od.z; rc[3] = os.x; rc[4] = os.y; rc[5] = os.z;
         }
-    } else {
+    }
+    if (BWD) {
         a_pos = group_sum(a_pos, G);
         a_nrm = group_sum(a_nrm, G);
         a_kd = group_sum(a_kd, G);
@@ -530,24 +536,68 @@ __global__ void __launch_bounds__(256) k_env_shade(ShadeArgs A) {
     }
 }
 
+// Pass 2 (fwd): one lane per shadow ray; 64 consecutive rays share an origin (2S >= 64) or a few origins.
+// A lean kernel (traversal state only) so that 6-8 waves per SIMD hide the BVH fetch latency.
+__global__ void __launch_bounds__(256) k_shade_trace(ShadeArgs A, int64_t n_rays, int rays_per_pixel) {
+    __shared__ int32_t stack[BVH_STACK * 256];
+    int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool visible = true;
+    if (r < n_rays) {
+        int64_t gid = A.pix[r / rays_per_pixel];
+        const float* o = A.ro + 3 * gid;
+        const float* d = A.ray_dir + 3 * r;
+        visible = !bvh_any_hit(A.bvh, o[0], o[1], o[2], d[0], d[1], d[2], stack, threadIdx.x, 256);
+    }
+    uint64_t bits = __ballot(visible);
+    if ((threadIdx.x & 63) == 0 && r < n_rays) A.vis_bits[r >> 6] = bits;
+}
+
+// Pass 3 (fwd): per-pixel sum of V * contribution
+__global__ void __launch_bounds__(256) k_shade_accumulate(ShadeArgs A) {
+    const int G = A.G;
+    int64_t k = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    int j = threadIdx.x & (G - 1);
+    if (k >= A.n_cov) return;
+    const int S2 = 2 * A.n * A.n;
+    const int64_t r0 = k * S2;
+    v3 ad = V3(0.f), as = V3(0.f);
+    for (int i = j; i < S2; i += G) {
+        int64_t r = r0 + i;
+        float Vis = vis_of(A, r);
+        const float* rc = A.ray_contrib + 6 * r;
+        ad += V3(rc[0], rc[1], rc[2]) * Vis;
+        as += V3(rc[3], rc[4], rc[5]) * Vis;
+    }
+    ad = group_sum(ad, G);
+    as = group_sum(as, G);
+    if (j == 0) {
+        int64_t gid = A.pix[k];
+        float* od = A.diff + 3 * gid;
+        float* os = A.spec + 3 * gid;
+        od[0] = ad.x; od[1] = ad.y; od[2] = ad.z;
+        os[0] = as.x; os[1] = as.y; os[2] = as.z;
+    }
+}
+
 int cdf_iters(int size) { return (int)std::ceil(std::log2((float)(size - 1))) + 1; }
 
-int fill_args(ShadeArgs& A, const gs_bvh* bvh, const float* mask, const float* ro, const float* pos, const float* nrm, const float* view_pos,
-              const float* kd, const float* ks, const float* light, const float* pdf, const float* rows, const float* cols, int64_t Hl, int64_t Wl,
-              const int32_t* perms, int64_t P, int64_t B, int64_t H, int64_t W, int bsdf, int n, uint32_t seed, float shadow_scale) {
+int fill_args(ShadeArgs& A, const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* ro, const float* pos, const float* nrm,
+              const float* view_pos, const float* kd, const float* ks, const float* light, const float* pdf, const float* rows, const float* cols,
+              int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B, int64_t H, int64_t W, int bsdf, int n, uint32_t seed,
+              float shadow_scale, uint64_t* vis_bits) {
     GS_REQUIRE(bvh != nullptr, "env_shade: bvh is null");
-    GS_REQUIRE(mask && ro && pos && nrm && view_pos && kd && ks && light && pdf && rows && cols && perms, "env_shade: null pointer");
+    GS_REQUIRE(pix && ro && pos && nrm && view_pos && kd && ks && light && pdf && rows && cols && perms && vis_bits, "env_shade: null pointer");
     GS_REQUIRE(bsdf >= 0 && bsdf <= 2, "env_shade: BSDF id must be 0 (pbr), 1 (diffuse) or 2 (white)");
     GS_REQUIRE(n >= 1 && n <= 64 && P >= 1 && Hl >= 2 && Wl >= 2, "env_shade: bad sample / probe configuration");
-    GS_REQUIRE(B * H * W < (1ll << 32), "env_shade: too many pixels for the 32-bit pixel hash");
+    GS_REQUIRE(B * H * W < (1ll << 31), "env_shade: too many pixels for 32-bit pixel ids");
     A.bvh = bvh_view(bvh);
     A.probe = {light, pdf, rows, cols, (int)Hl, (int)Wl, cdf_iters((int)Hl), cdf_iters((int)Wl)};
-    A.mask = mask; A.ro = ro; A.pos = pos; A.nrm = nrm; A.view_pos = view_pos; A.kd = kd; A.ks = ks;
-    A.perms = perms; A.P = (int)P; A.B = B; A.HW = H * W; A.W = (int)W; A.bsdf = bsdf; A.n = n;
+    A.pix = pix; A.n_cov = n_cov; A.ro = ro; A.pos = pos; A.nrm = nrm; A.view_pos = view_pos; A.kd = kd; A.ks = ks;
+    A.perms = perms; A.P = (int)P; A.HW = H * W; A.bsdf = bsdf; A.n = n;
     int G = 1;
     while (G * 2 <= std::min(n * n, 64)) G *= 2;
     A.G = G;
-    A.seed = seed; A.shadow_scale = shadow_scale;
+    A.seed = seed; A.shadow_scale = shadow_scale; A.vis_bits = vis_bits;
     return 0;
 }
 
@@ -609,47 +659,63 @@ __global__ void __launch_bounds__(256) k_bilateral(const float* __restrict__ col
 
 }  // namespace
 
-extern "C" int gs_env_shade_fwd(const gs_bvh* bvh, const float* mask, const float* ro, const float* gb_pos, const float* gb_normal,
+extern "C" int64_t gs_env_shade_vis_words(int64_t n_cov, int n_samples_x) {
+    return (n_cov * 2 * n_samples_x * n_samples_x + 63) / 64 + 1;
+}
+
+extern "C" int64_t gs_env_shade_scratch_bytes(int64_t n_cov, int n_samples_x) {
+    return n_cov * 2 * n_samples_x * n_samples_x * (int64_t)(3 + 6) * 4 + 256;
+}
+
+extern "C" int gs_env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* ro, const float* gb_pos, const float* gb_normal,
                                 const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
                                 const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
-                                int64_t H, int64_t W, int bsdf, int n_samples_x, uint32_t rnd_seed, float shadow_scale, float* diff, float* spec,
-                                gs_stream_t stream) {
+                                int64_t H, int64_t W, int bsdf, int n_samples_x, uint32_t rnd_seed, float shadow_scale, void* scratch,
+                                uint64_t* vis_bits, float* diff, float* spec, gs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
     if (B * H * W == 0) return 0;
-    GS_REQUIRE(diff && spec, "gs_env_shade_fwd: null output");
+    if (diff) GS_HIP_CHECK(hipMemsetAsync(diff, 0, (size_t)B * H * W * 12, stream));
+    if (spec) GS_HIP_CHECK(hipMemsetAsync(spec, 0, (size_t)B * H * W * 12, stream));
+    if (n_cov == 0) return 0;
+    GS_REQUIRE(scratch != nullptr, "gs_env_shade_fwd: null scratch");
     ShadeArgs A{};
-    int rc = fill_args(A, bvh, mask, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl, perms, P, B, H, W, bsdf,
-                       n_samples_x, rnd_seed, shadow_scale);
+    int rc = fill_args(A, bvh, pix, n_cov, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl, perms, P, B, H, W, bsdf,
+                       n_samples_x, rnd_seed, shadow_scale, vis_bits);
     if (rc) return rc;
+    const int64_t S2 = 2ll * n_samples_x * n_samples_x, n_rays = n_cov * S2;
+    A.ray_dir = (float*)scratch;
+    A.ray_contrib = A.ray_dir + 3 * n_rays;
     A.diff = diff;
     A.spec = spec;
-    GS_HIP_CHECK(hipMemsetAsync(diff, 0, (size_t)B * H * W * 12, (hipStream_t)stream));
-    GS_HIP_CHECK(hipMemsetAsync(spec, 0, (size_t)B * H * W * 12, (hipStream_t)stream));
-    int64_t lanes = B * H * W * A.G;
-    hipLaunchKernelGGL(k_env_shade<false>, dim3((unsigned)gs::cdiv(lanes, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    int64_t lanes = n_cov * A.G;
+    hipLaunchKernelGGL(k_shade_samples<false>, dim3((unsigned)gs::cdiv(lanes, 256)), dim3(256), 0, stream, A);
+    hipLaunchKernelGGL(k_shade_trace, dim3((unsigned)gs::cdiv(n_rays, 256)), dim3(256), 0, stream, A, n_rays, (int)S2);
+    if (diff && spec) hipLaunchKernelGGL(k_shade_accumulate, dim3((unsigned)gs::cdiv(lanes, 256)), dim3(256), 0, stream, A);
     GS_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int gs_env_shade_bwd(const gs_bvh* bvh, const float* mask, const float* ro, const float* gb_pos, const float* gb_normal,
+extern "C" int gs_env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* gb_pos, const float* gb_normal,
                                 const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
                                 const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
-                                int64_t H, int64_t W, int bsdf, int n_samples_x, uint32_t rnd_seed, float shadow_scale, const float* g_diff,
-                                const float* g_spec, float* g_pos, float* g_normal, float* g_kd, float* g_ks, float* g_light,
-                                gs_stream_t stream) {
+                                int64_t H, int64_t W, int bsdf, int n_samples_x, uint32_t rnd_seed, float shadow_scale, const uint64_t* vis_bits,
+                                const float* g_diff, const float* g_spec, float* g_pos, float* g_normal, float* g_kd, float* g_ks, float* g_light,
+                                gs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
     if (B * H * W == 0) return 0;
     GS_REQUIRE(g_diff && g_spec && g_pos && g_normal && g_kd && g_ks && g_light, "gs_env_shade_bwd: null pointer");
+    size_t nb = (size_t)B * H * W * 12;
+    GS_HIP_CHECK(hipMemsetAsync(g_pos, 0, nb, stream));
+    GS_HIP_CHECK(hipMemsetAsync(g_normal, 0, nb, stream));
+    GS_HIP_CHECK(hipMemsetAsync(g_kd, 0, nb, stream));
+    GS_HIP_CHECK(hipMemsetAsync(g_ks, 0, nb, stream));
+    if (n_cov == 0) return 0;
     ShadeArgs A{};
-    int rc = fill_args(A, bvh, mask, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl, perms, P, B, H, W, bsdf,
-                       n_samples_x, rnd_seed, shadow_scale);
+    int rc = fill_args(A, bvh, pix, n_cov, gb_pos /* ro unused in bwd */, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl,
+                       perms, P, B, H, W, bsdf, n_samples_x, rnd_seed, shadow_scale, const_cast<uint64_t*>(vis_bits));
     if (rc) return rc;
     A.g_diff = g_diff; A.g_spec = g_spec; A.g_pos = g_pos; A.g_nrm = g_normal; A.g_kd = g_kd; A.g_ks = g_ks; A.g_light = g_light;
-    size_t nb = (size_t)B * H * W * 12;
-    GS_HIP_CHECK(hipMemsetAsync(g_pos, 0, nb, (hipStream_t)stream));
-    GS_HIP_CHECK(hipMemsetAsync(g_normal, 0, nb, (hipStream_t)stream));
-    GS_HIP_CHECK(hipMemsetAsync(g_kd, 0, nb, (hipStream_t)stream));
-    GS_HIP_CHECK(hipMemsetAsync(g_ks, 0, nb, (hipStream_t)stream));
-    int64_t lanes = B * H * W * A.G;
-    hipLaunchKernelGGL(k_env_shade<true>, dim3((unsigned)gs::cdiv(lanes, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_shade_samples<true>, dim3((unsigned)gs::cdiv(n_cov * A.G, 256)), dim3(256), 0, stream, A);
     GS_LAUNCH_CHECK();
     return 0;
 }

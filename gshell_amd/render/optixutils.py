@@ -82,8 +82,21 @@ def set_random_perm(n_samples_x, table):
 
 class _optix_env_shade_func(torch.autograd.Function):
     @staticmethod
+    def _launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n, seed, shadow_scale, dims, vis, diff, spec):
+        L = _lib.lib()
+        B, H, W = dims
+        n_cov = pix.shape[0]
+        scratch = torch.empty((max(int(L.gs_env_shade_scratch_bytes(c_int64(n_cov), c_int(n))), 8) + 7) // 8, dtype=torch.int64, device=pix.device)
+        check(L.gs_env_shade_fwd(optix_ctx.handle, ptr(pix, torch.int32), c_int64(n_cov), ptr(t["ro"]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view),
+                                 ptr(t["kd"]), ptr(t["ks"]), ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]), c_int64(lgt.shape[1]),
+                                 ptr(perms, torch.int32), c_int64(perms.shape[0]), c_int64(B), c_int64(H), c_int64(W), c_int(BSDF), c_int(n),
+                                 c_uint32(seed & 0xFFFFFFFF), c_float(shadow_scale), ptr(scratch), ptr(vis), ptr(diff), ptr(spec), stream()),
+              "gs_env_shade_fwd")
+
+    @staticmethod
     def forward(ctx, optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, BSDF, n_samples_x, rnd_seed,
                 shadow_scale):
+        L = _lib.lib()
         _rnd_seed = int(np.random.randint(2 ** 31)) if rnd_seed is None else int(rnd_seed)
         B, H, W, _ = gb_pos.shape
         dev = gb_pos.device
@@ -91,7 +104,8 @@ class _optix_env_shade_func(torch.autograd.Function):
 
         def c3(t):
             return t.detach().expand(full).contiguous().float()
-        t_mask = mask.detach().expand(B, H, W).contiguous().float()
+        # covered pixels, ascending (one host sync for the count, like the reference's mask-dependent launches)
+        pix = torch.nonzero(mask.detach().expand(B, H, W).reshape(-1) > 0).reshape(-1).int()
         t = dict(ro=c3(ro), pos=c3(gb_pos), nrm=c3(gb_normal), kd=c3(gb_kd), ks=c3(gb_ks))
         if tuple(gb_view_pos.shape) not in ((B, 1, 1, 3), (1, 1, 1, 3)):
             raise _lib.GShellHipError(f"gb_view_pos must be [B,1,1,3] (one eye per view), got {tuple(gb_view_pos.shape)}")
@@ -100,32 +114,37 @@ class _optix_env_shade_func(torch.autograd.Function):
         perms = random_perm(n_samples_x, dev)
         diff = torch.empty(full, dtype=torch.float32, device=dev)
         spec = torch.empty(full, dtype=torch.float32, device=dev)
-        ctx.args = (optix_ctx, t_mask, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, rnd_seed, _rnd_seed, shadow_scale)
+        vis = torch.empty((int(L.gs_env_shade_vis_words(c_int64(pix.shape[0]), c_int(n_samples_x))),), dtype=torch.int64, device=dev)
         with torch.cuda.device(dev):
-            check(_lib.lib().gs_env_shade_fwd(optix_ctx.handle, ptr(t_mask), ptr(t["ro"]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view), ptr(t["kd"]),
-                                              ptr(t["ks"]), ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]),
-                                              c_int64(lgt.shape[1]), ptr(perms, torch.int32), c_int64(perms.shape[0]), c_int64(B), c_int64(H),
-                                              c_int64(W), c_int(BSDF), c_int(n_samples_x), c_uint32(_rnd_seed & 0xFFFFFFFF), c_float(shadow_scale),
-                                              ptr(diff), ptr(spec), stream()), "gs_env_shade_fwd")
+            _optix_env_shade_func._launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, _rnd_seed, shadow_scale,
+                                              (B, H, W), vis, diff, spec)
+        ctx.args = (optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, rnd_seed, _rnd_seed, shadow_scale, vis)
         ctx.shapes = (gb_pos.shape, gb_normal.shape, gb_kd.shape, gb_ks.shape, light.shape)
         return diff, spec
 
     @staticmethod
     def backward(ctx, diff_grad, spec_grad):
-        optix_ctx, t_mask, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, rnd_seed, _fwd_seed, shadow_scale = ctx.args
-        # like the reference (ops.py:100): a None seed ("decorrelated") draws a fresh seed for the backward pass
-        _rnd_seed = int(np.random.randint(2 ** 31)) if rnd_seed is None else _fwd_seed
+        optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, rnd_seed, _fwd_seed, shadow_scale, vis = ctx.args
         B, H, W, _ = t["pos"].shape
         dev = t["pos"].device
         gd, gs = diff_grad.contiguous().float(), spec_grad.contiguous().float()
         g_pos, g_nrm, g_kd, g_ks = (torch.empty((B, H, W, 3), dtype=torch.float32, device=dev) for _ in range(4))
         g_light = torch.zeros_like(lgt)
         with torch.cuda.device(dev):
-            check(_lib.lib().gs_env_shade_bwd(optix_ctx.handle, ptr(t_mask), ptr(t["ro"]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view), ptr(t["kd"]),
+            if rnd_seed is None:
+                # "decorrelated" mode (ops.py:100): the backward pass draws a fresh seed -> new rays: trace them (no shading outputs)
+                _rnd_seed = int(np.random.randint(2 ** 31))
+                vis = torch.empty_like(vis)
+                _optix_env_shade_func._launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, _rnd_seed,
+                                                  shadow_scale, (B, H, W), vis, None, None)
+            else:
+                _rnd_seed = _fwd_seed      # same seed -> same rays -> the cached visibility bits are exact
+            check(_lib.lib().gs_env_shade_bwd(optix_ctx.handle, ptr(pix), c_int64(pix.shape[0]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view), ptr(t["kd"]),
                                               ptr(t["ks"]), ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]),
                                               c_int64(lgt.shape[1]), ptr(perms), c_int64(perms.shape[0]), c_int64(B), c_int64(H), c_int64(W),
-                                              c_int(BSDF), c_int(n_samples_x), c_uint32(_rnd_seed & 0xFFFFFFFF), c_float(shadow_scale), ptr(gd),
-                                              ptr(gs), ptr(g_pos), ptr(g_nrm), ptr(g_kd), ptr(g_ks), ptr(g_light), stream()), "gs_env_shade_bwd")
+                                              c_int(BSDF), c_int(n_samples_x), c_uint32(_rnd_seed & 0xFFFFFFFF), c_float(shadow_scale), ptr(vis),
+                                              ptr(gd), ptr(gs), ptr(g_pos), ptr(g_nrm), ptr(g_kd), ptr(g_ks), ptr(g_light), stream()),
+                  "gs_env_shade_bwd")
         s = ctx.shapes
 
         def red(g, shape):

@@ -241,26 +241,34 @@ int gs_bvh_any_hit(const gs_bvh* bvh, const float* origins, const float* dirs, i
 /* ------------------------------------------------------------------------------------
  * Monte-Carlo environment shading   (replaces ou.optix_env_shade, render/optixutils/ops.py:81-108,
  *   :141-143; raygen program c_src/envsampling/kernel.cu:463-541; BSDF c_src/bsdf.h)
- *   mask [B,H,W]; ro, gb_pos, gb_normal, gb_kd, gb_ks [B,H,W,3]; view_pos [B,3];
+ *   pix [n_cov] i32 = linear indices (b*H*W + y*W + x) of the pixels with mask > 0, ascending;
+ *   ro, gb_pos, gb_normal, gb_kd, gb_ks [B,H,W,3]; view_pos [B,3];
  *   light [Hl,Wl,3], pdf [Hl,Wl], rows [Hl], cols [Hl,Wl]; perms [P, n^2] i32;
- *   bsdf 0 'pbr' / 1 'diffuse' / 2 'white'; rays per pixel and pass = 2 n^2.
- *   fwd: diff, spec [B,H,W,3] WRITTEN.  bwd re-traces with the same sampling:
- *   g_pos, g_normal, g_kd, g_ks [B,H,W,3] WRITTEN; g_light [Hl,Wl,3] ACCUMULATED (atomics).
+ *   bsdf 0 'pbr' / 1 'diffuse' / 2 'white'; rays per covered pixel = 2 n^2.
+ *   fwd: scratch = gs_env_shade_scratch_bytes(n_cov, n) bytes (ray directions + unshadowed contributions);
+ *        vis_bits [gs_env_shade_vis_words(n_cov, n)] u64 WRITTEN: 1 bit per ray, 1 = unoccluded (saved for bwd);
+ *        diff, spec [B,H,W,3] WRITTEN (both NULL = trace only, used when the backward pass wants fresh samples).
+ *   bwd: identical sampling with the cached visibility (no rays are traced):
+ *        g_pos, g_normal, g_kd, g_ks [B,H,W,3] WRITTEN; g_light [Hl,Wl,3] ACCUMULATED (atomics).
  *   ro and view_pos receive no gradient, as in the reference (ops.py:108).
  * ---------------------------------------------------------------------------------- */
-int gs_env_shade_fwd(const gs_bvh* bvh, const float* mask, const float* ro, const float* gb_pos,
+int64_t gs_env_shade_scratch_bytes(int64_t n_cov, int n_samples_x);
+int64_t gs_env_shade_vis_words(int64_t n_cov, int n_samples_x);
+int gs_env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* ro,
+                     const float* gb_pos, const float* gb_normal, const float* view_pos,
+                     const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
+                     const float* rows, const float* cols, int64_t Hl, int64_t Wl,
+                     const int32_t* perms, int64_t P, int64_t B, int64_t H, int64_t W, int bsdf,
+                     int n_samples_x, uint32_t rnd_seed, float shadow_scale, void* scratch,
+                     uint64_t* vis_bits, float* diff, float* spec, gs_stream_t stream);
+int gs_env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* gb_pos,
                      const float* gb_normal, const float* view_pos, const float* gb_kd,
                      const float* gb_ks, const float* light, const float* pdf, const float* rows,
                      const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P,
                      int64_t B, int64_t H, int64_t W, int bsdf, int n_samples_x, uint32_t rnd_seed,
-                     float shadow_scale, float* diff, float* spec, gs_stream_t stream);
-int gs_env_shade_bwd(const gs_bvh* bvh, const float* mask, const float* ro, const float* gb_pos,
-                     const float* gb_normal, const float* view_pos, const float* gb_kd,
-                     const float* gb_ks, const float* light, const float* pdf, const float* rows,
-                     const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P,
-                     int64_t B, int64_t H, int64_t W, int bsdf, int n_samples_x, uint32_t rnd_seed,
-                     float shadow_scale, const float* g_diff, const float* g_spec, float* g_pos,
-                     float* g_normal, float* g_kd, float* g_ks, float* g_light, gs_stream_t stream);
+                     float shadow_scale, const uint64_t* vis_bits, const float* g_diff,
+                     const float* g_spec, float* g_pos, float* g_normal, float* g_kd, float* g_ks,
+                     float* g_light, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Bilateral denoiser   (replaces ou.bilateral_denoiser, render/optixutils/ops.py:110-123, :145-147;
