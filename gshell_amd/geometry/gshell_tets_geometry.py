@@ -9,7 +9,7 @@ from .. import _lib
 from .._lib import c_int64, check, ptr, stream
 from ..render import mesh, optixutils as ou, regularizer, render
 from .gshell_tets import GShell_Tets
-from .mlp import MLP
+from .mlp import MLP, forward_row_sparse_backward
 
 
 class _SdfRegFn(torch.autograd.Function):
@@ -125,7 +125,8 @@ class GShellTetsGeometry(torch.nn.Module):
 
     def getMesh(self, material):
         v_deformed = self.verts + self.max_displacement * self.deform
-        sdf = self.sdf_net(v_deformed) if self.FLAGS.use_sdf_mlp else self.sdf
+        # SDF of every grid vertex; backward only through the rows that receive gradient (see geometry/mlp.py)
+        sdf = forward_row_sparse_backward(self.sdf_net, v_deformed) if self.FLAGS.use_sdf_mlp else self.sdf
         msdf = self.msdf
         v_deformed = v_deformed + self.offset
         verts, faces, uvs, uv_idx, v_tng, extra = self.gshell_tets(v_deformed, sdf, msdf, self.indices)

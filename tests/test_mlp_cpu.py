@@ -1,0 +1,56 @@
+"""SDF network: structure / state_dict names of the reference (geometry/mlp.py:7-40, embedding.py) and exactness of the
+row-sparse backward (CPU, torch)."""
+import os
+
+import pytest
+import torch
+
+from gshell_amd.geometry.mlp import MLP, forward_row_sparse_backward
+
+
+def _ref_mlp():
+    from oracle import refload
+    if not refload.reference_available():
+        pytest.skip("reference tree not present")
+    import sys
+    import types
+    with refload.CudaToCpu():
+        emb = refload.load_simple("geometry/embedding.py", "ref_embedding")
+        pkg = types.ModuleType("refgeo")
+        pkg.embedding = emb
+        src = open(os.path.join(refload.REF_ROOT, "geometry/mlp.py")).read().replace("from .embedding import Embedding", "")
+        mod = types.ModuleType("ref_mlp")
+        mod.Embedding = emb.Embedding
+        exec(compile(src, "ref_mlp", "exec"), mod.__dict__)
+    return mod.MLP
+
+
+def test_matches_reference_module_bitwise():
+    RefMLP = _ref_mlp()
+    torch.manual_seed(0)
+    ref = RefMLP(skip_in=[3], n_freq=6, n_hidden=6, d_hidden=256)
+    ours = MLP(skip_in=[3], n_freq=6, n_hidden=6, d_hidden=256)
+    assert list(ref.state_dict().keys()) == list(ours.state_dict().keys())
+    ours.load_state_dict(ref.state_dict())
+    x = torch.rand(257, 3) * 1.4 - 0.7
+    assert torch.equal(ours(x), ref(x))
+    assert sum(p.numel() for p in ours.parameters()) == 415233
+
+
+def test_row_sparse_backward_is_exact():
+    torch.manual_seed(1)
+    net = MLP(skip_in=[3], n_freq=6, n_hidden=6, d_hidden=64)
+    x = (torch.rand(500, 3) - 0.5).requires_grad_(True)
+    g = torch.zeros(500, 1)
+    g[torch.randperm(500)[:60]] = torch.randn(60, 1)
+    y_ref = net(x)
+    ref = torch.autograd.grad(y_ref, [x] + list(net.parameters()), g)
+    x2 = x.detach().clone().requires_grad_(True)
+    y = forward_row_sparse_backward(net, x2)
+    assert torch.equal(y, y_ref.detach())
+    got = torch.autograd.grad(y, [x2] + list(net.parameters()), g)
+    for a, b in zip(got, ref):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    # all-zero upstream gradient
+    z = torch.autograd.grad(forward_row_sparse_backward(net, x2), [x2] + list(net.parameters()), torch.zeros(500, 1))
+    assert all(float(t.abs().max()) == 0.0 for t in z)
