@@ -1,0 +1,224 @@
+// Fused forward pass of the G-Shell SDF network on gfx950 matrix cores (fp32-in / fp32-accumulate MFMA).
+//
+// Replaces, for the full-grid forward evaluation (geometry/gshell_tets_geometry.py:194 `sdf = self.sdf_net(v_deformed)`,
+// N = 2.28 M grid vertices at tet-res 256), the reference's module geometry/mlp.py:7-40 + geometry/embedding.py:22-39:
+//   emb = (x, sin(2^k x), cos(2^k x))_{k < n_freq}                      [3 (2 n_freq + 1)]
+//   h   = softplus_100(W0 emb + b0);  h = softplus_100(W_i [h | emb if i == skip] + b_i)  for the hidden layers;
+//   sdf = w_out . h + b_out
+// The reference (and a plain torch port) runs 15 GEMM + ~25 elementwise launches per pass and streams every
+// [N,256] fp32 activation through HBM (2.3 GB each at res 256: ~65 GB of traffic for ~1.9 TFLOP of work).  Here ONE
+// workgroup carries a 64-row tile through ALL layers:
+//   * activations ping-pong between two LDS tiles [64][257] fp32 (row stride 257 -> conflict-free column reads),
+//     the positional encoding stays in a third LDS tile for the skip connection; nothing but x[N,3] is read from
+//     and sdf[N] written to HBM (16 B / vertex);
+//   * weights (1.6 MB, L2-resident, pre-transposed k-major by the caller) stream through a double-buffered
+//     [2][8][256] LDS stage; 4 waves each own a 64x64 output block = 2x2 accumulators of
+//     v_mfma_f32_32x32x2_f32 (exact fp32, bitwise a k-ordered fmaf chain), 4 independent MFMAs per k-step,
+//     which saturates the per-SIMD matrix pipe from one wave per SIMD (MI355X_MICROARCH: 64-cycle issue = latency);
+//   * bias + Softplus(beta = 100, threshold 20) are applied on the accumulators in registers.
+// Roofline: MFMA fp32, 826 880 flop / vertex (d_hidden 256, 6 hidden layers, skip at 3) against 157 TFLOP/s.
+// The backward pass is row-sparse and lives in gshell_amd/geometry/mlp.py (only ~10 % of the rows carry gradient).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "../../include/gshell_hip.h"
+#include "common.hpp"
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int TM = 64;          // rows per workgroup
+constexpr int D = 256;          // hidden width (fixed by the kernel)
+constexpr int LDX = D + 1;      // activation tile row stride (floats)
+constexpr int EMAX = 40;        // max embedding width handled (3 (2*6 + 1) = 39, padded to even)
+constexpr int LDE = EMAX + 1;
+constexpr int KC = 8;           // weight rows per LDS stage
+constexpr int MAX_LAYERS = 16;
+
+struct MlpArgs {
+    const float* x;       // [N,3]
+    float* out;           // [N]
+    int64_t N;
+    int n_freq, E, Epad;  // E = 3 (2 n_freq + 1), Epad = E rounded up to a multiple of KC
+    int n_layers;         // hidden-producing layers (first + n_hidden)
+    int skip_layer;       // index (>= 1) of the layer whose input is [h | emb], or -1
+    const float* wt[MAX_LAYERS];    // k-major weights [K_l (padded), 256]; K_0 = Epad, K_l = 256 (+ Epad for the skip layer)
+    const float* bias[MAX_LAYERS];  // [256]
+    const float* w_out;             // [256] followed by the output bias
+};
+
+__device__ __forceinline__ float softplus100(float x) {
+    // hardware exp/log (v_exp_f32 / v_log_f32): absolute error <= 1e-9 on the softplus value, ~10 VALU ops instead of ~80
+    float bx = x * 100.0f;
+    return bx > 20.0f ? x : __logf(1.0f + __expf(bx)) * 0.01f;
+}
+
+// acc += A[64 x K] (LDS, row stride lda) * Wt[K x 256] (global, k-major) restricted to this wave's 64 columns.
+// Weight rows stream through the double-buffered LDS stage `wst` ([2][KC][D]).
+__device__ __forceinline__ void gemm_segment(v16f (&acc)[2][2], const float* __restrict__ a_lds, int lda, int K, const float* __restrict__ wt,
+                                             float* __restrict__ wst, int tid, int& stage) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int arow = lane & 31, ak = lane >> 5;
+    const int nchunks = K / KC;
+    // stage mapping: thread t moves 8 consecutive floats of weight row t/32
+    const int srow = tid >> 5, scol = (tid & 31) * 8;
+    float4 w0 = *reinterpret_cast<const float4*>(wt + (int64_t)srow * D + scol);
+    float4 w1 = *reinterpret_cast<const float4*>(wt + (int64_t)srow * D + scol + 4);
+    {
+        float* dst = wst + (stage & 1) * KC * D + srow * D + scol;
+        *reinterpret_cast<float4*>(dst) = w0;
+        *reinterpret_cast<float4*>(dst + 4) = w1;
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        if (more) {
+            const float* src = wt + (int64_t)((c + 1) * KC + srow) * D + scol;
+            w0 = *reinterpret_cast<const float4*>(src);
+            w1 = *reinterpret_cast<const float4*>(src + 4);
+        }
+        // keep the weight prefetch ABOVE the MFMA block: without this fence hipcc sinks the two global loads to just
+        // before the ds_write at the bottom of the iteration and the whole L2 latency is exposed every 8 k-rows
+        __builtin_amdgcn_sched_barrier(0);
+        const float* wcur = wst + (stage & 1) * KC * D + wave * 64 + arow;
+        const float* acur = a_lds + arow * lda + c * KC + ak;
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
+            float a0 = acur[2 * s], a1 = acur[32 * lda + 2 * s];
+            float b0 = wcur[(2 * s + ak) * D], b1 = wcur[(2 * s + ak) * D + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        ++stage;
+        if (more) {
+            float* dst = wst + (stage & 1) * KC * D + srow * D + scol;
+            *reinterpret_cast<float4*>(dst) = w0;
+            *reinterpret_cast<float4*>(dst + 4) = w1;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256, 1) k_sdf_mlp_fwd(MlpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xa = smem;                       // [TM][LDX]
+    float* xb = xa + TM * LDX;              // [TM][LDX]
+    float* emb = xb + TM * LDX;             // [TM][LDE]
+    float* wst = emb + TM * LDE;            // [2][KC][D]   (offset is a multiple of 4 floats: 2*64*257 + 64*41 = 35520)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * TM;
+
+    // positional encoding of the tile -> emb (zero padded to Epad columns, zero rows past N)
+    for (int idx = tid; idx < TM * A.Epad; idx += 256) {
+        int row = idx / A.Epad, f = idx - row * A.Epad;
+        int64_t r = r0 + row;
+        float v = 0.f;
+        if (r < A.N && f < A.E) {
+            if (f < 3)
+                v = A.x[3 * r + f];
+            else {
+                int g = f - 3, k = g / 6, sc = (g % 6) / 3, c = g % 3;
+                float arg = (float)(1 << k) * A.x[3 * r + c];
+                v = sc ? cosf(arg) : sinf(arg);
+            }
+        }
+        emb[row * LDE + f] = v;
+    }
+    __syncthreads();
+
+    float* xin = xa;
+    float* xout = xb;
+    int stage = 0;
+    for (int l = 0; l < A.n_layers; ++l) {
+        v16f acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        if (l == 0) {
+            gemm_segment(acc, emb, LDE, A.Epad, A.wt[0], wst, tid, stage);
+        } else {
+            gemm_segment(acc, xin, LDX, D, A.wt[l], wst, tid, stage);
+            if (l == A.skip_layer) gemm_segment(acc, emb, LDE, A.Epad, A.wt[l] + (int64_t)D * D, wst, tid, stage);
+        }
+        // epilogue: bias + softplus, accumulator layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+        const float* bias = A.bias[l];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int col = wave * 64 + j * 32 + (lane & 31);
+            float bj = bias[col];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    xout[row * LDX + col] = softplus100(acc[i][j][r] + bj);
+                }
+        }
+        __syncthreads();
+        float* t = xin;
+        xin = xout;
+        xout = t;
+    }
+    // output layer: 4 lanes per row, 64 columns each
+    {
+        int row = tid >> 2, q = tid & 3;
+        float s = 0.f;
+        const float* h = xin + row * LDX + q * 64;
+        const float* w = A.w_out + q * 64;
+        for (int c = 0; c < 64; ++c) s += h[c] * w[c];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        int64_t r = r0 + row;
+        if (q == 0 && r < A.N) A.out[r] = s + A.w_out[D];
+    }
+}
+
+constexpr size_t SMEM_BYTES = (size_t)(2 * TM * LDX + TM * LDE + 2 * KC * D) * sizeof(float);
+
+}  // namespace
+
+extern "C" int64_t gs_sdf_mlp_packed_floats(int n_freq, int n_hidden, int skip_layer) {
+    int E = 3 * (2 * n_freq + 1);
+    int Epad = (E + KC - 1) / KC * KC;
+    int64_t n = (int64_t)Epad * D + D;                       // layer 0 weights + bias
+    for (int i = 1; i <= n_hidden; ++i) n += (int64_t)(D + (i == skip_layer ? Epad : 0)) * D + D;
+    return n + D + 1;                                        // output weights + bias
+}
+
+// packed = [ Wt_0 (Epad x 256, k-major, zero padded) | b_0 | Wt_1 | b_1 | ... | w_out (256) | b_out ]
+// with Wt_l = transpose of torch's Linear.weight [256, K_l]; for the skip layer the K axis is [h (256) | emb (Epad)].
+extern "C" int gs_sdf_mlp_fwd(const float* x, int64_t N, const float* packed, int n_freq, int n_hidden, int skip_layer, float* out,
+                              gs_stream_t stream) {
+    if (N == 0) return 0;
+    GS_REQUIRE(x && packed && out, "gs_sdf_mlp_fwd: null pointer");
+    int E = 3 * (2 * n_freq + 1);
+    int Epad = (E + KC - 1) / KC * KC;
+    GS_REQUIRE(n_freq >= 0 && n_freq <= 10 && Epad <= EMAX, "gs_sdf_mlp_fwd: positional encoding wider than 40 is not supported");
+    GS_REQUIRE(n_hidden >= 0 && n_hidden + 1 <= MAX_LAYERS, "gs_sdf_mlp_fwd: too many layers");
+    GS_REQUIRE(skip_layer == -1 || (skip_layer >= 1 && skip_layer <= n_hidden), "gs_sdf_mlp_fwd: bad skip layer");
+    MlpArgs A{};
+    A.x = x; A.out = out; A.N = N; A.n_freq = n_freq; A.E = E; A.Epad = Epad; A.n_layers = n_hidden + 1; A.skip_layer = skip_layer;
+    const float* p = packed;
+    A.wt[0] = p; p += (int64_t)Epad * D;
+    A.bias[0] = p; p += D;
+    for (int i = 1; i <= n_hidden; ++i) {
+        A.wt[i] = p; p += (int64_t)(D + (i == skip_layer ? Epad : 0)) * D;
+        A.bias[i] = p; p += D;
+    }
+    A.w_out = p;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sdf_mlp_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_sdf_mlp_fwd, dim3((unsigned)gs::cdiv(N, TM)), dim3(256), SMEM_BYTES, (hipStream_t)stream, A);
+    GS_LAUNCH_CHECK();
+    return 0;
+}

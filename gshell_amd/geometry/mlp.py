@@ -49,6 +49,46 @@ class MLP(nn.Module):
         return h
 
 
+def _fusable(net, x):
+    lin = [m for m in net.net if isinstance(m, nn.Linear)]
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 3 and lin[-1].out_features == 1
+            and all(m.out_features == 256 for m in lin[:-1]) and len(net.skip_count) <= 1 and net.emb.N_freqs <= 6
+            and all(f == 2.0 ** k for k, f in enumerate(net.emb.freq_bands)))
+
+
+def pack_weights(net):
+    """Flat fp32 buffer in the layout of gs_sdf_mlp_fwd (include/gshell_hip.h): k-major weights, zero-padded embedding rows."""
+    lin = [m for m in net.net if isinstance(m, nn.Linear)]
+    E = net.emb.out_channels
+    Epad = (E + 7) // 8 * 8
+    skip = -1
+    if net.skip_count:
+        skip = [i for i, m in enumerate(net.net) if isinstance(m, nn.Linear)].index(net.skip_count[0])
+    parts = []
+    for i, m in enumerate(lin[:-1]):
+        wt = m.weight.detach().t()                                   # [K, 256]
+        if i == 0 or i == skip:
+            wt = torch.cat([wt, wt.new_zeros(Epad - E, wt.shape[1])], dim=0)
+        parts += [wt.reshape(-1), m.bias.detach()]
+    parts += [lin[-1].weight.detach().reshape(-1), lin[-1].bias.detach().reshape(-1)]
+    return torch.cat(parts).contiguous().float(), len(lin) - 2, skip
+
+
+def fused_forward(net, x):
+    """sdf = net(x) through the fused MFMA kernel (no autograd)."""
+    from .. import _lib
+    from .._lib import c_int, c_int64, check, ptr, stream
+    packed, n_hidden, skip = pack_weights(net)
+    L = _lib.lib()
+    assert packed.numel() == L.gs_sdf_mlp_packed_floats(c_int(net.emb.N_freqs), c_int(n_hidden), c_int(skip))
+    xc = x.detach().contiguous()
+    out = torch.empty((xc.shape[0],), dtype=torch.float32, device=xc.device)
+    with torch.cuda.device(xc.device):
+        check(L.gs_sdf_mlp_fwd(ptr(xc, torch.float32, "x"), c_int64(xc.shape[0]), ptr(packed), c_int(net.emb.N_freqs), c_int(n_hidden), c_int(skip),
+                               ptr(out), stream()), "gs_sdf_mlp_fwd")
+    return out[:, None]
+
+
 class _RowSparseBackward(torch.autograd.Function):
     """y = net(x) over ALL rows, backward only over the rows whose upstream gradient is non-zero.
 
@@ -62,7 +102,7 @@ class _RowSparseBackward(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, net, *params):
         with torch.no_grad():
-            y = net(x)
+            y = fused_forward(net, x) if _fusable(net, x) else net(x)
         ctx.net = net
         ctx.save_for_backward(x)
         return y

@@ -322,6 +322,20 @@ int gs_face_normal_bwd(const float* v_pos, int64_t V, const int32_t* tri, int64_
                        int64_t B, int64_t H, int64_t W, const float* g_out, float* g_v_pos,
                        gs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * SDF network, fused forward   (replaces MLP.forward + Embedding.forward, geometry/mlp.py:32-40,
+ *   geometry/embedding.py:22-39, as called on the whole grid at geometry/gshell_tets_geometry.py:194)
+ *   x [N,3] -> out [N];  d_hidden = 256, d_out = 1, Softplus(beta=100).
+ *   packed (gs_sdf_mlp_packed_floats floats) = [Wt_0 | b_0 | Wt_1 | b_1 | ... | w_out(256) | b_out], where
+ *   Wt_l is the TRANSPOSE of torch's Linear.weight (k-major [K_l, 256]); K_0 = E padded to a multiple of 8 with zero
+ *   rows (E = 3 (2 n_freq + 1)); K_l = 256, plus the zero-padded E rows of the embedding for the skip layer
+ *   (input order [h | emb], geometry/mlp.py:37).  skip_layer: 1-based index among the hidden layers' Linear
+ *   modules counted from the first Linear as 0 (reference skip_in=[3] -> skip_layer = 4), or -1.
+ * ---------------------------------------------------------------------------------- */
+int64_t gs_sdf_mlp_packed_floats(int n_freq, int n_hidden, int skip_layer);
+int gs_sdf_mlp_fwd(const float* x, int64_t N, const float* packed, int n_freq, int n_hidden,
+                   int skip_layer, float* out, gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,3 +135,32 @@ def test_sdf_reg_loss():
     l2 = compute_sdf_reg_loss(s2, edges)
     l2.backward()
     assert float(l2) == 0.0 and float(s2.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n_hidden,skip_in", [(6, [3]), (2, []), (3, [0])])
+def test_fused_sdf_mlp_forward(n_hidden, skip_in):
+    """Fused MFMA forward vs the plain torch module on the same device and on CPU (fp32)."""
+    from gshell_amd.geometry.mlp import MLP, forward_row_sparse_backward, fused_forward
+    torch.manual_seed(0)
+    net = MLP(skip_in=skip_in, n_freq=6, n_hidden=n_hidden, d_hidden=256)
+    with torch.no_grad():
+        for p in net.parameters():          # non-trivial biases
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.05)
+    x = torch.rand(1000 + 37, 3) * 1.4 - 0.7
+    ref = net(x).detach()
+    netd = net.to(DEV)
+    xd = x.to(DEV)
+    out = fused_forward(netd, xd)
+    assert out.shape == (x.shape[0], 1)
+    # fp32 MFMA = k-ordered fma chain; torch CPU = blocked SGEMM: agreement at fp32 round-off of a 256-term dot product
+    err = (out.cpu() - ref).abs().max() / ref.abs().max()
+    assert err < 2e-5, float(err)
+    xg = xd.clone().requires_grad_(True)
+    y = forward_row_sparse_backward(netd, xg)
+    g = torch.zeros_like(y)
+    g[::7] = 1.0
+    y.backward(g)
+    xr = x.clone().requires_grad_(True)
+    net.cpu()(xr).backward(g.cpu())
+    assert (xg.grad.cpu() - xr.grad).abs().max() <= 1e-4 * xr.grad.abs().max()
