@@ -20,7 +20,7 @@
 struct gs_bvh {
     int64_t T = 0;           // triangles in the current build
     int depth = 0;           // leaves live at heap level `depth` (>= 1)
-    int leaf = 1;            // triangles per leaf (1..4)
+    int leaf = 1;            // triangles per leaf (1..GS_BVH_LEAF)
     int64_t n_internal = 0;  // (4^depth - 1) / 3
     int64_t n_leaf = 0;      // ceil(T / leaf)
     float4* groups = nullptr;   // [n_internal * 6]
@@ -63,8 +63,9 @@ __device__ __forceinline__ bool tri_hit(const float4* __restrict__ tp, float ox,
 
 // true if the ray (o, d), t in (0, 1e16), hits any triangle.  `stack` = this block's LDS stack base,
 // entry e of lane `tid` lives at stack[e * nthreads + tid].
+template <bool STATS = false>
 __device__ __forceinline__ bool bvh_any_hit(const BvhView& bv, float ox, float oy, float oz, float dx, float dy, float dz, int32_t* stack,
-                                            int tid, int nthreads) {
+                                            int tid, int nthreads, int* n_nodes = nullptr, int* n_tris = nullptr) {
     if (bv.T <= 0) return false;
     if (!(dx == dx && dy == dy && dz == dz) || (dx == 0.f && dy == 0.f && dz == 0.f)) return false;
     float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
@@ -74,6 +75,7 @@ __device__ __forceinline__ bool bvh_any_hit(const BvhView& bv, float ox, float o
     while (sp > 0) {
         --sp;
         int32_t n = stack[sp * nthreads + tid];
+        if (STATS) ++*n_nodes;
         const float4* g = bv.groups + (int64_t)n * 6;
         float4 lox = g[0], loy = g[1], loz = g[2], hix = g[3], hiy = g[4], hiz = g[5];
         const float* plx = &lox.x; const float* ply = &loy.x; const float* plz = &loz.x;
@@ -97,8 +99,10 @@ __device__ __forceinline__ bool bvh_any_hit(const BvhView& bv, float ox, float o
             if (c >= bv.n_internal) {
                 int64_t li = c - bv.n_internal;
                 int64_t t_begin = li * bv.leaf, t_end = min(t_begin + bv.leaf, bv.T);
-                for (int64_t t = t_begin; t < t_end; ++t)
+                for (int64_t t = t_begin; t < t_end; ++t) {
+                    if (STATS) ++*n_tris;
                     if (tri_hit(bv.tris + 3 * t, ox, oy, oz, dx, dy, dz)) return true;
+                }
             } else if (sp < BVH_STACK) {
                 stack[sp * nthreads + tid] = (int32_t)c;
                 ++sp;

@@ -543,10 +543,16 @@ __global__ void __launch_bounds__(256) k_shade_trace(ShadeArgs A, int64_t n_rays
     int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool visible = true;
     if (r < n_rays) {
-        int64_t gid = A.pix[r / rays_per_pixel];
-        const float* o = A.ro + 3 * gid;
-        const float* d = A.ray_dir + 3 * r;
-        visible = !bvh_any_hit(A.bvh, o[0], o[1], o[2], d[0], d[1], d[2], stack, threadIdx.x, 256);
+        // a sample whose unshadowed contribution is exactly zero (direction below the horizon of the shading normal: Lambert
+        // and the front-facing specular test both vanish) cannot reach the outputs or any gradient whatever V is: not traced.
+        const float* rc = A.ray_contrib + 6 * r;
+        bool live = (rc[0] != 0.f) | (rc[1] != 0.f) | (rc[2] != 0.f) | (rc[3] != 0.f) | (rc[4] != 0.f) | (rc[5] != 0.f);
+        if (live) {
+            int64_t gid = A.pix[r / rays_per_pixel];
+            const float* o = A.ro + 3 * gid;
+            const float* d = A.ray_dir + 3 * r;
+            visible = !bvh_any_hit(A.bvh, o[0], o[1], o[2], d[0], d[1], d[2], stack, threadIdx.x, 256);
+        }
     }
     uint64_t bits = __ballot(visible);
     if ((threadIdx.x & 63) == 0 && r < n_rays) A.vis_bits[r >> 6] = bits;

@@ -237,6 +237,9 @@ int gs_bvh_build(gs_bvh* bvh, const float* verts, int64_t V, const int32_t* tris
 int gs_bvh_info(const gs_bvh* bvh, int64_t* T, int64_t* depth, int64_t* leaf_size, int64_t* bytes);
 int gs_bvh_any_hit(const gs_bvh* bvh, const float* origins, const float* dirs, int64_t n,
                    uint8_t* hit, gs_stream_t stream);
+/* diagnostic variant: stats [n,2] i32 = (internal nodes visited, triangles tested) per ray */
+int gs_bvh_any_hit_stats(const gs_bvh* bvh, const float* origins, const float* dirs, int64_t n,
+                         uint8_t* hit, int32_t* stats, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Monte-Carlo environment shading   (replaces ou.optix_env_shade, render/optixutils/ops.py:81-108,

@@ -34,7 +34,7 @@ def test_bvh_any_hit_matches_bruteforce(kind, ntri):
     # identical float Moeller-Trumbore on both sides; the conservative boxes may only ADD candidates
     np.testing.assert_array_equal(hit, ref)
     info = ctx.info()
-    assert info["T"] == tri.shape[0] and 1 <= info["leaf_size"] <= 4
+    assert info["T"] == tri.shape[0] and 1 <= info["leaf_size"] <= 2
     # rebuild with an empty mesh: nothing is occluded
     ou.optix_build_bvh(ctx, torch.zeros(0, 3, device=DEV), torch.zeros(0, 3, dtype=torch.int32, device=DEV), rebuild=1)
     assert int(ou.any_hit(ctx, torch.tensor(org, device=DEV), torch.tensor(d, device=DEV)).sum()) == 0
