@@ -114,6 +114,13 @@ def roofline(op_times, N, Ftets, V_aug, T, B, H, W, n):
         return None
     name, rec = max(op_times.items(), key=lambda kv: kv[1]["ms"] * kv[1]["n"])
     npix = B * H * W
+    if name == "gs_sdf_mlp_fwd":
+        # fp32 MFMA roofline: 2 * (39*256 + 5*256*256 + 295*256 + 256) = 826 880 flop per grid vertex
+        flops = 826880.0 * N
+        tf = flops / (rec["ms"] * 1e-3) / 1e12
+        return {"kernel": "k_sdf_mlp_fwd (gs_sdf_mlp_fwd)", "bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
+                "frac": round(tf / 157.3, 4), "traffic": None, "avg_launch_ms": round(rec["ms"], 4), "algorithmic_flops": flops,
+                "note": "fp32-in/fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32); HBM traffic is 16 B/vertex by construction"}
     # algorithmic HBM bytes per launch (DESIGN.md "Kernels"): inputs read once + outputs written once
     alg = {
         "gs_env_shade_fwd": npix * (4 + 6 * 12 + 24),

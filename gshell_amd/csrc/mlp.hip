@@ -11,10 +11,10 @@
 //   * activations ping-pong between two LDS tiles [64][257] fp32 (row stride 257 -> conflict-free column reads),
 //     the positional encoding stays in a third LDS tile for the skip connection; nothing but x[N,3] is read from
 //     and sdf[N] written to HBM (16 B / vertex);
-//   * weights (1.6 MB, L2-resident, pre-transposed k-major by the caller) stream through a double-buffered
-//     [2][8][256] LDS stage; 4 waves each own a 64x64 output block = 2x2 accumulators of
-//     v_mfma_f32_32x32x2_f32 (exact fp32, bitwise a k-ordered fmaf chain), 4 independent MFMAs per k-step,
-//     which saturates the per-SIMD matrix pipe from one wave per SIMD (MI355X_MICROARCH: 64-cycle issue = latency);
+//   * weights (1.6 MB, L2-resident, pre-transposed k-major by the caller) are read as MFMA B-fragments directly from
+//     global memory with a register double buffer (no LDS stage, no barrier inside the k-loop); 8 waves each own a
+//     64x32 output block = 2 accumulators of v_mfma_f32_32x32x2_f32 (exact fp32, bitwise a k-ordered fmaf chain);
+//     two waves per SIMD cover each other's LDS / L1 latencies (MI355X_MICROARCH: 64-cycle issue = latency);
 //   * bias + Softplus(beta = 100, threshold 20) are applied on the accumulators in registers.
 // Roofline: MFMA fp32, 826 880 flop / vertex (d_hidden 256, 6 hidden layers, skip at 3) against 157 TFLOP/s.
 // The backward pass is row-sparse and lives in gshell_amd/geometry/mlp.py (only ~10 % of the rows carry gradient).
@@ -30,11 +30,12 @@ namespace {
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int TM = 64;          // rows per workgroup
+constexpr int NT = 512;         // threads per workgroup: 8 waves, each owns 64 rows x 32 columns (2 accumulators); 2 waves / SIMD
 constexpr int D = 256;          // hidden width (fixed by the kernel)
 constexpr int LDX = D + 1;      // activation tile row stride (floats)
 constexpr int EMAX = 40;        // max embedding width handled (3 (2*6 + 1) = 39, padded to even)
 constexpr int LDE = EMAX + 1;
-constexpr int KC = 8;           // weight rows per LDS stage
+constexpr int KC = 8;           // weight rows per register-prefetch chunk
 constexpr int MAX_LAYERS = 16;
 
 struct MlpArgs {
@@ -56,64 +57,51 @@ __device__ __forceinline__ float softplus100(float x) {
 }
 
 // acc += A[64 x K] (LDS, row stride lda) * Wt[K x 256] (global, k-major) restricted to this wave's 64 columns.
-// Weight rows stream through the double-buffered LDS stage `wst` ([2][KC][D]).
-__device__ __forceinline__ void gemm_segment(v16f (&acc)[2][2], const float* __restrict__ a_lds, int lda, int K, const float* __restrict__ wt,
-                                             float* __restrict__ wst, int tid, int& stage) {
+// B fragments come straight from global memory (the 1.6 MB of weights are L2-resident and every wave of every CU walks the
+// same rows, so the per-CU L1 serves most of them): no LDS staging and therefore NO barrier inside the k-loop -- the
+// waves of a workgroup drift freely and keep the matrix pipes busy.  Loads for the next 8 k-rows are issued
+// before the MFMAs of the current 8 (register double buffer, 16 VGPRs); sched_barrier pins that order.
+__device__ __forceinline__ void gemm_segment(v16f (&acc)[2], const float* __restrict__ a_lds, int lda, int K, const float* __restrict__ wt, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const int arow = lane & 31, ak = lane >> 5;
     const int nchunks = K / KC;
-    // stage mapping: thread t moves 8 consecutive floats of weight row t/32
-    const int srow = tid >> 5, scol = (tid & 31) * 8;
-    float4 w0 = *reinterpret_cast<const float4*>(wt + (int64_t)srow * D + scol);
-    float4 w1 = *reinterpret_cast<const float4*>(wt + (int64_t)srow * D + scol + 4);
-    {
-        float* dst = wst + (stage & 1) * KC * D + srow * D + scol;
-        *reinterpret_cast<float4*>(dst) = w0;
-        *reinterpret_cast<float4*>(dst + 4) = w1;
-    }
-    __syncthreads();
+    const float* wp = wt + (int64_t)ak * D + wave * 32 + arow;     // B[k = 2s + ak][n = wave*32 + arow]
+    float b[KC / 2], nb[KC / 2];
+#pragma unroll
+    for (int s = 0; s < KC / 2; ++s) b[s] = wp[(2 * s) * D];
     for (int c = 0; c < nchunks; ++c) {
         const bool more = c + 1 < nchunks;
+        const float* wn = wp + (int64_t)(c + 1) * KC * D;
         if (more) {
-            const float* src = wt + (int64_t)((c + 1) * KC + srow) * D + scol;
-            w0 = *reinterpret_cast<const float4*>(src);
-            w1 = *reinterpret_cast<const float4*>(src + 4);
+#pragma unroll
+            for (int s = 0; s < KC / 2; ++s) nb[s] = wn[(2 * s) * D];
         }
-        // keep the weight prefetch ABOVE the MFMA block: without this fence hipcc sinks the two global loads to just
-        // before the ds_write at the bottom of the iteration and the whole L2 latency is exposed every 8 k-rows
         __builtin_amdgcn_sched_barrier(0);
-        const float* wcur = wst + (stage & 1) * KC * D + wave * 64 + arow;
         const float* acur = a_lds + arow * lda + c * KC + ak;
 #pragma unroll
         for (int s = 0; s < KC / 2; ++s) {
             float a0 = acur[2 * s], a1 = acur[32 * lda + 2 * s];
-            float b0 = wcur[(2 * s + ak) * D], b1 = wcur[(2 * s + ak) * D + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[s], acc[1], 0, 0, 0);
         }
-        ++stage;
+        __builtin_amdgcn_sched_barrier(0);
         if (more) {
-            float* dst = wst + (stage & 1) * KC * D + srow * D + scol;
-            *reinterpret_cast<float4*>(dst) = w0;
-            *reinterpret_cast<float4*>(dst + 4) = w1;
+#pragma unroll
+            for (int s = 0; s < KC / 2; ++s) b[s] = nb[s];
         }
-        __syncthreads();
     }
 }
 
-__global__ void __launch_bounds__(256, 1) k_sdf_mlp_fwd(MlpArgs A) {
+__global__ void __launch_bounds__(NT, 2) k_sdf_mlp_fwd(MlpArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xa = smem;                       // [TM][LDX]
     float* xb = xa + TM * LDX;              // [TM][LDX]
     float* emb = xb + TM * LDX;             // [TM][LDE]
-    float* wst = emb + TM * LDE;            // [2][KC][D]   (offset is a multiple of 4 floats: 2*64*257 + 64*41 = 35520)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * TM;
 
     // positional encoding of the tile -> emb (zero padded to Epad columns, zero rows past N)
-    for (int idx = tid; idx < TM * A.Epad; idx += 256) {
+    for (int idx = tid; idx < TM * A.Epad; idx += NT) {
         int row = idx / A.Epad, f = idx - row * A.Epad;
         int64_t r = r0 + row;
         float v = 0.f;
@@ -132,55 +120,49 @@ __global__ void __launch_bounds__(256, 1) k_sdf_mlp_fwd(MlpArgs A) {
 
     float* xin = xa;
     float* xout = xb;
-    int stage = 0;
     for (int l = 0; l < A.n_layers; ++l) {
-        v16f acc[2][2];
+        v16f acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         if (l == 0) {
-            gemm_segment(acc, emb, LDE, A.Epad, A.wt[0], wst, tid, stage);
+            gemm_segment(acc, emb, LDE, A.Epad, A.wt[0], tid);
         } else {
-            gemm_segment(acc, xin, LDX, D, A.wt[l], wst, tid, stage);
-            if (l == A.skip_layer) gemm_segment(acc, emb, LDE, A.Epad, A.wt[l] + (int64_t)D * D, wst, tid, stage);
+            gemm_segment(acc, xin, LDX, D, A.wt[l], tid);
+            if (l == A.skip_layer) gemm_segment(acc, emb, LDE, A.Epad, A.wt[l] + (int64_t)D * D, tid);
         }
         // epilogue: bias + softplus, accumulator layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-        const float* bias = A.bias[l];
+        int col = wave * 32 + (lane & 31);
+        float bj = A.bias[l][col];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int col = wave * 64 + j * 32 + (lane & 31);
-            float bj = bias[col];
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    xout[row * LDX + col] = softplus100(acc[i][j][r] + bj);
-                }
-        }
+            for (int r = 0; r < 16; ++r) {
+                int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                xout[row * LDX + col] = softplus100(acc[i][r] + bj);
+            }
         __syncthreads();
         float* t = xin;
         xin = xout;
         xout = t;
     }
-    // output layer: 4 lanes per row, 64 columns each
+    // output layer: 8 lanes per row, 32 columns each
     {
-        int row = tid >> 2, q = tid & 3;
+        int row = tid >> 3, q = tid & 7;
         float s = 0.f;
-        const float* h = xin + row * LDX + q * 64;
-        const float* w = A.w_out + q * 64;
-        for (int c = 0; c < 64; ++c) s += h[c] * w[c];
+        const float* h = xin + row * LDX + q * 32;
+        const float* w = A.w_out + q * 32;
+        for (int c = 0; c < 32; ++c) s += h[c] * w[c];
         s += __shfl_xor(s, 1, 64);
         s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
         int64_t r = r0 + row;
         if (q == 0 && r < A.N) A.out[r] = s + A.w_out[D];
     }
 }
 
-constexpr size_t SMEM_BYTES = (size_t)(2 * TM * LDX + TM * LDE + 2 * KC * D) * sizeof(float);
+constexpr size_t SMEM_BYTES = (size_t)(2 * TM * LDX + TM * LDE) * sizeof(float);
 
 }  // namespace
 
@@ -218,7 +200,7 @@ extern "C" int gs_sdf_mlp_fwd(const float* x, int64_t N, const float* packed, in
         GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sdf_mlp_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_sdf_mlp_fwd, dim3((unsigned)gs::cdiv(N, TM)), dim3(256), SMEM_BYTES, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_sdf_mlp_fwd, dim3((unsigned)gs::cdiv(N, TM)), dim3(NT), SMEM_BYTES, (hipStream_t)stream, A);
     GS_LAUNCH_CHECK();
     return 0;
 }
