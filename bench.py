@@ -108,6 +108,16 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_traffic.json; collected with
+    rocprofv3 --pmc in separate runs, corrected as MI355X_MICROARCH.md prescribes) -- None if not measured."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return float(json.load(f)[kernel]["bytes"])
+    except Exception:
+        return None
+
+
 def roofline(op_times, N, Ftets, V_aug, T, B, H, W, n):
     """Roofline of the dominant hand-written kernel family of the iteration (HIP events around its C-ABI launch)."""
     if not op_times:
@@ -119,7 +129,7 @@ def roofline(op_times, N, Ftets, V_aug, T, B, H, W, n):
         flops = 826880.0 * N
         tf = flops / (rec["ms"] * 1e-3) / 1e12
         return {"kernel": "k_sdf_mlp_fwd (gs_sdf_mlp_fwd)", "bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
-                "frac": round(tf / 157.3, 4), "traffic": None, "avg_launch_ms": round(rec["ms"], 4), "algorithmic_flops": flops,
+                "frac": round(tf / 157.3, 4), "traffic": pmc_traffic("k_sdf_mlp_fwd") if N == 2282489 else None, "avg_launch_ms": round(rec["ms"], 4), "algorithmic_flops": flops,
                 "note": "fp32-in/fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32); HBM traffic is 16 B/vertex by construction"}
     # algorithmic HBM bytes per launch (DESIGN.md "Kernels"): inputs read once + outputs written once
     alg = {

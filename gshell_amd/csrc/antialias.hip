@@ -15,9 +15,9 @@
 //   1. gs_tri_adjacency  : opposite vertex across each triangle edge, by ONE radix sort of the 3T
 //                          (min,max) edge keys (deterministic; replaces the per-call hash build).
 //   2. gs_aa_analyze     : ONE pass per render producing a dense alpha[B,H,W,2] (right / down pair).
-//   3. gs_aa_apply_fwd   : any number of channels (all output buffers concatenated) in one launch,
-//                          gather form -> no atomics, bit-reproducible.
-//   4. gs_aa_apply_bwd   : gather form for colour grads + per-pair d loss / d alpha.
+//   3. gs_aa_apply_fwd   : any number of channels (all output buffers concatenated) in one launch, lane per
+//                          (pixel, channel), gather form -> no atomics, bit-reproducible, fully coalesced.
+//   4. gs_aa_apply_bwd   : gather form for colour grads; d loss / d alpha by sparse atomics (silhouette pixels only).
 //   5. gs_aa_analyze_bwd : sparse: only pairs with alpha != 0 touch vertex gradients (atomics).
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -177,11 +177,16 @@ __global__ void __launch_bounds__(256) k_aa_analyze(const float4* __restrict__ p
     alpha[pix] = out;
 }
 
-// out[p] = c[p] + sum over the (up to) four pairs that target p, in the fixed order right, left, down, up
+// out[p] = c[p] + sum over the (up to) four pairs that target p, in the fixed order right, left, down, up.
+// One lane per (pixel, channel) with the channel index fastest: a wave touches 64 consecutive floats of every tensor it
+// reads or writes (the first version walked the C channels of one pixel per lane -- 180-byte lane stride at C = 45 -- and
+// rocprof showed 7x the algorithmic HBM traffic).
 __global__ void __launch_bounds__(256) k_aa_apply_fwd(const float* __restrict__ color, const float2* __restrict__ alpha, int64_t B, int H,
                                                       int W, int C, float* __restrict__ out) {
-    int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= B * (int64_t)H * W) return;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n = B * (int64_t)H * W * C;
+    if (i >= n) return;
+    int64_t pix = i / C;
     int rem = (int)(pix % ((int64_t)H * W));
     int py = rem / W, px = rem - py * W;
     float2 a = alpha[pix];
@@ -191,62 +196,47 @@ __global__ void __launch_bounds__(256) k_aa_apply_fwd(const float* __restrict__ 
     float au = (py > 0) ? alpha[pix - W].y : 0.f;                      // pair (up, p)
     al = al < 0.f ? al : 0.f;
     au = au < 0.f ? au : 0.f;
-    const float* c = color + pix * C;
-    float* o = out + pix * C;
-    if (ar == 0.f && ad == 0.f && al == 0.f && au == 0.f) {
-        for (int k = 0; k < C; ++k) o[k] = c[k];
-        return;
-    }
-    const float* cr = c + C;
-    const float* cl = c - C;
-    const float* cd = c + (int64_t)W * C;
-    const float* cu = c - (int64_t)W * C;
-    for (int k = 0; k < C; ++k) {
-        float v = c[k];
-        float acc = v;
-        if (ar != 0.f) acc += ar * (cr[k] - v);
-        if (al != 0.f) acc += al * (v - cl[k]);
-        if (ad != 0.f) acc += ad * (cd[k] - v);
-        if (au != 0.f) acc += au * (v - cu[k]);
-        o[k] = acc;
-    }
+    float v = color[i];
+    float acc = v;
+    if (ar != 0.f) acc += ar * (color[i + C] - v);
+    if (al != 0.f) acc += al * (v - color[i - C]);
+    if (ad != 0.f) acc += ad * (color[i + (int64_t)W * C] - v);
+    if (au != 0.f) acc += au * (v - color[i - (int64_t)W * C]);
+    out[i] = acc;
 }
 
-// colour gradient (gather form) and d loss / d alpha of the two pairs owned by this pixel
+// colour gradient (gather form, same lane mapping) and d loss / d alpha of the two pairs owned by this pixel
+// (g_alpha must be zero-filled: channels of a silhouette pixel add their share with one atomic each -- sparse).
 __global__ void __launch_bounds__(256) k_aa_apply_bwd(const float* __restrict__ color, const float2* __restrict__ alpha, int64_t B, int H,
                                                       int W, int C, const float* __restrict__ g_out, float* __restrict__ g_color,
-                                                      float2* __restrict__ g_alpha) {
-    int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= B * (int64_t)H * W) return;
+                                                      float* __restrict__ g_alpha) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n = B * (int64_t)H * W * C;
+    if (i >= n) return;
+    int64_t pix = i / C;
     int rem = (int)(pix % ((int64_t)H * W));
     int py = rem / W, px = rem - py * W;
     float2 a = alpha[pix];
     float al = (px > 0) ? alpha[pix - 1].x : 0.f;
     float au = (py > 0) ? alpha[pix - W].y : 0.f;
-    const float* g = g_out + pix * C;
-    // pair (p, right): tau = a.x > 0 ? p : right ; c0 = c[p], c1 = c[right]
-    const float* g_r = a.x > 0.f ? g : g + C;
-    const float* g_d = a.y > 0.f ? g : g + (int64_t)W * C;
-    // pair (left, p): tau = al > 0 ? left : p ; here p is c1
-    const float* g_l = al > 0.f ? g - C : g;
-    const float* g_u = au > 0.f ? g - (int64_t)W * C : g;
-    const float* c = color + pix * C;
-    float ga_r = 0.f, ga_d = 0.f;
-    for (int k = 0; k < C; ++k) {
-        float acc = g[k];
-        if (a.x != 0.f) {
-            acc -= a.x * g_r[k];
-            ga_r += g_r[k] * (c[C + k] - c[k]);
-        }
-        if (a.y != 0.f) {
-            acc -= a.y * g_d[k];
-            ga_d += g_d[k] * (c[(int64_t)W * C + k] - c[k]);
-        }
-        if (al != 0.f) acc += al * g_l[k];
-        if (au != 0.f) acc += au * g_u[k];
-        if (g_color) g_color[pix * C + k] = acc;
+    const int64_t dn = (int64_t)W * C;
+    float g = g_out[i];
+    float acc = g;
+    if (a.x != 0.f) {   // pair (p, right): tau = a.x > 0 ? p : right ; c0 = c[p], c1 = c[right]
+        float gt = a.x > 0.f ? g : g_out[i + C];
+        acc -= a.x * gt;
+        float d = gt * (color[i + C] - color[i]);
+        if (g_alpha && d != 0.f) atomicAdd(&g_alpha[2 * pix], d);
     }
-    if (g_alpha) g_alpha[pix] = make_float2(ga_r, ga_d);
+    if (a.y != 0.f) {
+        float gt = a.y > 0.f ? g : g_out[i + dn];
+        acc -= a.y * gt;
+        float d = gt * (color[i + dn] - color[i]);
+        if (g_alpha && d != 0.f) atomicAdd(&g_alpha[2 * pix + 1], d);
+    }
+    if (al != 0.f) acc += al * (al > 0.f ? g_out[i - C] : g);       // pair (left, p): tau = al > 0 ? left : p ; here p is c1
+    if (au != 0.f) acc += au * (au > 0.f ? g_out[i - dn] : g);
+    if (g_color) g_color[i] = acc;
 }
 
 __device__ __forceinline__ void pair_bwd(const float4* __restrict__ pv, float* __restrict__ gp, const PairGeom& g, float g_alpha, int d,
@@ -357,7 +347,7 @@ extern "C" int gs_aa_apply_fwd(const float* color, const float* alpha, int64_t B
     int64_t npix = B * H * W;
     if (npix == 0 || C == 0) return 0;
     GS_REQUIRE(color && alpha && out && color != out, "gs_aa_apply_fwd: null or aliased pointer");
-    hipLaunchKernelGGL(k_aa_apply_fwd, dim3((unsigned)gs::cdiv(npix, 256)), dim3(256), 0, (hipStream_t)stream, color, (const float2*)alpha, B,
+    hipLaunchKernelGGL(k_aa_apply_fwd, dim3((unsigned)gs::cdiv(npix * C, 256)), dim3(256), 0, (hipStream_t)stream, color, (const float2*)alpha, B,
                        (int)H, (int)W, (int)C, out);
     GS_LAUNCH_CHECK();
     return 0;
@@ -368,8 +358,9 @@ extern "C" int gs_aa_apply_bwd(const float* color, const float* alpha, int64_t B
     int64_t npix = B * H * W;
     if (npix == 0 || C == 0) return 0;
     GS_REQUIRE(color && alpha && g_out, "gs_aa_apply_bwd: null pointer");
-    hipLaunchKernelGGL(k_aa_apply_bwd, dim3((unsigned)gs::cdiv(npix, 256)), dim3(256), 0, (hipStream_t)stream, color, (const float2*)alpha, B,
-                       (int)H, (int)W, (int)C, g_out, g_color, (float2*)g_alpha);
+    if (g_alpha) GS_HIP_CHECK(hipMemsetAsync(g_alpha, 0, (size_t)npix * 8, (hipStream_t)stream));
+    hipLaunchKernelGGL(k_aa_apply_bwd, dim3((unsigned)gs::cdiv(npix * C, 256)), dim3(256), 0, (hipStream_t)stream, color, (const float2*)alpha, B,
+                       (int)H, (int)W, (int)C, g_out, g_color, g_alpha);
     GS_LAUNCH_CHECK();
     return 0;
 }
