@@ -60,7 +60,9 @@ def check(status, what=""):
 
 
 def ptr(t, dtype=None, name="tensor"):
-    """Device pointer of a contiguous CUDA(HIP) tensor (None -> NULL). Mirrors the
+    """Device pointer of a contiguous CUDA(HIP) tensor (None -> NULL).  The CALLER must keep `t` referenced until the
+    launch has been enqueued: never pass an inline temporary (`ptr(x.int())`) -- torch frees it when ptr() returns and the
+    next temporary may be handed the same block.  Mirrors the
     reference's CHECK_TENSOR guards (render/renderutils/c_src/torch_bindings.cpp:27-31)."""
     if t is None:
         return c_void_p(0)

@@ -1,0 +1,180 @@
+// G-FlexiCubes topology kernels on gfx950 (integer / index work of the extraction).
+//
+// Replaces the per-call index machinery of geometry/gshell_flexicubes.py:136-230: `_identify_surf_cubes` (:334-343),
+// `_get_case_id` incl. the C16/C19 ambiguity fix-up on a dense [res,res,res,5] volume (:266-306), `_identify_surf_edges`
+// (`torch.unique(..., return_inverse, return_counts)` over 12 edges of every surface cube, :309-331), the python loop over
+// `num_vd` groups that builds the edge-group -> dual-vertex tables (:406-440, :481-485) and the stable sort that gathers the
+// four dual vertices around every crossing edge (:493-505, :517-522).
+// With a STATIC per-grid edge table (unique ordered edges, cube -> edge ids, the <= 4 incident cube-edges of every edge; built
+// once per grid) the reference's orderings are reproduced by prefix ranks only:
+//   dual-vertex id  = base(num_vd group) + rank of the cube inside its group * num_vd + j
+//   quad order      = crossing edges shared by 4 cubes in ascending edge id, "flipped" quads first
+// so no sort and no unique run per call.  The floating-point part (weighted zero crossings, L_dev, the mSDF cut
+// interpolation) currently runs as gather / index_add torch ops over these index tables.
+#include <hip/hip_runtime.h>
+
+#include "../../include/gshell_hip.h"
+#include "common.hpp"
+#include "flexi_tables.hpp"
+
+namespace {
+
+// corner c = (c&1, (c>>1)&1, c>>2); occupancy = s < 0 (inside is negative here, reference :315,:339)
+__global__ void __launch_bounds__(256) k_flexi_case_raw(const float* __restrict__ s, const int32_t* __restrict__ cubes, int64_t F,
+                                                        uint8_t* __restrict__ case_raw, uint8_t* __restrict__ surf) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= F) return;
+    const int4* q = reinterpret_cast<const int4*>(cubes + 8 * c);
+    int4 lo = q[0], hi = q[1];
+    int idx[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    int code = 0, cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int o = s[idx[k]] < 0.0f ? 1 : 0;
+        code |= o << k;
+        cnt += o;
+    }
+    case_raw[c] = (uint8_t)code;
+    surf[c] = (cnt > 0 && cnt < 8) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_flexi_case_resolve(const uint8_t* __restrict__ case_raw, const uint8_t* __restrict__ surf, int64_t F,
+                                                            int r0, int r1, int r2, uint8_t* __restrict__ case_out, uint8_t* __restrict__ num_vd,
+                                                            uint8_t* __restrict__ n_ent) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= F) return;
+    int cs = case_raw[c];
+    if (!surf[c]) {
+        case_out[c] = (uint8_t)cs;
+        num_vd[c] = 0;
+        n_ent[c] = 0;
+        return;
+    }
+    if (c_check[cs][0] == 1) {  // C16 / C19: inverted when the cube across the ambiguous face is ambiguous too (:294-305)
+        int i = (int)(c / ((int64_t)r1 * r2)), j = (int)((c / r2) % r1), k = (int)(c % r2);
+        int ai = i + c_check[cs][1], aj = j + c_check[cs][2], ak = k + c_check[cs][3];
+        if (ai >= 0 && ai < r0 && aj >= 0 && aj < r1 && ak >= 0 && ak < r2) {
+            int64_t a = ((int64_t)ai * r1 + aj) * r2 + ak;
+            if (surf[a] && c_check[case_raw[a]][0] == 1) cs = c_check[cs][4];
+        }
+    }
+    case_out[c] = (uint8_t)cs;
+    int nv = c_num_vd[cs];
+    num_vd[c] = (uint8_t)nv;
+    int ne = 0;
+    for (int j = 0; j < nv; ++j) ne += c_n_ent[cs][j];
+    n_ent[c] = (uint8_t)ne;
+}
+
+// flags: bit0 crossing, bit1 crossing edge shared by 4 cubes (emits a quad), bit2 s[first end point] > 0 (quad flipped)
+__global__ void __launch_bounds__(256) k_flexi_edge_flags(const float* __restrict__ s, const int2* __restrict__ edges, const uint8_t* __restrict__ ncubes,
+                                                          int64_t E, uint8_t* __restrict__ flags) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int2 ab = edges[e];
+    float sa = s[ab.x], sb = s[ab.y];
+    int cross = (sa < 0.0f) != (sb < 0.0f);
+    flags[e] = (uint8_t)(cross | ((cross && ncubes[e] == 4) ? 2 : 0) | ((sa > 0.0f) ? 4 : 0));
+}
+
+// per surface cube: its edge-group entries in the order (dual vertex j, slot) at ent_base[c], dual vertex ids at vd_base[c] + j
+__global__ void __launch_bounds__(256) k_flexi_entries(const uint8_t* __restrict__ case_id, const uint8_t* __restrict__ num_vd,
+                                                       const int32_t* __restrict__ vd_base, const int32_t* __restrict__ ent_base,
+                                                       const int32_t* __restrict__ cube_edge, int64_t F, int32_t* __restrict__ ent_vd,
+                                                       int32_t* __restrict__ ent_edge, int32_t* __restrict__ ent_cube, int32_t* __restrict__ ent_e,
+                                                       int32_t* __restrict__ vd_idx_map, int32_t* __restrict__ vd_cube) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= F) return;
+    int nv = num_vd[c];
+    if (nv == 0) return;
+    int cs = case_id[c];
+    int32_t vb = vd_base[c];
+    int64_t pos = ent_base[c];
+    for (int j = 0; j < nv; ++j) {
+        vd_cube[vb + j] = (int32_t)c;
+        for (int k = 0; k < 7; ++k) {
+            int e = c_dmc[cs][j][k];
+            if (e == 255) continue;
+            ent_vd[pos] = vb + j;
+            ent_edge[pos] = cube_edge[12 * c + e];
+            ent_cube[pos] = (int32_t)c;
+            ent_e[pos] = e;
+            vd_idx_map[12 * c + e] = vb + j;
+            ++pos;
+        }
+    }
+}
+
+// one lane per grid edge that emits a quad: gather the 4 dual vertices (ascending cube order), orient by the sign of the
+// first end point, split along the diagonal with the larger gamma product (reference :493-522, non-training branch)
+__global__ void __launch_bounds__(256) k_flexi_quads(const uint8_t* __restrict__ flags, const int32_t* __restrict__ qrank, const int32_t* __restrict__ inc,
+                                                     const int32_t* __restrict__ vd_idx_map, const float* __restrict__ vd_gamma, int64_t E,
+                                                     int64_t* __restrict__ faces, int32_t* __restrict__ faces_i32) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int fl = flags[e];
+    if (!(fl & 2)) return;
+    int32_t q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = vd_idx_map[inc[4 * e + k]];
+    int32_t v[4];
+    if (fl & 4) { v[0] = q[0]; v[1] = q[1]; v[2] = q[3]; v[3] = q[2]; }
+    else        { v[0] = q[2]; v[1] = q[3]; v[2] = q[1]; v[3] = q[0]; }
+    float g02 = vd_gamma[v[0]] * vd_gamma[v[2]], g13 = vd_gamma[v[1]] * vd_gamma[v[3]];
+    int32_t t[6];
+    if (g02 > g13) { t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[0]; t[4] = v[2]; t[5] = v[3]; }
+    else           { t[0] = v[0]; t[1] = v[1]; t[2] = v[3]; t[3] = v[3]; t[4] = v[1]; t[5] = v[2]; }
+    int64_t o = 6 * (int64_t)qrank[e];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        faces[o + k] = t[k];
+        if (faces_i32) faces_i32[o + k] = t[k];
+    }
+}
+
+}  // namespace
+
+extern "C" int gs_flexi_classify(const float* s, const int32_t* cubes_fx8, int64_t F, int64_t res0, int64_t res1, int64_t res2, uint8_t* scratch_2F,
+                                 uint8_t* case_id, uint8_t* num_vd, uint8_t* n_ent, gs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (F == 0) return 0;
+    GS_REQUIRE(s && cubes_fx8 && scratch_2F && case_id && num_vd && n_ent, "gs_flexi_classify: null pointer");
+    GS_REQUIRE(res0 * res1 * res2 == F, "gs_flexi_classify: res does not match the number of cubes (regular grid expected)");
+    uint8_t* case_raw = scratch_2F;
+    uint8_t* surf = scratch_2F + F;
+    hipLaunchKernelGGL(k_flexi_case_raw, dim3((unsigned)gs::cdiv(F, 256)), dim3(256), 0, stream, s, cubes_fx8, F, case_raw, surf);
+    hipLaunchKernelGGL(k_flexi_case_resolve, dim3((unsigned)gs::cdiv(F, 256)), dim3(256), 0, stream, case_raw, surf, F, (int)res0, (int)res1, (int)res2,
+                       case_id, num_vd, n_ent);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_flexi_edge_flags(const float* s, const int32_t* edges_ex2, const uint8_t* ncubes, int64_t E, uint8_t* flags, gs_stream_t stream) {
+    if (E == 0) return 0;
+    GS_REQUIRE(s && edges_ex2 && ncubes && flags, "gs_flexi_edge_flags: null pointer");
+    hipLaunchKernelGGL(k_flexi_edge_flags, dim3((unsigned)gs::cdiv(E, 256)), dim3(256), 0, (hipStream_t)stream, s, (const int2*)edges_ex2, ncubes, E, flags);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_flexi_entries(const uint8_t* case_id, const uint8_t* num_vd, const int32_t* vd_base, const int32_t* ent_base, const int32_t* cube_edge,
+                                int64_t F, int32_t* ent_vd, int32_t* ent_edge, int32_t* ent_cube, int32_t* ent_e, int32_t* vd_idx_map, int32_t* vd_cube,
+                                gs_stream_t stream) {
+    if (F == 0) return 0;
+    GS_REQUIRE(case_id && num_vd && vd_base && ent_base && cube_edge && ent_vd && ent_edge && ent_cube && ent_e && vd_idx_map && vd_cube,
+               "gs_flexi_entries: null pointer");
+    hipLaunchKernelGGL(k_flexi_entries, dim3((unsigned)gs::cdiv(F, 256)), dim3(256), 0, (hipStream_t)stream, case_id, num_vd, vd_base, ent_base, cube_edge, F,
+                       ent_vd, ent_edge, ent_cube, ent_e, vd_idx_map, vd_cube);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_flexi_quads(const uint8_t* flags, const int32_t* qrank, const int32_t* inc_ex4, const int32_t* vd_idx_map, const float* vd_gamma, int64_t E,
+                              int64_t* faces, int32_t* faces_i32, gs_stream_t stream) {
+    if (E == 0) return 0;
+    GS_REQUIRE(flags && qrank && inc_ex4 && vd_idx_map && vd_gamma && faces, "gs_flexi_quads: null pointer");
+    hipLaunchKernelGGL(k_flexi_quads, dim3((unsigned)gs::cdiv(E, 256)), dim3(256), 0, (hipStream_t)stream, flags, qrank, inc_ex4, vd_idx_map, vd_gamma, E, faces,
+                       faces_i32);
+    GS_LAUNCH_CHECK();
+    return 0;
+}

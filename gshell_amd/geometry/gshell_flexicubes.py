@@ -1,0 +1,210 @@
+"""G-FlexiCubes extractor -- drop-in for the reference's geometry/gshell_flexicubes.py (class GShellFlexiCubes,
+`construct_voxel_grid` :103-134 and `__call__` :136-230; the non-training, grad_func=None path every G-Shell script runs).
+
+    verts, faces, L_dev, extra = GShellFlexiCubes()(x_nx3, s_n, nu_n, cube_fx8, res, beta_fx12, alpha_fx8, gamma_f)
+
+Index / topology work runs as HIP kernels (gshell_amd/csrc/flexi.hip) over a STATIC per-grid edge table, so no
+`torch.unique` / stable sort / python loop over `num_vd` groups runs per call; the floating-point part (weighted zero
+crossings, dual vertices, L_dev, the mSDF cut interpolation) is expressed as gather / index_add torch ops on the index
+tables the kernels emit, which gives its backward pass through autograd.  Output orderings are bit-identical to the
+reference (tests/test_flexi_gpu.py against goldens minted from the real reference).
+
+Not implemented (never reached by the reference's scripts): training=True quad fans, output_tetmesh, grad_func.
+"""
+import torch
+
+from .. import _lib
+from .._lib import c_int64, check, ptr, stream
+
+# local cube edge e joins corners _CUBE_EDGES[e] in this orientation (reference :88-89)
+_CUBE_EDGES = [[0, 1], [1, 5], [4, 5], [0, 4], [2, 3], [3, 7], [6, 7], [2, 6], [2, 0], [3, 1], [7, 5], [6, 4]]
+# mSDF cut of a triangle: ids 0-2 corners, 3-5 boundary points on edges (01, 12, 20); index = m0*4 + m1*2 + m2 (reference
+# geometry/flexicubes_table.py:794-812)
+_CUT_N = [0, 1, 1, 2, 1, 2, 2, 1]
+_CUT_CFG = [[0, 0, 0, 0, 0, 0], [4, 2, 5, 0, 0, 0], [3, 1, 4, 0, 0, 0], [3, 1, 2, 3, 2, 5], [0, 3, 5, 0, 0, 0], [0, 3, 4, 0, 4, 2],
+            [0, 1, 4, 0, 4, 5], [0, 1, 2, 0, 0, 0]]
+
+
+class FlexiTopology:
+    """Static per-grid tables in HBM (built once with torch sort/unique; the per-call path never sorts)."""
+
+    def __init__(self, cube_fx8, num_verts, res):
+        dev = cube_fx8.device
+        cubes = cube_fx8.long()
+        self.F, self.N = int(cubes.shape[0]), int(num_verts)
+        self.res = [int(res)] * 3 if not isinstance(res, (list, tuple)) else [int(r) for r in res]
+        ce = torch.tensor(_CUBE_EDGES, device=dev)
+        pairs = cubes[:, ce]
+        key = pairs[..., 0] * self.N + pairs[..., 1]
+        ukey, inv, counts = torch.unique(key.reshape(-1), return_inverse=True, return_counts=True)
+        self.E = int(ukey.numel())
+        self.edges = torch.stack([ukey // self.N, ukey % self.N], -1).int().contiguous()
+        self.cube_edge = inv.reshape(-1, 12).int().contiguous()
+        self.ncubes = counts.to(torch.uint8).contiguous()
+        order = torch.sort(inv, stable=True).indices
+        start = torch.cumsum(counts, 0) - counts
+        inc = torch.full((self.E, 4), -1, dtype=torch.int32, device=dev)
+        grp = inv[order]
+        inc[grp, torch.arange(order.numel(), device=dev) - start[grp]] = order.int()
+        self.inc = inc.contiguous()
+        self.cubes_i32 = cubes.int().contiguous()
+        self.corner_of_edge = ce                                   # [12,2]
+
+
+class GShellFlexiCubes:
+    def __init__(self, device="cuda", qef_reg_scale=1e-3, weight_scale=0.99):
+        self.device = device
+        self.weight_scale = weight_scale
+        self.qef_reg_scale = qef_reg_scale
+        self.cube_edges = torch.tensor(_CUBE_EDGES, dtype=torch.long, device=device).reshape(-1)
+        self._topo_cache = {}
+
+    # ---- grid ------------------------------------------------------------------------------------------
+    def construct_voxel_grid(self, res):
+        """Vertices in [-0.5, 0.5]^3 and the 8 corner indices of every cube, in the reference's layout (:103-134): vertex
+        index = lexicographic rank of (x,y,z); cube (i,j,k) has number (i*res_y + j)*res_z + k; corner c = (c&1, (c>>1)&1, c>>2)."""
+        r = [res] * 3 if isinstance(res, int) else list(res)
+        dev = self.device
+        ax = [torch.arange(n + 1, device=dev) for n in r]
+        i, j, k = torch.meshgrid(*ax, indexing="ij")
+        verts = torch.stack([i / r[0], j / r[1], k / r[2]], -1).reshape(-1, 3).float() - 0.5
+        ci, cj, ck = torch.meshgrid(*[torch.arange(n, device=dev) for n in r], indexing="ij")
+        base = torch.stack([ci, cj, ck], -1).reshape(-1, 1, 3)
+        corner = torch.tensor([[c & 1, (c >> 1) & 1, c >> 2] for c in range(8)], device=dev)[None]
+        p = base + corner
+        cubes = (p[..., 0] * (r[1] + 1) + p[..., 1]) * (r[2] + 1) + p[..., 2]
+        return verts, cubes
+
+    def topology(self, cube_fx8, num_verts, res):
+        key = (cube_fx8.data_ptr(), tuple(cube_fx8.shape), int(num_verts), str(res))
+        t = self._topo_cache.get(key)
+        if t is None:
+            t = FlexiTopology(cube_fx8, num_verts, res)
+            self._topo_cache = {key: t}
+        return t
+
+    # ---- extraction ----------------------------------------------------------------------------------------
+    def __call__(self, x_nx3, s_n, nu_n, cube_fx8, res, beta_fx12=None, alpha_fx8=None, gamma_f=None, training=False, output_tetmesh=False,
+                 grad_func=None):
+        if training or output_tetmesh or grad_func is not None:
+            raise NotImplementedError("training=True / output_tetmesh / grad_func are never used by the G-Shell scripts (SURVEY.md 3.4)")
+        L = _lib.lib()
+        dev = x_nx3.device
+        topo = self.topology(cube_fx8, x_nx3.shape[0], res)
+        F, E, N = topo.F, topo.E, topo.N
+        s1 = s_n.reshape(-1)
+        nu1 = nu_n.reshape(-1)
+        s_c = s1.detach().contiguous().float()
+        i32 = dict(dtype=torch.int32, device=dev)
+        u8 = dict(dtype=torch.uint8, device=dev)
+
+        with torch.cuda.device(dev), torch.no_grad():
+            case_id, num_vd, n_ent = torch.empty(F, **u8), torch.empty(F, **u8), torch.empty(F, **u8)
+            scratch = torch.empty(2 * F, **u8)
+            check(L.gs_flexi_classify(ptr(s_c, torch.float32, "s"), ptr(topo.cubes_i32), c_int64(F), c_int64(topo.res[0]), c_int64(topo.res[1]),
+                                      c_int64(topo.res[2]), ptr(scratch), ptr(case_id), ptr(num_vd), ptr(n_ent), stream()), "gs_flexi_classify")
+            flags = torch.empty(E, **u8)
+            check(L.gs_flexi_edge_flags(ptr(s_c), ptr(topo.edges), ptr(topo.ncubes), c_int64(E), ptr(flags), stream()), "gs_flexi_edge_flags")
+            # prefix ranks (reference orderings): dual vertices by (num_vd group, cube, j), entries by (group, cube, j, slot),
+            # quads by ascending edge id with the flipped ones first
+            nv = num_vd.long()
+            ne = n_ent.long()
+            vd_base = torch.zeros(F, dtype=torch.long, device=dev)
+            ent_base = torch.zeros(F, dtype=torch.long, device=dev)
+            tot_vd = torch.zeros((), dtype=torch.long, device=dev)
+            tot_ent = torch.zeros((), dtype=torch.long, device=dev)
+            for n in (1, 2, 3, 4):
+                m = nv == n
+                ml = m.long()
+                vd_base = torch.where(m, tot_vd + (torch.cumsum(ml, 0) - 1) * n, vd_base)
+                en = ne * ml
+                ent_base = torch.where(m, tot_ent + torch.cumsum(en, 0) - en, ent_base)
+                tot_vd = tot_vd + ml.sum() * n
+                tot_ent = tot_ent + en.sum()
+            quad = (flags & 2) != 0
+            flip = (flags & 4) != 0
+            qf, qn = (quad & flip).long(), (quad & ~flip).long()
+            n_flip = qf.sum()
+            qrank = torch.where(flip, torch.cumsum(qf, 0) - 1, n_flip + torch.cumsum(qn, 0) - 1).int().contiguous()
+            n_vd, n_entries, n_quads = (int(v) for v in torch.stack([tot_vd, tot_ent, n_flip + qn.sum()]).tolist())     # the one host sync
+        if n_vd == 0:           # no surface: the reference returns a 3-tuple (:193-202)
+            return (torch.zeros((0, 3), device=dev), torch.zeros((0, 3), dtype=torch.long, device=dev), torch.zeros((0,), device=dev))
+
+        with torch.cuda.device(dev), torch.no_grad():
+            ent_vd, ent_edge, ent_cube, ent_e = (torch.empty(n_entries, **i32) for _ in range(4))
+            vd_idx_map = torch.full((F, 12), -1, **i32)
+            vd_cube = torch.empty(n_vd, **i32)
+            vd_base32, ent_base32 = vd_base.int().contiguous(), ent_base.int().contiguous()     # keep alive across the launch
+            check(L.gs_flexi_entries(ptr(case_id), ptr(num_vd), ptr(vd_base32), ptr(ent_base32), ptr(topo.cube_edge),
+                                     c_int64(F), ptr(ent_vd), ptr(ent_edge), ptr(ent_cube), ptr(ent_e), ptr(vd_idx_map), ptr(vd_cube), stream()),
+                  "gs_flexi_entries")
+
+        # ---- normalised weights (:242-264)
+        ws = self.weight_scale
+        beta = torch.ones((F, 12), device=dev) if beta_fx12 is None else torch.tanh(beta_fx12) * ws + 1
+        alpha = torch.ones((F, 8), device=dev) if alpha_fx8 is None else torch.tanh(alpha_fx8) * ws + 1
+        gamma = torch.ones((F,), device=dev) if gamma_f is None else torch.sigmoid(gamma_f) * ws + (1 - ws) / 2
+
+        # ---- dual vertices (:387-485): float math over the entry tables
+        ev, ee, ec, el = ent_vd.long(), ent_edge.long(), ent_cube.long(), ent_e.long()
+        a_id, b_id = topo.edges[ee, 0].long(), topo.edges[ee, 1].long()
+        corner = topo.corner_of_edge[el]
+        ca = (s1[a_id] * alpha[ec, corner[:, 0]])[:, None]
+        cb = (s1[b_id] * alpha[ec, corner[:, 1]])[:, None]
+        xa, xb = x_nx3[a_id], x_nx3[b_id]
+        na, nb = nu1[a_id, None], nu1[b_id, None]
+
+        def interp(wa, wb, va, vb):
+            return (va * wb - vb * wa) / (wb - wa)
+        ue = interp(ca, cb, xa, xb)
+        nu_e = interp(ca, cb, na, nb)
+        nu_e_sv = interp(ca.detach(), cb.detach(), na, nb)
+        bt = beta[ec, el][:, None]
+        beta_sum = torch.zeros((n_vd, 1), device=dev).index_add(0, ev, bt)
+        vd = torch.zeros((n_vd, 3), device=dev).index_add(0, ev, ue * bt) / beta_sum
+        nu_d = torch.zeros((n_vd, 1), device=dev).index_add(0, ev, nu_e * bt) / beta_sum
+        nu_d = nu_d.index_add(0, ev, nu_e_sv * bt.detach())              # value of the reference's in-place index_add_ (:476-477)
+        nu_d_sv = nu_d / beta_sum.detach()
+        zc = interp(s1[a_id, None], s1[b_id, None], xa, xb)
+        dist = (zc - vd[ev]).norm(dim=-1)
+        ones = torch.ones_like(dist)
+        mean_l2 = torch.zeros(n_vd, device=dev).index_add(0, ev, dist) / torch.zeros(n_vd, device=dev).index_add(0, ev, ones)
+        L_dev = (dist - mean_l2[ev]).abs()
+
+        # ---- quads -> triangles (:487-522)
+        with torch.cuda.device(dev), torch.no_grad():
+            vd_gamma = gamma.detach()[vd_cube.long()].contiguous().float()
+            faces = torch.empty((2 * n_quads, 3), dtype=torch.int64, device=dev)
+            check(L.gs_flexi_quads(ptr(flags), ptr(qrank), ptr(topo.inc), ptr(vd_idx_map), ptr(vd_gamma), c_int64(E), ptr(faces), ptr(None),
+                                   stream()), "gs_flexi_quads")
+
+        # ---- mSDF cut (:554-599)
+        extra = {'n_verts_watertight': n_vd, 'vertices_watertight': vd, 'faces_watertight': faces, 'msdf_watertight': nu_d}
+        with torch.no_grad():
+            mocc = (nu_d.reshape(-1) >= 0)[faces]
+            msum = mocc.sum(-1)
+            uncut_mask, cut_mask = msum == 3, (msum < 3) & (msum > 0)
+            uncut, cut = faces[uncut_mask], faces[cut_mask]
+        if uncut.shape[0] == 0:         # reference quirk: nothing survives un-cut -> the UNCUT mesh is returned (:566-567)
+            extra.update(msdf=nu_d, msdf_boundary=nu_d[:1].detach() * 0.0)
+            return vd, faces, L_dev, extra
+        pa, pb = cut[:, [0, 1, 2]].reshape(-1), cut[:, [1, 2, 0]].reshape(-1)
+
+        def interp_nonan(wa, wb, va, vb):
+            den = wb - wa
+            ok = den.abs() > 0
+            safe = torch.where(ok, den, torch.ones_like(den))
+            return va * torch.where(ok, wb / safe, torch.zeros_like(den)) + vb * torch.where(ok, -wa / safe, torch.zeros_like(den))
+        bverts = interp_nonan(nu_d[pa], nu_d[pb], vd[pa], vd[pb])
+        bnu = interp_nonan(nu_d_sv[pa].detach(), nu_d_sv[pb].detach(), nu_d_sv[pa], nu_d_sv[pb])
+        with torch.no_grad():
+            mc = mocc[cut_mask].long()
+            cfg = mc[:, 0] * 4 + mc[:, 1] * 2 + mc[:, 2]
+            idx_map = torch.cat([cut, n_vd + torch.arange(cut.shape[0] * 3, device=dev).reshape(-1, 3)], -1)
+            cut_n = torch.tensor(_CUT_N, device=dev)[cfg]
+            cut_cfg = torch.tensor(_CUT_CFG, device=dev)[cfg]
+            one, two = cut_n == 1, cut_n == 2
+            faces_open = torch.cat([uncut, torch.gather(idx_map[one], 1, cut_cfg[one][:, :3]).reshape(-1, 3),
+                                    torch.gather(idx_map[two], 1, cut_cfg[two][:, :6]).reshape(-1, 3)])
+        extra.update(msdf=torch.cat([nu_d_sv, bnu]), msdf_boundary=bnu)
+        return torch.cat([vd, bverts]), faces_open, L_dev, extra

@@ -339,6 +339,28 @@ int64_t gs_sdf_mlp_packed_floats(int n_freq, int n_hidden, int skip_layer);
 int gs_sdf_mlp_fwd(const float* x, int64_t N, const float* packed, int n_freq, int n_hidden,
                    int skip_layer, float* out, gs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * G-FlexiCubes topology   (replaces the index machinery of GShellFlexiCubes.__call__,
+ *   geometry/gshell_flexicubes.py:136-230: _identify_surf_cubes :334, _get_case_id :266, _identify_surf_edges :309,
+ *   the edge-group tables of _compute_vd :406-485 and the quad gathering / splitting of _triangulate :493-522)
+ *   Static per-grid tables come from the caller: edges [E,2] i32 (unique ORDERED cube edges, lexicographic),
+ *   cube_edge [F,12] i32, ncubes [E] u8, inc [E,4] i32 (incident cube*12+e, ascending, -1 padded).
+ *   gs_flexi_classify  : case_id / num_vd / n_ent [F] u8 (0 for non-surface cubes); scratch 2F bytes; regular grid res0*res1*res2 = F.
+ *   gs_flexi_edge_flags: flags [E] u8: bit0 crossing, bit1 emits a quad (crossing & 4 cubes), bit2 s[first end] > 0.
+ *   gs_flexi_entries   : edge-group entries at ent_base[c] (order: dual vertex, slot) and dual vertex ids vd_base[c] + j:
+ *                        ent_vd / ent_edge / ent_cube / ent_e [n_ent] i32, vd_idx_map [F,12] i32 (caller pre-fills -1), vd_cube [n_vd].
+ *   gs_flexi_quads     : faces [2Q,3] i64 (+ optional i32 copy) at 6*qrank[e]; vd_gamma [n_vd] f32 = normalised gamma per dual vertex.
+ * ---------------------------------------------------------------------------------- */
+int gs_flexi_classify(const float* s, const int32_t* cubes_fx8, int64_t F, int64_t res0, int64_t res1, int64_t res2,
+                      uint8_t* scratch_2F, uint8_t* case_id, uint8_t* num_vd, uint8_t* n_ent, gs_stream_t stream);
+int gs_flexi_edge_flags(const float* s, const int32_t* edges_ex2, const uint8_t* ncubes, int64_t E, uint8_t* flags,
+                        gs_stream_t stream);
+int gs_flexi_entries(const uint8_t* case_id, const uint8_t* num_vd, const int32_t* vd_base, const int32_t* ent_base,
+                     const int32_t* cube_edge, int64_t F, int32_t* ent_vd, int32_t* ent_edge, int32_t* ent_cube,
+                     int32_t* ent_e, int32_t* vd_idx_map, int32_t* vd_cube, gs_stream_t stream);
+int gs_flexi_quads(const uint8_t* flags, const int32_t* qrank, const int32_t* inc_ex4, const int32_t* vd_idx_map,
+                   const float* vd_gamma, int64_t E, int64_t* faces, int32_t* faces_i32, gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
