@@ -62,6 +62,13 @@ class ViewShard:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
 
+    def broadcast(self, tensors, src=0):
+        """Make replicated state bit-identical on every rank (parameters after a pre-fit whose GPU reductions are not
+        order-deterministic): geometry replication relies on identical SDF signs everywhere."""
+        if self.world > 1:
+            for t in tensors:
+                dist.broadcast(t.data if hasattr(t, "data") else t, src=src, group=self.group)
+
 
 def flat_all_reduce_grads(params, shard, buf=None):
     """Sum the gradients of `params` over the ranks of `shard` with ONE all-reduce of a flat fp32 bucket
@@ -136,6 +143,11 @@ class Trainer:
         self.scheds = [torch.optim.lr_scheduler.LambdaLR(o, lr_lambda=sched) for o in (self.opt_mat, self.opt_mesh, self.opt_light)]
         self.it = 0
         self._flat = None
+
+    def sync_replicas(self):
+        """Broadcast every trainable tensor from rank 0 (call once after construction / pre-fitting)."""
+        self.shard.broadcast(self.all_params())
+        self.lgt.update_pdf()
 
     def all_params(self):
         return [p for g in self.opt_mesh.param_groups for p in g['params']] + self.mat_params + list(self.lgt.parameters())

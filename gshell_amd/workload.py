@@ -104,4 +104,5 @@ def build(res=256, n_samples=8, batch=4, train_res=(512, 512), shard=None, fit_s
     trainer = Trainer(flags, tet_grid=(verts, tets), shard=shard)
     fit_sdf_net(trainer.geometry, steps=fit_steps, seed=seed)
     set_mid_training_state(trainer.geometry, seed)
+    trainer.sync_replicas()          # ranks of a view-sharded job must start from bit-identical parameters
     return trainer

@@ -42,6 +42,9 @@ def _worker(rank, world, port, B, out_q):
     flags = torch.zeros(6, dtype=torch.int32)
     flags[rank::3] = 1
     shard.all_reduce_max(flags)                            # union of per-rank visibility flags
+    rep = torch.full((3,), float(rank + 1))
+    shard.broadcast([rep])                                 # replicas start from rank 0's values
+    assert rep.tolist() == [1.0, 1.0, 1.0]
     out_q.put((rank, views, a.grad.clone(), b.grad.clone(), unused.grad.clone(), flags.clone()))
     dist.barrier()
     dist.destroy_process_group()
