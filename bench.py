@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--train-res", type=int, default=512)
     ap.add_argument("--n-samples", type=int, default=8)
     ap.add_argument("--fit-steps", type=int, default=400)
+    ap.add_argument("--geometry", choices=["tets", "flexicubes"], default="tets", help="flexicubes + --res 80 = BASELINE.json configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--op-times", action="store_true", help="also print per-op HIP-event times (adds sync points)")
     return ap.parse_args()
@@ -52,7 +53,7 @@ def main():
     shard = ViewShard(rank, world)
     B_local, B_global = a.views, a.views * world
     H = W = a.train_res
-    trainer = workload.build(res=a.res, n_samples=a.n_samples, batch=B_global, train_res=(H, W), shard=shard, fit_steps=a.fit_steps)
+    trainer = workload.build(res=a.res, n_samples=a.n_samples, batch=B_global, train_res=(H, W), shard=shard, fit_steps=a.fit_steps, geometry=a.geometry)
     # this rank's views of every global batch: ids [it*B + r, it*B + r + world, ...]
     n_iters = a.warmup + a.steps
     targets = [workload.make_targets(trainer, [(it * B_global + v) % 72 for v in shard.local_views(B_global)], (H, W)) for it in range(min(n_iters, 4))]
@@ -91,7 +92,7 @@ def main():
             "value": round(mpix, 4), "unit": "Mpixels/s", "iters_per_sec": round(a.steps / dt, 4),
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"tet-res{a.res} (BCC {N} verts / {Ftets} tets), {B_local} views/GPU x {H}x{W}, n_samples={a.n_samples} "
+            "config": {"workload": f"{'G-FlexiCubes res' if a.geometry == 'flexicubes' else 'tet-res'}{a.res} ({'voxel grid' if a.geometry == 'flexicubes' else 'BCC'} {N} verts / {Ftets} cells), {B_local} views/GPU x {H}x{W}, n_samples={a.n_samples} "
                                    f"({2 * a.n_samples ** 2} shadow rays/px/pass), full train iteration fwd+bwd+3xAdam",
                        "global_batch": B_global, "mesh": {"V_aug": V_aug, "T": T}, "parallelism": f"view-shard dp{world}, geometry replicated"},
         }

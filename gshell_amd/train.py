@@ -134,7 +134,9 @@ class Trainer:
             {'params': [p for n, p in named if 'deform' in n], 'lr': lr_pos},
             {'params': [p for n, p in named if 'msdf' in n], 'lr': lr_pos},
             {'params': [p for n, p in named if 'sdf' in n and 'msdf' not in n], 'lr': lr_pos * 1e-2},
+            {'params': [p for n, p in named if 'sdf' not in n and 'deform' not in n], 'lr': lr_pos * 1e-2},     # FlexiCubes per-cube weights
         ]
+        groups = [g for g in groups if len(g['params'])]
         self.opt_mesh = torch.optim.Adam(groups, eps=1e-8) if FLAGS.use_sdf_mlp else torch.optim.Adam(self.geometry.parameters(), lr=lr_pos)
         self.mat_params = list(self.mat['kd_ks'].parameters())
         self.opt_mat = torch.optim.Adam(self.mat_params, lr=lr_mat)

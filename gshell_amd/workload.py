@@ -44,7 +44,8 @@ def views(indices, device, radius=2.2):
 
 
 def skirt_sdf(x):
-    """Signed field whose zero set is a capped cone; sign convention of the reference's sphere init (positive outside)."""
+    """Signed field whose zero set is a capped cone; sign convention of the reference's sphere init (positive outside;
+    FlexiCubes reads negative = inside, MarchingTets only needs the sign change)."""
     r = torch.sqrt(x[:, 0] ** 2 + x[:, 2] ** 2)
     inside = torch.minimum(0.42 - 0.22 * x[:, 1] - r, 0.5 - x[:, 1].abs())
     return -inside
@@ -94,14 +95,20 @@ def make_targets(trainer, view_ids, res, seed=1):
     return target
 
 
-def build(res=256, n_samples=8, batch=4, train_res=(512, 512), shard=None, fit_steps=400, seed=0, **flag_overrides):
+def build(res=256, n_samples=8, batch=4, train_res=(512, 512), shard=None, fit_steps=400, seed=0, geometry="tets", **flag_overrides):
+    """geometry = "tets" (G-MarchingTets on the BCC grid standing in for data/tets/{res}_tets.npz) or "flexicubes"
+    (G-FlexiCubes on the reference's own res^3 voxel grid, BASELINE.json configs[4])."""
     from .train import Trainer, default_flags
     dev = torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(seed)
     np.random.seed(seed)
-    verts, tets = gridlib.grid_for_res(res, device=dev)
     flags = default_flags(gshell_grid=res, n_samples=n_samples, batch=batch, train_res=list(train_res), sdf_mlp_pretrain_steps=0, **flag_overrides)
-    trainer = Trainer(flags, tet_grid=(verts, tets), shard=shard)
+    if geometry == "flexicubes":
+        from .geometry.gshell_flexicubes_geometry import GShellFlexiCubesGeometry
+        trainer = Trainer(flags, shard=shard, geometry=GShellFlexiCubesGeometry(res, flags.mesh_scale, flags))
+    else:
+        verts, tets = gridlib.grid_for_res(res, device=dev)
+        trainer = Trainer(flags, tet_grid=(verts, tets), shard=shard)
     fit_sdf_net(trainer.geometry, steps=fit_steps, seed=seed)
     set_mid_training_state(trainer.geometry, seed)
     trainer.sync_replicas()          # ranks of a view-sharded job must start from bit-identical parameters
