@@ -201,8 +201,9 @@ class GShellFlexiCubes:
             mc = mocc[cut_mask].long()
             cfg = mc[:, 0] * 4 + mc[:, 1] * 2 + mc[:, 2]
             idx_map = torch.cat([cut, n_vd + torch.arange(cut.shape[0] * 3, device=dev).reshape(-1, 3)], -1)
-            cut_n = torch.tensor(_CUT_N, device=dev)[cfg]
-            cut_cfg = torch.tensor(_CUT_CFG, device=dev)[cfg]
+            if getattr(self, "_cut_tabs", None) is None or self._cut_tabs[0].device != cfg.device:
+                self._cut_tabs = (torch.tensor(_CUT_N, device=dev), torch.tensor(_CUT_CFG, device=dev))
+            cut_n, cut_cfg = self._cut_tabs[0][cfg], self._cut_tabs[1][cfg]
             one, two = cut_n == 1, cut_n == 2
             faces_open = torch.cat([uncut, torch.gather(idx_map[one], 1, cut_cfg[one][:, :3]).reshape(-1, 3),
                                     torch.gather(idx_map[two], 1, cut_cfg[two][:, :6]).reshape(-1, 3)])

@@ -177,7 +177,7 @@ class GShellTetsGeometry(torch.nn.Module):
         msdf_img = buffers['msdf_image']
         img_loss = img_loss + 5e-1 * F.l1_loss(msdf_img.clamp(min=0) * (gt_mask == 0).float(), torch.zeros_like(gt_mask))
         img_loss = img_loss + 5e-1 * F.l1_loss(msdf_img.clamp(max=0) * (gt_mask == 1).float(), torch.ones_like(gt_mask))
-        depth_loss = torch.tensor(0., device=dev)        # use_depth is off in every reference config
+        depth_loss = torch.zeros((), device=dev)         # use_depth is off in every reference config
 
         # ---- eikonal on the SDF network at surface samples (reference :302-324): double backward stays in torch
         if FL.use_sdf_mlp and FL.use_eikonal and d['sampled_pts'] is not None:
@@ -190,17 +190,17 @@ class GShellTetsGeometry(torch.nn.Module):
             grad = torch.autograd.grad(sdf_eik.sum(), v, create_graph=True)[0]
             eik_loss = eik_coeff * (grad.pow(2).sum(dim=-1).sqrt() - 1).pow(2).mean()
         else:
-            eik_loss = torch.tensor(0., device=dev)
+            eik_loss = torch.zeros((), device=dev)
 
         # ---- mSDF open / close regularisers (reference :326-358)
         if FL.use_mesh_msdf_reg:
             regscale = (64 / self.grid_res) ** 3
-            eps = torch.tensor([1e-3], device=dev)
+            eps = torch.full((1,), 1e-3, device=dev)          # torch.full: no host->device copy (a pageable H2D copy stalls the queue)
             if FL.msdf_reg_open_scale > 0:
-                m = d['msdf'].clamp(min=-eps).squeeze()
+                m = d['msdf'].clamp(min=-eps).reshape(-1)
                 msdf_reg = FL.msdf_reg_open_scale * regscale * F.huber_loss(m, -eps.expand(d['msdf'].size(0)), reduction='sum')
             else:
-                msdf_reg = torch.tensor(0., device=dev)
+                msdf_reg = torch.zeros((), device=dev)
             if FL.msdf_reg_close_scale != 0:
                 with torch.no_grad():
                     nwt = d['n_verts_watertight']
@@ -215,10 +215,10 @@ class GShellTetsGeometry(torch.nn.Module):
                     vis_mask = torch.zeros(d['msdf_boundary'].size(0), dtype=torch.bool, device=dev)
                     vis_mask[vis_verts[vis_verts >= nwt] - nwt] = True
                 bm = d['msdf_boundary'][vis_mask]
-                msdf_reg = msdf_reg + FL.msdf_reg_close_scale * regscale * F.huber_loss(bm.clamp(max=eps).squeeze(), eps.expand(bm.size(0)),
+                msdf_reg = msdf_reg + FL.msdf_reg_close_scale * regscale * F.huber_loss(bm.clamp(max=eps).reshape(-1), eps.expand(bm.size(0)),
                                                                                         reduction='sum')
         else:
-            msdf_reg = torch.tensor(0., device=dev)
+            msdf_reg = torch.zeros((), device=dev)
 
         sdf_weight = FL.sdf_regularizer - (FL.sdf_regularizer - 0.01) * min(1.0, 4.0 * t_iter)
         sdf_reg = compute_sdf_reg_loss(d['sdf'], self.all_edges).mean() * sdf_weight

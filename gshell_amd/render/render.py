@@ -31,6 +31,17 @@ def _noise(name, draw):
     return draw()
 
 
+_consts = {}
+
+
+def _const_011(dev):
+    """[1,1,1,3] mask (0,1,1), created once per device (a fresh torch.tensor(...) per call is a blocking H2D copy)."""
+    key = ("011", str(dev))
+    if key not in _consts:
+        _consts[key] = torch.tensor([0, 1, 1], dtype=torch.float32, device=dev)[None, None, None, :]
+    return _consts[key]
+
+
 def interpolate(attr, rast, attr_idx, rast_db=None):
     return dr.interpolate(attr.contiguous(), rast, attr_idx, rast_db=rast_db, diff_attrs=None if rast_db is None else 'all')
 
@@ -66,7 +77,7 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
         assert all_tex.shape[-1] == 6, "Combined kd_ks must be 6 channels"
         kd, ks = all_tex[..., 0:3], all_tex[..., 3:6]
         kd_grad = torch.abs(all_tex_jitter[..., 0:3] - kd)
-        ks_grad = torch.abs(all_tex_jitter[..., 3:6] - ks) * torch.tensor([0, 1, 1], dtype=torch.float32, device=dev)[None, None, None, :]
+        ks_grad = torch.abs(all_tex_jitter[..., 3:6] - ks) * _const_011(dev)      # omit the o-component (reference :74)
     else:
         raise NotImplementedError("only the combined 'kd_ks' material of the G-Shell scripts is supported (uv-textured materials need "
                                   "mip-mapped texture sampling, which the G-Shell path never enters)")

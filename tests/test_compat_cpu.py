@@ -1,0 +1,47 @@
+"""The drop-in shim resolves the reference's import names to this package (host logic; no GPU needed)."""
+import subprocess
+import sys
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import sys
+sys.path.insert(0, %r)
+import gshell_amd.compat as c
+c.install()
+from geometry.gshell_tets_geometry import GShellTetsGeometry
+from geometry.gshell_tets import GShell_Tets
+from geometry.gshell_flexicubes_geometry import GShellFlexiCubesGeometry
+from render import render, light, mlptexture, mesh, util, regularizer
+import render.renderutils as ru
+import render.optixutils as ou
+import nvdiffrast.torch as dr
+import tinycudann as tcnn
+import kaolin
+from denoiser.denoiser import BilateralDenoiser
+assert GShellTetsGeometry.__module__ == "gshell_amd.geometry.gshell_tets_geometry"
+for name in ("render_mesh", "render_layer", "shade"):
+    assert hasattr(render, name)
+for name in ("xfm_points", "prepare_shading_normal", "image_loss"):
+    assert hasattr(ru, name)
+for name in ("OptiXContext", "optix_build_bvh", "optix_env_shade", "bilateral_denoiser"):
+    assert hasattr(ou, name)
+for name in ("RasterizeGLContext", "RasterizeCudaContext", "DepthPeeler", "rasterize", "interpolate", "texture", "antialias"):
+    assert hasattr(dr, name)
+assert hasattr(tcnn, "Encoding") and callable(kaolin.ops.mesh.sample_points)
+import inspect
+# signatures the reference's call sites rely on (render/render.py:325-346, ops.py:141, gshell_tets.py:245)
+sig = inspect.signature(render.render_mesh)
+assert list(sig.parameters)[:7] == ["FLAGS", "ctx", "mesh", "mtx_in", "view_pos", "lgt", "resolution"]
+assert list(inspect.signature(ou.optix_env_shade).parameters)[:12] == ["optix_ctx", "mask", "ro", "gb_pos", "gb_normal", "gb_view_pos", "gb_kd", "gb_ks",
+                                                                       "light", "pdf", "rows", "cols"]
+assert list(inspect.signature(GShell_Tets.__call__).parameters)[1:5] == ["pos_nx3", "sdf_n", "msdf_n", "tet_fx4"]
+print("compat ok")
+"""
+
+
+def test_compat_install_resolves_reference_imports():
+    out = subprocess.run([sys.executable, "-c", SCRIPT % ROOT], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "compat ok" in out.stdout
