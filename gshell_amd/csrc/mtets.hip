@@ -86,6 +86,27 @@ __device__ __forceinline__ bool msdf_weights(float ma, float mb, float& wa, floa
 
 __device__ __forceinline__ int sel4(int a, int b, int c, int d, int k) { return k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d)); }
 
+// Inputs of the generative-decode variant (ref :446-629, marching_from_auggrid): every per-edge
+// quantity is looked up in a cubic grid at the edge's canonical midpoint instead of being
+// interpolated from per-vertex fields.
+struct AugIn {
+    const int32_t* vdisc;     // [N,3] grid vertex -> integer cell of the (2x denser) cubic grid (ref 'verts_discretized')
+    const float* coeff;       // [G,G,G] crossing coefficient per tet-edge midpoint (ref 'coeff_sdf_interp')
+    const float* msdf_grid;   // [G,G,G] mSDF sign per tet-edge midpoint (ref 'midpoint_msdf_sign_n')
+    const float* occ;         // [G2,G2,G2] boundary coefficient per mesh-edge midpoint (ref 'occgrid')
+    int G, G2;
+};
+// flat index of the canonical midpoint of grid edge (a,b) (ref :481: mean of the two cells, truncated)
+__device__ __forceinline__ int64_t aug_mid(const AugIn& g, int a, int b) {
+    int64_t idx = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int m = (g.vdisc[(int64_t)a * 3 + d] + g.vdisc[(int64_t)b * 3 + d]) >> 1;
+        idx = idx * g.G + min(max(m, 0), g.G - 1);
+    }
+    return idx;
+}
+
 // ------------------------------------------------------------------------------------
 // count phase
 // ------------------------------------------------------------------------------------
@@ -142,10 +163,11 @@ __device__ __forceinline__ void code_cats(uint8_t cb, int& ntri, int& ci, int& n
     ncut = ntri == 1 ? nt : (ntri == 2 ? nq : 0);
 }
 
+template <bool AUG>
 __global__ void __launch_bounds__(256) k_classify(const int4* __restrict__ tets, int64_t F, const uint64_t* __restrict__ occ,
                                                   const float* __restrict__ sdf, const float* __restrict__ msdf,
                                                   uint8_t* __restrict__ code_out, int32_t* __restrict__ blk_cnt,
-                                                  unsigned long long* __restrict__ counts) {
+                                                  unsigned long long* __restrict__ counts, AugIn G) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t* __restrict__ occ32 = (const uint32_t*)occ;
     int cnt[MT_NCAT];
@@ -174,10 +196,15 @@ __global__ void __launch_bounds__(256) k_classify(const int4* __restrict__ tets,
                     int gi = sel4(t.x, t.y, t.z, t.w, c_edge_ca[le]);
                     int gj = sel4(t.x, t.y, t.z, t.w, c_edge_cb[le]);
                     int a = min(gi, gj), b = max(gi, gj);
-                    float wa, wb;
-                    sdf_weights(sdf[a], sdf[b], wa, wb);
-                    float mv = msdf[a] * wa + msdf[b] * wb;
-                    ci = (ci << 1) | (mv > 0.0f ? 1 : 0);  // ref :396-399 (first corner = MSB)
+                    float mv;
+                    if (AUG) {
+                        mv = G.msdf_grid[aug_mid(G, a, b)];  // ref :486
+                    } else {
+                        float wa, wb;
+                        sdf_weights(sdf[a], sdf[b], wa, wb);
+                        mv = msdf[a] * wa + msdf[b] * wb;
+                    }
+                    ci = (ci << 1) | (mv > 0.0f ? 1 : 0);  // ref :396-399 / :603-606 (first corner = MSB)
                 }
                 ncut = ntri == 1 ? c_ncut_tri[ci] : c_ncut_quad[ci];
             }
@@ -221,11 +248,12 @@ __device__ int block_prefix_256(const int32_t* __restrict__ seq, int64_t n, int 
 // ------------------------------------------------------------------------------------
 // fill phase
 // ------------------------------------------------------------------------------------
+template <bool AUG>
 __global__ void __launch_bounds__(256) k_vertices(const int2* __restrict__ edges, int64_t nchunks, const uint64_t* __restrict__ mask,
                                                   const int32_t* __restrict__ edge_blk, int32_t* __restrict__ chunk_base,
                                                   const float* __restrict__ pos, const float* __restrict__ sdf,
                                                   const float* __restrict__ msdf, float* __restrict__ verts_wt,
-                                                  float* __restrict__ msdf_aug, int32_t* __restrict__ vert_ab) {
+                                                  float* __restrict__ msdf_aug, int32_t* __restrict__ vert_ab, AugIn G) {
     __shared__ uint64_t s_mask[MT_CHUNKS_PER_BLOCK];
     __shared__ int s_base[MT_CHUNKS_PER_BLOCK];
     __shared__ int s_w[4];
@@ -259,11 +287,19 @@ __global__ void __launch_bounds__(256) k_vertices(const int2* __restrict__ edges
             const int vid = s_base[lc] + __popcll(mm & lanemask_lt());
             const int64_t e = ((int64_t)blockIdx.x * MT_CHUNKS_PER_BLOCK + lc) * 64 + lane;
             const int2 ab = edges[e];
-            float wa, wb;
-            sdf_weights(sdf[ab.x], sdf[ab.y], wa, wb);
+            if (AUG) {
+                const int64_t mid = aug_mid(G, ab.x, ab.y);
+                const float c = fminf(fmaxf(G.coeff[mid], 0.0f), 1.0f), omc = 1.0f - c;  // ref :483
 #pragma unroll
-            for (int d = 0; d < 3; ++d) verts_wt[(int64_t)vid * 3 + d] = pos[(int64_t)ab.x * 3 + d] * wa + pos[(int64_t)ab.y * 3 + d] * wb;  // ref :286
-            msdf_aug[vid] = msdf[ab.x] * wa + msdf[ab.y] * wb;  // ref :289-290 (same value with/without stop-grad)
+                for (int d = 0; d < 3; ++d) verts_wt[(int64_t)vid * 3 + d] = pos[(int64_t)ab.y * 3 + d] * c + pos[(int64_t)ab.x * 3 + d] * omc;  // ref :484
+                msdf_aug[vid] = G.msdf_grid[mid];  // ref :486
+            } else {
+                float wa, wb;
+                sdf_weights(sdf[ab.x], sdf[ab.y], wa, wb);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) verts_wt[(int64_t)vid * 3 + d] = pos[(int64_t)ab.x * 3 + d] * wa + pos[(int64_t)ab.y * 3 + d] * wb;  // ref :286
+                msdf_aug[vid] = msdf[ab.x] * wa + msdf[ab.y] * wb;  // ref :289-290 (same value with/without stop-grad)
+            }
             vert_ab[2 * (int64_t)vid] = ab.x;
             vert_ab[2 * (int64_t)vid + 1] = ab.y;
         }
@@ -379,9 +415,13 @@ struct FillArgs {
     int32_t* faces_aug_i32;
     uint8_t* used_wt;
     int32_t* poly;
+    const int32_t* vert_ab;  // AUG only
+    float* bnd_w;            // AUG only: [3 M1 + 4 M2, 2] weights of the two loop corners
+    AugIn G;
 };
 
 // One thread per polygon (surface-crossing tet), dense.
+template <bool AUG>
 __global__ void __launch_bounds__(256) k_polys(FillArgs A) {
     const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (slot >= A.M1 + A.M2) return;
@@ -413,6 +453,31 @@ __global__ void __launch_bounds__(256) k_polys(FillArgs A) {
     const int used = ntri == 1 ? c_used_tri[ci] : c_used_quad[ci];
     for (int k = 0; k < n; ++k) {
         const int a = pc[k], bb = pc[(k + 1 == n) ? 0 : k + 1];
+        if (AUG) {
+            // canonical positions of the two mesh vertices are cell sums / 2 (ref :479); the occgrid
+            // cell is their mean * 2 truncated (ref :543-544) = (sum_a + sum_b) >> 1 in integers, and
+            // the coefficient applies to whichever end comes first in the canonical order (ref :556-577)
+            const int a0 = A.vert_ab[2 * (int64_t)a], a1 = A.vert_ab[2 * (int64_t)a + 1];
+            const int b0 = A.vert_ab[2 * (int64_t)bb], b1 = A.vert_ab[2 * (int64_t)bb + 1];
+            int64_t cell = 0;
+            int order = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int sa = A.G.vdisc[(int64_t)a0 * 3 + d] + A.G.vdisc[(int64_t)a1 * 3 + d];
+                const int sb = A.G.vdisc[(int64_t)b0 * 3 + d] + A.G.vdisc[(int64_t)b1 * 3 + d];
+                cell = cell * A.G.G2 + min(max((sa + sb) >> 1, 0), A.G.G2 - 1);
+                order += (sa > sb ? 1 : (sa < sb ? -1 : 0)) * (d == 0 ? 16 : (d == 1 ? 4 : 1));
+            }
+            const float c = A.G.occ[cell] * 0.5f + 0.5f, omc = 1.0f - c;  // ref :547, :551
+            const float wa = order > 0 ? c : omc, wb = order > 0 ? omc : c;
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                A.verts_aug[(bnd + k) * 3 + d] = A.verts_wt[(int64_t)a * 3 + d] * wa + A.verts_wt[(int64_t)bb * 3 + d] * wb;  // ref :584-585
+            A.msdf_aug[bnd + k] = 0.0f;  // ref :597-600
+            A.bnd_w[2 * (prow + k)] = wa;
+            A.bnd_w[2 * (prow + k) + 1] = wb;
+            continue;
+        }
         const float ma = A.msdf_aug[a], mb = A.msdf_aug[bb];
         float wa, wb;
         msdf_weights(ma, mb, wa, wb);
@@ -435,7 +500,7 @@ __global__ void __launch_bounds__(256) k_polys(FillArgs A) {
             int64_t idx;
             if (loc < n) {
                 idx = sel4(pc[0], pc[1], pc[2], pc[3], loc);
-                A.used_wt[idx] = 1;
+                if (!AUG) A.used_wt[idx] = 1;
             } else {
                 idx = bnd + (loc - n);
             }
@@ -620,7 +685,7 @@ __global__ void k_tng_verts(int64_t V, const float* __restrict__ acc, float* __r
 }
 
 __global__ void k_tng_boundary(int64_t V, int64_t M1, int64_t M2, const float* __restrict__ msdf_aug,
-                               const int32_t* __restrict__ poly, float* __restrict__ tng) {
+                               const int32_t* __restrict__ poly, const float* __restrict__ bnd_w, float* __restrict__ tng) {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= 3 * M1 + 4 * M2) return;
     int n, k;
@@ -629,7 +694,8 @@ __global__ void k_tng_boundary(int64_t V, int64_t M1, int64_t M2, const float* _
     else { int64_t q = j - 3 * M1; n = 4; p0 = 3 * M1 + (q / 4) * 4; k = (int)(q & 3); }
     const int a = poly[p0 + k], b = poly[p0 + ((k + 1 == n) ? 0 : k + 1)];
     float wa, wb;
-    msdf_weights(msdf_aug[a], msdf_aug[b], wa, wb);
+    if (bnd_w) { wa = bnd_w[2 * (p0 + k)]; wb = bnd_w[2 * (p0 + k) + 1]; }  // ref :588-589
+    else msdf_weights(msdf_aug[a], msdf_aug[b], wa, wb);
 #pragma unroll
     for (int d = 0; d < 3; ++d) tng[(V + j) * 3 + d] = tng[(int64_t)a * 3 + d] * wa + tng[(int64_t)b * 3 + d] * wb;
 }
@@ -639,11 +705,8 @@ __global__ void k_tng_boundary(int64_t V, int64_t M1, int64_t M2, const float* _
 // ====================================================================================
 // C ABI
 // ====================================================================================
-extern "C" int gs_mtets_count(gs_mtets_topo* t, const float* pos, const float* sdf, const float* msdf, gs_stream_t stream_,
-                              int64_t* counts_host) {
-    GS_REQUIRE(t && sdf && msdf && counts_host, "gs_mtets_count: null argument");
-    (void)pos;
-    hipStream_t stream = (hipStream_t)stream_;
+template <bool AUG>
+static int count_impl(gs_mtets_topo* t, const float* sdf, const float* msdf, const AugIn& G, hipStream_t stream, int64_t* counts_host) {
     if (t->F == 0 || t->N == 0) {
         for (int k = 0; k < GS_MTETS_NCOUNTS; ++k) counts_host[k] = t->last_counts[k] = 0;
         return 0;
@@ -651,7 +714,7 @@ extern "C" int gs_mtets_count(gs_mtets_topo* t, const float* pos, const float* s
     unsigned long long* cnt = (unsigned long long*)t->counts_dev;
     k_occ_bits<<<gs::cdiv(t->N, 256), 256, 0, stream>>>(sdf, t->N, t->occ_bits, cnt);
     k_edge_cross<<<t->nb_e, 256, 0, stream>>>((const int2*)t->edges, t->E, t->nchunks, t->occ_bits, t->edge_mask, t->edge_blk, cnt);
-    k_classify<<<t->nb_t, 256, 0, stream>>>((const int4*)t->tet, t->F, t->occ_bits, sdf, msdf, t->tet_code, t->tet_blk, cnt);
+    k_classify<AUG><<<t->nb_t, 256, 0, stream>>>((const int4*)t->tet, t->F, t->occ_bits, sdf, msdf, t->tet_code, t->tet_blk, cnt, G);
     GS_LAUNCH_CHECK();
     GS_HIP_CHECK(hipMemcpyAsync(t->counts_host, t->counts_dev, sizeof(int64_t) * GS_MTETS_NCOUNTS, hipMemcpyDeviceToHost, stream));
     GS_HIP_CHECK(hipStreamSynchronize(stream));
@@ -664,21 +727,35 @@ extern "C" int gs_mtets_count(gs_mtets_topo* t, const float* pos, const float* s
     return 0;
 }
 
-extern "C" int gs_mtets_fill(gs_mtets_topo* t, const float* pos, const float* sdf, const float* msdf, float* verts_aug,
-                             float* msdf_aug, float* verts_wt, int64_t* faces_wt, int64_t* faces_aug, int32_t* faces_aug_i32,
-                             int32_t* vert_ab, uint8_t* used_wt, int32_t* poly, uint8_t* cut_code, int32_t* tet_id,
-                             uint8_t* sign_code, int32_t* grp_rank, gs_stream_t stream_) {
-    GS_REQUIRE(t && pos && sdf && msdf, "gs_mtets_fill: null argument");
-    hipStream_t stream = (hipStream_t)stream_;
+extern "C" int gs_mtets_count(gs_mtets_topo* t, const float* pos, const float* sdf, const float* msdf, gs_stream_t stream_,
+                              int64_t* counts_host) {
+    GS_REQUIRE(t && sdf && msdf && counts_host, "gs_mtets_count: null argument");
+    (void)pos;
+    return count_impl<false>(t, sdf, msdf, AugIn{}, (hipStream_t)stream_, counts_host);
+}
+
+extern "C" int gs_mtets_aug_count(gs_mtets_topo* t, const float* sdf, const int32_t* vdisc, const float* msdf_sign_grid, int64_t G,
+                                  gs_stream_t stream_, int64_t* counts_host) {
+    GS_REQUIRE(t && sdf && vdisc && msdf_sign_grid && counts_host && G > 0, "gs_mtets_aug_count: null argument");
+    AugIn A{};
+    A.vdisc = vdisc; A.msdf_grid = msdf_sign_grid; A.G = (int)G;
+    return count_impl<true>(t, sdf, nullptr, A, (hipStream_t)stream_, counts_host);
+}
+
+template <bool AUG>
+static int fill_impl(gs_mtets_topo* t, const float* pos, const float* sdf, const float* msdf, const AugIn& G, float* verts_aug,
+                     float* msdf_aug, float* verts_wt, int64_t* faces_wt, int64_t* faces_aug, int32_t* faces_aug_i32,
+                     int32_t* vert_ab, uint8_t* used_wt, int32_t* poly, uint8_t* cut_code, int32_t* tet_id,
+                     uint8_t* sign_code, int32_t* grp_rank, float* bnd_w, hipStream_t stream) {
     const int64_t* c = t->last_counts;
     const int64_t V = c[0], M1 = c[1], M2 = c[2];
     if (V == 0) return 0;
-    GS_REQUIRE(verts_aug && msdf_aug && verts_wt && faces_wt && vert_ab && used_wt && poly && cut_code && tet_id,
+    GS_REQUIRE(verts_aug && msdf_aug && verts_wt && faces_wt && vert_ab && (AUG || used_wt) && poly && cut_code && tet_id,
                "gs_mtets_fill: null output");
     GS_REQUIRE(c[9] == 0 || faces_aug, "gs_mtets_fill: faces_aug is null");
-    GS_HIP_CHECK(hipMemsetAsync(used_wt, 0, (size_t)V, stream));
-    k_vertices<<<t->nb_e, 256, 0, stream>>>((const int2*)t->edges, t->nchunks, t->edge_mask, t->edge_blk, t->chunk_base, pos, sdf,
-                                            msdf, verts_wt, msdf_aug, vert_ab);
+    if (!AUG) GS_HIP_CHECK(hipMemsetAsync(used_wt, 0, (size_t)V, stream));
+    k_vertices<AUG><<<t->nb_e, 256, 0, stream>>>((const int2*)t->edges, t->nchunks, t->edge_mask, t->edge_blk, t->chunk_base, pos, sdf,
+                                                 msdf, verts_wt, msdf_aug, vert_ab, G);
     GS_REQUIRE(grp_rank && sign_code, "gs_mtets_fill: null scratch");
     k_compact<<<gs::cdiv(t->nb_t, MT_COMPACT_SPAN), 256, 0, stream>>>(t->tet_code, t->F, t->tet_blk, M1, tet_id, cut_code, sign_code, grp_rank);
     FillArgs A;
@@ -693,10 +770,34 @@ extern "C" int gs_mtets_fill(gs_mtets_topo* t, const float* pos, const float* sd
     A.tet_id = tet_id; A.cut_code = cut_code; A.sign_code = sign_code; A.grp_rank = grp_rank;
     A.verts_aug = verts_aug; A.msdf_aug = msdf_aug; A.faces_wt = faces_wt; A.faces_aug = faces_aug;
     A.faces_aug_i32 = faces_aug_i32; A.used_wt = used_wt; A.poly = poly;
-    if (M1 + M2 > 0) k_polys<<<gs::cdiv(M1 + M2, 256), 256, 0, stream>>>(A);
-    k_mask_wt<<<gs::cdiv(V * 3, 256), 256, 0, stream>>>(V, verts_wt, used_wt, verts_aug);
+    A.vert_ab = vert_ab; A.bnd_w = bnd_w; A.G = G;
+    if (M1 + M2 > 0) k_polys<AUG><<<gs::cdiv(M1 + M2, 256), 256, 0, stream>>>(A);
+    if (AUG) GS_HIP_CHECK(hipMemcpyAsync(verts_aug, verts_wt, sizeof(float) * 3 * (size_t)V, hipMemcpyDeviceToDevice, stream));  // no masking (ref :582-587)
+    else k_mask_wt<<<gs::cdiv(V * 3, 256), 256, 0, stream>>>(V, verts_wt, used_wt, verts_aug);
     GS_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gs_mtets_fill(gs_mtets_topo* t, const float* pos, const float* sdf, const float* msdf, float* verts_aug,
+                             float* msdf_aug, float* verts_wt, int64_t* faces_wt, int64_t* faces_aug, int32_t* faces_aug_i32,
+                             int32_t* vert_ab, uint8_t* used_wt, int32_t* poly, uint8_t* cut_code, int32_t* tet_id,
+                             uint8_t* sign_code, int32_t* grp_rank, gs_stream_t stream_) {
+    GS_REQUIRE(t && pos && sdf && msdf, "gs_mtets_fill: null argument");
+    return fill_impl<false>(t, pos, sdf, msdf, AugIn{}, verts_aug, msdf_aug, verts_wt, faces_wt, faces_aug, faces_aug_i32, vert_ab,
+                            used_wt, poly, cut_code, tet_id, sign_code, grp_rank, nullptr, (hipStream_t)stream_);
+}
+
+extern "C" int gs_mtets_aug_fill(gs_mtets_topo* t, const float* pos, const float* sdf, const int32_t* vdisc, const float* coeff_grid,
+                                 const float* msdf_sign_grid, int64_t G, const float* occgrid, int64_t G2, float* verts_aug,
+                                 float* msdf_aug, float* verts_wt, int64_t* faces_wt, int64_t* faces_aug, int32_t* faces_aug_i32,
+                                 int32_t* vert_ab, int32_t* poly, uint8_t* cut_code, int32_t* tet_id, uint8_t* sign_code,
+                                 int32_t* grp_rank, float* bnd_w, gs_stream_t stream_) {
+    GS_REQUIRE(t && pos && sdf && vdisc && coeff_grid && msdf_sign_grid && occgrid && G > 0 && G2 > 0, "gs_mtets_aug_fill: null argument");
+    GS_REQUIRE(t->last_counts[1] + t->last_counts[2] == 0 || bnd_w, "gs_mtets_aug_fill: bnd_w is null");
+    AugIn A{};
+    A.vdisc = vdisc; A.coeff = coeff_grid; A.msdf_grid = msdf_sign_grid; A.occ = occgrid; A.G = (int)G; A.G2 = (int)G2;
+    return fill_impl<true>(t, pos, sdf, nullptr, A, verts_aug, msdf_aug, verts_wt, faces_wt, faces_aug, faces_aug_i32, vert_ab,
+                           nullptr, poly, cut_code, tet_id, sign_code, grp_rank, bnd_w, (hipStream_t)stream_);
 }
 
 extern "C" int gs_mtets_bwd(int64_t N, int64_t V, int64_t M1, int64_t M2, const float* pos, const float* sdf, const float* msdf,
@@ -719,12 +820,11 @@ extern "C" int gs_mtets_bwd(int64_t N, int64_t V, int64_t M1, int64_t M2, const 
     return 0;
 }
 
-extern "C" int gs_mtets_tangents(int64_t V, int64_t M1, int64_t M2, int64_t F, const float* verts_wt, const int64_t* faces_wt,
-                                 const float* msdf_aug, const int32_t* poly, const float* lin, int64_t Nuv, float* scratch,
-                                 float* v_tng_aug, gs_stream_t stream_) {
-    (void)F;
+static int tangents_impl(int64_t V, int64_t M1, int64_t M2, const float* verts_wt, const int64_t* faces_wt, const float* msdf_aug,
+                         const float* bnd_w, const int32_t* poly, const float* lin, int64_t Nuv, float* scratch, float* v_tng_aug,
+                         gs_stream_t stream_) {
     if (V == 0) return 0;
-    GS_REQUIRE(verts_wt && faces_wt && msdf_aug && poly && lin && scratch && v_tng_aug, "gs_mtets_tangents: null argument");
+    GS_REQUIRE(verts_wt && faces_wt && (msdf_aug || bnd_w) && poly && lin && scratch && v_tng_aug, "gs_mtets_tangents: null argument");
     GS_REQUIRE(4 * Nuv * Nuv >= V, "gs_mtets_tangents: uv atlas smaller than the vertex count");
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t nf = M1 + 2 * M2, nb = 3 * M1 + 4 * M2;
@@ -732,7 +832,21 @@ extern "C" int gs_mtets_tangents(int64_t V, int64_t M1, int64_t M2, int64_t F, c
     GS_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float) * 7 * (size_t)V, stream));
     k_tng_faces<<<gs::cdiv(nf, 256), 256, 0, stream>>>(nf, verts_wt, faces_wt, lin, (int)Nuv, pad, scratch);
     k_tng_verts<<<gs::cdiv(V, 256), 256, 0, stream>>>(V, scratch, v_tng_aug);
-    if (nb > 0) k_tng_boundary<<<gs::cdiv(nb, 256), 256, 0, stream>>>(V, M1, M2, msdf_aug, poly, v_tng_aug);
+    if (nb > 0) k_tng_boundary<<<gs::cdiv(nb, 256), 256, 0, stream>>>(V, M1, M2, msdf_aug, poly, bnd_w, v_tng_aug);
     GS_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gs_mtets_tangents(int64_t V, int64_t M1, int64_t M2, int64_t F, const float* verts_wt, const int64_t* faces_wt,
+                                 const float* msdf_aug, const int32_t* poly, const float* lin, int64_t Nuv, float* scratch,
+                                 float* v_tng_aug, gs_stream_t stream_) {
+    (void)F;
+    return tangents_impl(V, M1, M2, verts_wt, faces_wt, msdf_aug, nullptr, poly, lin, Nuv, scratch, v_tng_aug, stream_);
+}
+
+extern "C" int gs_mtets_aug_tangents(int64_t V, int64_t M1, int64_t M2, const float* verts_wt, const int64_t* faces_wt,
+                                     const float* bnd_w, const int32_t* poly, const float* lin, int64_t Nuv, float* scratch,
+                                     float* v_tng_aug, gs_stream_t stream_) {
+    GS_REQUIRE(M1 + M2 == 0 || bnd_w, "gs_mtets_aug_tangents: bnd_w is null");
+    return tangents_impl(V, M1, M2, verts_wt, faces_wt, nullptr, bnd_w, poly, lin, Nuv, scratch, v_tng_aug, stream_);
 }

@@ -167,3 +167,72 @@ class GShell_Tets:
             'polygon_tet_id': tet_id,
         }
         return verts_aug, faces_aug, None, None, v_tng_aug, extra
+
+    @torch.no_grad()
+    def marching_from_auggrid(self, pos_nx3, sdf_n, tet_fx4, sorted_tet_edges_fx6x2, coeff_sdf_interp, verts_discretized,
+                              midpoint_msdf_sign_n, occgrid):
+        """Generative-decode extraction; same signature and 9-tuple as the reference
+        (gshell_tets.py:446-629):
+
+            (verts_aug, faces_aug, None, None, v_tng_aug, verts, valid_tet_gidx, msdf_vert_aug, msdf_vert)
+
+        `sorted_tet_edges_fx6x2` must be the per-tet (min,max) edges in the base order
+        01 02 03 12 13 23 -- the layout of the npz's 'tet_edges' -- because the static
+        topology of this implementation is derived from `tet_fx4` in that order; it is
+        checked once per grid.  Grids are cubic: coeff / msdf-sign [G,G,G], occgrid [G2,G2,G2]."""
+        L = _lib.lib()
+        dev = pos_nx3.device
+        topo = self.topology(tet_fx4, pos_nx3.shape[0])
+        if sorted_tet_edges_fx6x2 is not None and getattr(topo, "_edges_checked", None) != sorted_tet_edges_fx6x2.data_ptr():
+            t = tet_fx4.long()
+            a = t[:, [0, 0, 0, 1, 1, 2]]
+            b = t[:, [1, 2, 3, 2, 3, 3]]
+            want = torch.stack([torch.minimum(a, b), torch.maximum(a, b)], -1)
+            if not torch.equal(sorted_tet_edges_fx6x2.reshape(-1, 6, 2).long(), want):
+                raise _lib.GShellHipError("sorted_tet_edges_fx6x2 is not the (min,max) edge table of tet_fx4 in the order 01 02 03 12 13 23")
+            topo._edges_checked = sorted_tet_edges_fx6x2.data_ptr()
+        pos_c = pos_nx3.detach().contiguous().float()
+        sdf_c = sdf_n.detach().contiguous().float().reshape(-1)
+        vdisc = verts_discretized.detach().round().to(torch.int32).contiguous()
+        coeff = coeff_sdf_interp.detach().contiguous().float()
+        mgrid = midpoint_msdf_sign_n.detach().contiguous().float()
+        occ = occgrid.detach().contiguous().float()
+        G, G2 = int(coeff.shape[0]), int(occ.shape[0])
+        if coeff.dim() != 3 or tuple(coeff.shape) != (G, G, G) or tuple(mgrid.shape) != (G, G, G) or tuple(occ.shape) != (G2, G2, G2):
+            raise _lib.GShellHipError(f"cubic grids expected, got {tuple(coeff.shape)}, {tuple(mgrid.shape)}, {tuple(occ.shape)}")
+        if pos_c.shape[0] != topo.N or sdf_c.numel() != topo.N or tuple(vdisc.shape) != (topo.N, 3):
+            raise _lib.GShellHipError("field sizes do not match the grid")
+        if getattr(topo, "_vdisc_checked", None) != (verts_discretized.data_ptr(), G, G2):
+            lo, hi = int(vdisc.min()), int(vdisc.max())
+            if lo < 0 or hi >= G or 2 * hi >= G2:       # the reference would raise an index error here
+                raise IndexError(f"verts_discretized range [{lo},{hi}] does not fit grids of {G}^3 / {G2}^3 cells")
+            topo._vdisc_checked = (verts_discretized.data_ptr(), G, G2)
+        counts = (c_int64 * 16)()
+        with torch.cuda.device(dev):
+            check(L.gs_mtets_aug_count(topo.handle, ptr(sdf_c, torch.float32, "sdf"), ptr(vdisc, torch.int32, "verts_discretized"),
+                                       ptr(mgrid), c_int64(G), stream(), counts), "gs_mtets_aug_count")
+            V, M1, M2, T, V_aug = counts[0], counts[1], counts[2], counts[9], counts[10]
+            f32 = dict(dtype=torch.float32, device=dev)
+            verts_aug = torch.empty((V_aug, 3), **f32)
+            msdf_aug = torch.empty((V_aug,), **f32)
+            verts_wt = torch.empty((V, 3), **f32)
+            faces_wt = torch.empty((M1 + 2 * M2, 3), dtype=torch.int64, device=dev)
+            faces_aug = torch.empty((T, 3), dtype=torch.int64, device=dev)
+            vert_ab = torch.empty((V, 2), dtype=torch.int32, device=dev)
+            poly = torch.empty((3 * M1 + 4 * M2,), dtype=torch.int32, device=dev)
+            cut_code = torch.empty((M1 + M2,), dtype=torch.uint8, device=dev)
+            tet_id = torch.empty((M1 + M2,), dtype=torch.int32, device=dev)
+            sign_code = torch.empty((M1 + M2,), dtype=torch.uint8, device=dev)
+            grp_rank = torch.empty((M1 + M2,), dtype=torch.int32, device=dev)
+            bnd_w = torch.empty((3 * M1 + 4 * M2, 2), **f32)
+            check(L.gs_mtets_aug_fill(topo.handle, ptr(pos_c), ptr(sdf_c), ptr(vdisc), ptr(coeff), ptr(mgrid), c_int64(G), ptr(occ),
+                                      c_int64(G2), ptr(verts_aug), ptr(msdf_aug), ptr(verts_wt), ptr(faces_wt), ptr(faces_aug),
+                                      ptr(None), ptr(vert_ab), ptr(poly), ptr(cut_code), ptr(tet_id), ptr(sign_code), ptr(grp_rank),
+                                      ptr(bnd_w), stream()), "gs_mtets_aug_fill")
+            v_tng_aug = torch.zeros((V_aug, 3), **f32)
+            if self.compute_tangents and V > 0:
+                scratch = torch.empty((V, 7), **f32)
+                check(L.gs_mtets_aug_tangents(c_int64(V), c_int64(M1), c_int64(M2), ptr(verts_wt), ptr(faces_wt), ptr(bnd_w),
+                                              ptr(poly), ptr(topo.uv_lin), c_int64(topo.Nuv), ptr(scratch), ptr(v_tng_aug),
+                                              stream()), "gs_mtets_aug_tangents")
+        return verts_aug, faces_aug, None, None, v_tng_aug, verts_wt, tet_id.long(), msdf_aug, msdf_aug[:V]

@@ -63,8 +63,6 @@ def sample_points(v_pos, faces, n, generator=None):
 class GShellTetsGeometry(torch.nn.Module):
     def __init__(self, grid_res, scale, FLAGS, offset=None, tet_init_file=None, extract_from_generative=False, tet_grid=None):
         super().__init__()
-        if extract_from_generative:
-            raise NotImplementedError("the generative-decode path (marching_from_auggrid) is SURVEY 8(f) rank 2, not built yet")
         self.FLAGS, self.grid_res, self.scale = FLAGS, grid_res, scale
         self.gshell_tets = GShell_Tets(compute_tangents=False)       # tangents are dead on the training path (render.py:264-267)
         self.boxscale = torch.tensor(FLAGS.boxscale).view(1, 3).cuda()
@@ -79,6 +77,19 @@ class GShellTetsGeometry(torch.nn.Module):
             self.verts = (self.verts - self.verts.mean(dim=0)) * scale * self.boxscale
             self.indices = torch.as_tensor(indices).long().cuda()
             self.generate_edges()
+            if extract_from_generative:
+                # cells of the 2x denser cubic grid that stores per-edge features (reference :70-78); the on-disk
+                # 'tet_edges' table is re-derived from the indices (same (min,max) pairs, order 01 02 03 12 13 23)
+                raw = torch.as_tensor(verts, dtype=torch.float32).cuda()
+                self.original_verts = raw.clone()
+                uniq = raw.reshape(-1).unique()
+                dx = (uniq[1] - uniq[0]) / 2.0
+                self.verts_discretized = ((raw - raw.min()) / dx).round()   # lattice coordinates; round() guards 3.9999 -> 3
+                t = self.indices
+                a, b = t[:, [0, 0, 0, 1, 1, 2]], t[:, [1, 2, 3, 2, 3, 3]]
+                self.sorted_tetedges = torch.stack([torch.minimum(a, b), torch.maximum(a, b)], -1)
+            else:
+                self.original_verts = None
             self.offset = 0.0 if offset is None else torch.tensor(offset).cuda().view(1, 3)
 
         if self.FLAGS.use_sdf_mlp:
@@ -122,6 +133,27 @@ class GShellTetsGeometry(torch.nn.Module):
         if not self.FLAGS.use_tanh_deform:
             self.deform.data[:] = self.deform.clamp(-1.0, 1.0)
         self.msdf.data[:] = self.msdf.clamp(-2.0, 2.0)
+
+    def getMesh_from_augmented_grid_withocc(self, material, sdf_sign, sdf_coeff, msdf_sign, occgrid):
+        """Mesh of one generated cubic grid (reference :167-189; caller eval_gmeshdiffusion_generated_samples.py:180)."""
+        v_deformed = self.verts + self.max_displacement * self.deform
+        sdf = self.sdf_net(v_deformed) if self.FLAGS.use_sdf_mlp else self.sdf
+        verts, faces, uvs, uv_idx, v_tng, _v_wt, _tet_gidx, v_msdf, _m_wt = self.gshell_tets_full.marching_from_auggrid(
+            v_deformed, sdf_sign, self.indices, self.sorted_tetedges, sdf_coeff, self.verts_discretized, msdf_sign, occgrid)
+        imesh = mesh.Mesh(verts, faces, v_tex=uvs, t_tex_idx=uv_idx, material=material)
+        imesh = mesh.auto_normals(imesh)
+        imesh = mesh.compute_tangents(imesh, v_tng=v_tng)
+        return {'imesh': imesh, 'sdf': sdf, 'v_msdf': v_msdf}
+
+    @property
+    def gshell_tets_full(self):
+        """Extractor with tangents enabled (the decode path returns them); shares the static topology."""
+        ext = getattr(self, "_gshell_tets_full", None)
+        if ext is None:
+            ext = GShell_Tets(compute_tangents=True)
+            ext._topo_cache = self.gshell_tets._topo_cache
+            self._gshell_tets_full = ext
+        return ext
 
     def getMesh(self, material):
         v_deformed = self.verts + self.max_displacement * self.deform

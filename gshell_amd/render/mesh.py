@@ -2,6 +2,7 @@
 import torch
 
 from .. import _lib
+from . import util
 from .._lib import c_int64, check, ptr, stream
 
 
@@ -68,3 +69,15 @@ def auto_normals(imesh):
     """Area-weighted smooth vertex normals (ref render/mesh.py:212-237)."""
     v_nrm = _AutoNormalsFn.apply(imesh.v_pos, imesh.faces_i32())
     return Mesh(v_nrm=v_nrm, t_nrm_idx=imesh.t_pos_idx, base=imesh)
+
+
+def compute_tangents(imesh, v_tng=None):
+    """Tangent frame from precomputed per-vertex tangents: normalise, make orthogonal to the
+    smooth normal, normalise again (reference render/mesh.py:243-247).  The uv-derived branch
+    (:249-287) needs a texture atlas, which no call site on the hot path provides."""
+    if v_tng is None:
+        raise NotImplementedError("compute_tangents without v_tng needs uv coordinates (reference mesh.py:249-287); "
+                                  "the G-Shell paths always pass v_tng or run with use_uv=False")
+    v_tng = util.safe_normalize(v_tng)
+    v_tng = util.safe_normalize(v_tng - util.dot(v_tng, imesh.v_nrm) * imesh.v_nrm)
+    return Mesh(v_tng=v_tng, t_tng_idx=imesh.t_nrm_idx, base=imesh)

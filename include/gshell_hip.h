@@ -95,6 +95,33 @@ int gs_mtets_tangents(int64_t V, int64_t M1, int64_t M2, int64_t F, const float*
                       const float* lin, int64_t Nuv, float* scratch, float* v_tng_aug,
                       gs_stream_t stream);
 
+/* Generative-decode variant of the extraction (replaces GShell_Tets.marching_from_auggrid,
+ * geometry/gshell_tets.py:446-629; caller getMesh_from_augmented_grid_withocc,
+ * geometry/gshell_tets_geometry.py:167-189; no autograd in the reference either).
+ * The mesh topology, vertex numbering and face order are those of gs_mtets_count/fill;
+ * per-edge quantities come from cubic grids indexed at canonical edge midpoints:
+ *   sdf_n [N] f32 (only its sign is used), vdisc [N,3] i32 = 'verts_discretized',
+ *   coeff_grid [G,G,G] f32 = 'coeff_sdf_interp' (clamped to [0,1], ref :483),
+ *   msdf_sign_grid [G,G,G] f32 = 'midpoint_msdf_sign_n', occgrid [G2,G2,G2] f32.
+ * Same count -> allocate -> fill protocol and output layout as gs_mtets_fill, except:
+ * unreferenced vertices are NOT zeroed, msdf_aug is 0 on boundary vertices (ref :597-600),
+ * and bnd_w [3 M1 + 4 M2, 2] f32 receives the boundary weights (for gs_mtets_aug_tangents).
+ * tet_id [M1+M2] i32 doubles as the reference's 'valid_tet_gidx' (ref :507).             */
+int gs_mtets_aug_count(gs_mtets_topo* topo, const float* sdf_n, const int32_t* vdisc_nx3,
+                       const float* msdf_sign_grid, int64_t G, gs_stream_t stream,
+                       int64_t* counts_host);
+int gs_mtets_aug_fill(gs_mtets_topo* topo, const float* pos_nx3, const float* sdf_n,
+                      const int32_t* vdisc_nx3, const float* coeff_grid,
+                      const float* msdf_sign_grid, int64_t G, const float* occgrid, int64_t G2,
+                      float* verts_aug, float* msdf_aug, float* verts_wt, int64_t* faces_wt,
+                      int64_t* faces_aug, int32_t* faces_aug_i32, int32_t* vert_ab, int32_t* poly,
+                      uint8_t* cut_code, int32_t* tet_id, uint8_t* sign_code, int32_t* grp_rank,
+                      float* bnd_w, gs_stream_t stream);
+int gs_mtets_aug_tangents(int64_t V, int64_t M1, int64_t M2, const float* verts_wt,
+                          const int64_t* faces_wt, const float* bnd_w, const int32_t* poly,
+                          const float* lin, int64_t Nuv, float* scratch, float* v_tng_aug,
+                          gs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Vertex transform   (replaces ru.xfm_points, render/renderutils/ops.py:518-537;
  *                     CUDA kernels render/renderutils/c_src/mesh.cu:22-94)

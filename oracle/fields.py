@@ -72,3 +72,34 @@ def loss_weights(n_aug: int, n_wt: int, seed: int = 0):
     return (rng.standard_normal((n_aug, 3)).astype(np.float32),
             rng.standard_normal((n_aug,)).astype(np.float32),
             rng.standard_normal((n_wt, 3)).astype(np.float32))
+
+
+def discretize_verts(verts: np.ndarray) -> np.ndarray:
+    """Integer cells of the 2x denser cubic grid (reference gshell_tets_geometry.py:72-78,
+    GMeshDiffusion/metadata/save_tet_info.py:39-44): dx = half the smallest coordinate step."""
+    v = verts.astype(np.float32)
+    u = np.unique(v.reshape(-1))
+    dx = (u[1] - u[0]) / np.float32(2.0)
+    return np.floor((v - v.min()) / dx + np.float32(1e-3)).astype(np.int64)
+
+
+def make_aug_grids(G: int, seed: int, msdf_kind: str = "sign"):
+    """Seeded cubic-grid inputs of marching_from_auggrid: crossing coefficients [G^3]
+    (deliberately spilling outside [0,1] to exercise the clamp), mSDF sign grid [G^3]
+    and the boundary occupancy grid [(2G)^3] in [-1,1]."""
+    rng = np.random.RandomState(1000 + seed)
+    coeff = rng.uniform(-0.2, 1.2, size=(G, G, G)).astype(np.float32)
+    occ = rng.uniform(-1.0, 1.0, size=(2 * G, 2 * G, 2 * G)).astype(np.float32)
+    if msdf_kind == "sign":
+        m = np.sign(rng.uniform(-0.6, 1.0, size=(G, G, G))).astype(np.float32)
+        m[rng.uniform(size=(G, G, G)) < 0.02] = 0.0
+    elif msdf_kind == "halfspace":
+        z = np.linspace(-1, 1, G, dtype=np.float32)
+        m = np.sign(0.2 - z[None, :, None] + 0.3 * z[:, None, None] + 0 * z[None, None, :]).astype(np.float32)
+    elif msdf_kind == "positive":
+        m = np.ones((G, G, G), np.float32)
+    elif msdf_kind == "negative":
+        m = -np.ones((G, G, G), np.float32)
+    else:
+        raise ValueError(msdf_kind)
+    return coeff, m, occ

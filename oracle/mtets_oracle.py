@@ -205,3 +205,89 @@ def _tangents(verts, faces, tet1, tet2, F):
         return x / torch.sqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=1e-20))
     t = nz(t)
     return nz(t - (t * nrm).sum(-1, keepdim=True) * nrm)
+
+
+def extract_from_auggrid(pos, sdf, tets, verts_disc, coeff_grid, msdf_grid, occgrid, topo=None, with_tangents=True):
+    """Generative-decode extraction (ref gshell_tets.py:446-629, `marching_from_auggrid`).
+
+    Same topology / numbering as `extract`; per-edge quantities are looked up in cubic
+    grids at canonical edge midpoints.  `verts_disc` [N,3] holds integer cells (the
+    reference stores them as floats, gshell_tets_geometry.py:72-78).  No autograd.
+    Parity pin: tests/test_oracle_mtets.py against goldens minted from the real
+    reference by oracle/make_golden_auggrid.py."""
+    if topo is None:
+        topo = build_topology(tets)
+    edges, tet_edge = topo["edges"], topo["tet_edge"]
+    sdf = sdf.float().reshape(-1)
+    vd = verts_disc.float()
+    F = tets.shape[0]
+    occ = sdf > 0                                                   # ref :454
+    occ4 = occ[tets.reshape(-1)].reshape(F, 4).long()
+    code = occ4[:, 0] + 2 * occ4[:, 1] + 4 * occ4[:, 2] + 8 * occ4[:, 3]     # ref :459-460
+    ntri = torch.tensor([len(r) // 3 for r in TRI_TABLE])[code]
+    ea, eb = edges[:, 0], edges[:, 1]
+    cross = occ[ea] != occ[eb]                                      # ref :470
+    vid_of_edge = torch.cumsum(cross.long(), 0) - 1
+    vid_of_edge = torch.where(cross, vid_of_edge, torch.full_like(vid_of_edge, -1))
+    va, vb = ea[cross], eb[cross]
+    V = int(va.shape[0])
+    canon = (vd[va] + vd[vb]) / 2.0                                 # ref :478-479
+    mid = torch.stack([vd[va], vd[vb]], 1).mean(dim=1).long()       # ref :481
+    c = coeff_grid[mid[:, 0], mid[:, 1], mid[:, 2]].reshape(-1, 1).clamp(0, 1)      # ref :483
+    verts = pos[vb] * c + pos[va] * (1 - c)                         # ref :484
+    mv = msdf_grid[mid[:, 0], mid[:, 1], mid[:, 2]]                 # ref :486
+
+    tet1 = torch.nonzero(ntri == 1).reshape(-1)
+    tet2 = torch.nonzero(ntri == 2).reshape(-1)
+    M1, M2 = int(tet1.shape[0]), int(tet2.shape[0])
+    tri_t, poly_t = _pad(TRI_TABLE, 6), _pad(POLY_TABLE, 4)
+    vid1 = vid_of_edge[tet_edge[tet1]]
+    vid2 = vid_of_edge[tet_edge[tet2]]
+    faces_wt = torch.cat([
+        torch.gather(vid1, 1, tri_t[code[tet1]][:, :3]).reshape(-1, 3),
+        torch.gather(vid2, 1, tri_t[code[tet2]][:, :6]).reshape(-1, 3)], 0)   # ref :513-516
+    poly1 = torch.gather(vid1, 1, poly_t[code[tet1]][:, :3])        # ref :533-538
+    poly2 = torch.gather(vid2, 1, poly_t[code[tet2]][:, :4])
+    v_tng = _tangents(verts, faces_wt, tet1, tet2, F) if with_tangents else torch.zeros_like(verts)
+
+    def boundary(poly):
+        a, b = poly, torch.roll(poly, -1, dims=1)
+        m0, m1 = canon[a], canon[b]                                 # ref :539-540
+        loc = (torch.stack([m0, m1], 2).mean(dim=2) * 2.0).long()   # ref :543-544
+        cg = occgrid[loc[..., 0], loc[..., 1], loc[..., 2]] * 0.5 + 0.5          # ref :547-548
+        order = (torch.sign(m0 - m1) * torch.tensor([16.0, 4.0, 1.0])).sum(-1)     # ref :556-558
+        first = order > 0                                           # ref :559 (descending sort of [o,-o])
+        w_a = torch.where(first, cg, 1 - cg)
+        w_b = torch.where(first, 1 - cg, cg)
+        p = verts[a] * w_a[..., None] + verts[b] * w_b[..., None]   # ref :584-585
+        tg = v_tng[a] * w_a[..., None] + v_tng[b] * w_b[..., None]  # ref :591-592
+        return p.reshape(-1, 3), tg.reshape(-1, 3)
+
+    p1, t1 = boundary(poly1)
+    p2, t2 = boundary(poly2)
+    verts_aug = torch.cat([verts, p1, p2], 0)
+    v_tng_aug = torch.cat([v_tng, t1, t2], 0)
+    msdf_aug = torch.cat([mv, torch.zeros(verts_aug.shape[0] - V)], 0)        # ref :597-600
+
+    mocc1 = (mv[poly1] > 0).long()                                  # ref :540-541
+    mocc2 = (mv[poly2] > 0).long()
+    ci1 = mocc1[:, 0] * 4 + mocc1[:, 1] * 2 + mocc1[:, 2]           # ref :602-606
+    ci2 = mocc2[:, 0] * 8 + mocc2[:, 1] * 4 + mocc2[:, 2] * 2 + mocc2[:, 3]
+    loc1 = torch.cat([poly1, V + torch.arange(3 * M1).reshape(-1, 3)], 1)             # ref :608
+    loc2 = torch.cat([poly2, V + 3 * M1 + torch.arange(4 * M2).reshape(-1, 4)], 1)    # ref :609
+    cut1, cut2 = _pad(CUT_TRI, 6), _pad(CUT_QUAD, 12)
+    n1 = torch.tensor([len(r) // 3 for r in CUT_TRI])[ci1]
+    n2 = torch.tensor([len(r) // 3 for r in CUT_QUAD])[ci2]
+    groups = []
+    for k in (1, 2):                                                # ref :614-621
+        sel = n1 == k
+        groups.append(torch.gather(loc1[sel], 1, cut1[ci1[sel]][:, :3 * k]).reshape(-1, 3))
+    for k in (1, 2, 3, 4):
+        sel = n2 == k
+        groups.append(torch.gather(loc2[sel], 1, cut2[ci2[sel]][:, :3 * k]).reshape(-1, 3))
+    faces_aug = torch.cat(groups, 0)
+    return {
+        "verts_aug": verts_aug, "faces_aug": faces_aug, "v_tng_aug": v_tng_aug,
+        "vertices_watertight": verts, "faces_watertight": faces_wt,
+        "valid_tet_gidx": torch.cat([tet1, tet2], 0), "msdf": msdf_aug, "msdf_watertight": mv,
+    }

@@ -39,3 +39,20 @@ def test_oracle_matches_reference_golden(path):
             got = t.grad.numpy() if t.grad is not None else np.zeros_like(ref)
             scale = max(1.0, float(np.abs(ref).max()))
             np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * scale, err_msg=name)
+
+
+AUG_FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "auggrid_*.npz")))
+
+
+@pytest.mark.parametrize("path", AUG_FILES, ids=[os.path.basename(p)[8:-4] for p in AUG_FILES])
+def test_auggrid_oracle_matches_reference_golden(path):
+    from tests.helpers import auggrid_inputs
+    g = np.load(path)
+    pos, tets, sdf, vdisc, coeff, mgrid, occ = auggrid_inputs(g)
+    out = mtets_oracle.extract_from_auggrid(torch.tensor(pos), torch.tensor(sdf), torch.tensor(tets), torch.tensor(vdisc),
+                                            torch.tensor(coeff), torch.tensor(mgrid), torch.tensor(occ))
+    np.testing.assert_array_equal(out["faces_aug"].numpy(), g["faces_aug"])
+    np.testing.assert_array_equal(out["valid_tet_gidx"].numpy(), g["valid_tet_gidx"])
+    for k in ("verts_aug", "vertices_watertight", "msdf", "msdf_watertight"):
+        np.testing.assert_array_equal(out[k].numpy(), g[k], err_msg=k)
+    np.testing.assert_allclose(out["v_tng_aug"].numpy(), g["v_tng_aug"], rtol=0, atol=2e-5)

@@ -45,7 +45,8 @@ def _worker(rank, world, port, B, out_q):
     rep = torch.full((3,), float(rank + 1))
     shard.broadcast([rep])                                 # replicas start from rank 0's values
     assert rep.tolist() == [1.0, 1.0, 1.0]
-    out_q.put((rank, views, a.grad.clone(), b.grad.clone(), unused.grad.clone(), flags.clone()))
+    # plain lists: tensors would travel as shared-memory fds, which race with this process exiting
+    out_q.put((rank, views, a.grad.tolist(), b.grad.tolist(), unused.grad.tolist(), flags.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -70,9 +71,10 @@ def test_sharded_gradient_equals_single_process(B):
     (per_view + glob).backward()
     assert sorted(results[0][1] + results[1][1]) == list(range(B))               # every view rendered exactly once
     for rank, views, ga, gb, gu, flags in results:
+        ga, gb, gu = torch.tensor(ga), torch.tensor(gb), torch.tensor(gu)
         assert torch.allclose(ga, a.grad, rtol=1e-5, atol=1e-6) and torch.allclose(gb, b.grad, rtol=1e-5, atol=1e-6)
         assert (gu == 0).all()
-        assert flags.tolist() == [1, 1, 0, 1, 1, 0]
+        assert flags == [1, 1, 0, 1, 1, 0]
 
 
 def test_view_shard_single_process_is_identity():
