@@ -186,3 +186,58 @@ class Trainer:
             self.geometry.clamp_deform()
         self.it += 1
         return img_loss.detach(), reg_loss.detach()
+
+    # ---- checkpoint / resume (the reference saves geometry / material / light state_dicts, train script :700-720) -------
+    def state_dict(self):
+        return {
+            'it': self.it,
+            'geometry': self.geometry.state_dict(),        # keys: sdf, msdf, deform, sdf_net.* (same names as the reference module)
+            'material': self.mat['kd_ks'].state_dict(),
+            'light': self.lgt.base.detach().clone(),       # [H,W,3] probe texels (the reference stores an .hdr, light.py:118-123)
+            'opt': [o.state_dict() for o in (self.opt_mat, self.opt_mesh, self.opt_light)],
+            'sched': [s.state_dict() for s in self.scheds],
+        }
+
+    def load_state_dict(self, sd):
+        self.geometry.load_state_dict(sd['geometry'])
+        self.mat['kd_ks'].load_state_dict(sd['material'])
+        self.lgt.base.data.copy_(sd['light'])
+        for o, s in zip((self.opt_mat, self.opt_mesh, self.opt_light), sd['opt']):
+            o.load_state_dict(s)
+        for o, s in zip(self.scheds, sd['sched']):
+            o.load_state_dict(s)
+        self.it = int(sd['it'])
+        self.lgt.update_pdf()
+
+    def save_checkpoint(self, path):
+        if self.shard.rank == 0:
+            torch.save(self.state_dict(), path)
+
+    def load_checkpoint(self, path):
+        self.load_state_dict(torch.load(path, map_location=self.geometry.verts.device, weights_only=False))
+
+
+@torch.no_grad()
+def validate(trainer, targets, out_dir=None):
+    """Validation loop of the reference (train script :227-272): render each target view with the current state,
+    MSE / PSNR of the clamped sRGB image against the target, `metrics.txt` with `ID, MSE, PSNR` rows and the averages.
+    `targets` is an iterable of single-view target dicts (mvp, campos, resolution, spp, background, img)."""
+    from .render import util
+    rows = []
+    for it, target in enumerate(targets):
+        buf = trainer.geometry.render(trainer.glctx, target, trainer.lgt, trainer.mat, denoiser=trainer.denoiser)['buffers']
+        opt = util.rgb_to_srgb(buf['shaded'][..., 0:3]).clamp(0.0, 1.0)
+        ref = util.rgb_to_srgb(target['img'][..., 0:3]).clamp(0.0, 1.0)
+        mse = float(torch.nn.functional.mse_loss(opt, ref))
+        rows.append((it, mse, util.mse_to_psnr(max(mse, 1e-12))))
+    avg_mse = sum(r[1] for r in rows) / max(len(rows), 1)
+    avg_psnr = sum(r[2] for r in rows) / max(len(rows), 1)
+    if out_dir is not None and trainer.shard.rank == 0:
+        import os
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, 'metrics.txt'), 'w') as f:
+            f.write('ID, MSE, PSNR\n')
+            for r in rows:
+                f.write("%d, %1.8f, %1.8f\n" % r)
+            f.write("AVERAGES: %1.4f, %2.3f\n" % (avg_mse, avg_psnr))
+    return avg_psnr

@@ -64,7 +64,7 @@ def fit_sdf_net(geometry, steps=400, batch=65536, seed=0):
         opt.zero_grad()
         loss.backward()
         opt.step()
-    return float(loss.detach())
+    return float(loss.detach()) if steps > 0 else float('nan')
 
 
 def set_mid_training_state(geometry, seed=0):
