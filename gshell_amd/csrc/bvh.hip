@@ -164,6 +164,38 @@ __global__ void __launch_bounds__(256) k_level_up(int64_t first, int64_t count, 
     }
 }
 
+// largest half <= x / smallest half >= x, as bit patterns (boxes may only grow when they are narrowed to 16 bits)
+__device__ __forceinline__ uint16_t half_floor(float x) {
+    union { _Float16 h; uint16_t b; } c;
+    c.h = (_Float16)x;
+    if ((float)c.h > x) c.b = (c.b & 0x7fff) == 0 ? 0x8001 : ((c.b & 0x8000) ? c.b + 1 : c.b - 1);
+    return c.b;
+}
+__device__ __forceinline__ uint16_t half_ceil(float x) {
+    union { _Float16 h; uint16_t b; } c;
+    c.h = (_Float16)x;
+    if ((float)c.h < x) c.b = (c.b & 0x7fff) == 0 ? 0x0001 : ((c.b & 0x8000) ? c.b - 1 : c.b + 1);
+    return c.b;
+}
+
+// fp32 build records (24 floats) -> traversal records (24 halves in a 64-byte slot), one thread per node
+__global__ void __launch_bounds__(256) k_pack_nodes(int64_t n_internal, const float* __restrict__ groups, uint4* __restrict__ nodes) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_internal) return;
+    const float* g = groups + n * 24;
+    uint32_t w[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int h0 = 2 * i, h1 = 2 * i + 1;
+        const uint16_t a = h0 < 12 ? half_floor(g[h0]) : half_ceil(g[h0]);
+        const uint16_t b = h1 < 12 ? half_floor(g[h1]) : half_ceil(g[h1]);
+        w[i] = (uint32_t)a | ((uint32_t)b << 16);
+    }
+    nodes[4 * n] = make_uint4(w[0], w[1], w[2], w[3]);
+    nodes[4 * n + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+    nodes[4 * n + 2] = make_uint4(w[8], w[9], w[10], w[11]);
+}
+
 }  // namespace
 
 extern "C" int gs_bvh_create(gs_bvh** out) {
@@ -176,7 +208,7 @@ extern "C" int gs_bvh_create(gs_bvh** out) {
 
 extern "C" int gs_bvh_destroy(gs_bvh* b) {
     if (!b) return 0;
-    for (void* p : {(void*)b->groups, (void*)b->tris, (void*)b->tri_id, (void*)b->keys, (void*)b->keys2, (void*)b->vals, (void*)b->vals2,
+    for (void* p : {(void*)b->groups, (void*)b->nodes, (void*)b->tris, (void*)b->tri_id, (void*)b->keys, (void*)b->keys2, (void*)b->vals, (void*)b->vals2,
                     (void*)b->bounds, b->sort_tmp})
         (void)hipFree(p);
     delete b;
@@ -188,7 +220,7 @@ extern "C" int gs_bvh_info(const gs_bvh* b, int64_t* T, int64_t* depth, int64_t*
     if (T) *T = b->T;
     if (depth) *depth = b->depth;
     if (leaf_size) *leaf_size = b->leaf;
-    if (bytes) *bytes = b->n_internal * 96 + b->T * 48;
+    if (bytes) *bytes = b->n_internal * 64 + b->T * 48;   // what traversal reads
     return 0;
 }
 
@@ -204,6 +236,7 @@ extern "C" int gs_bvh_build(gs_bvh* b, const float* verts, int64_t V, const int3
     while ((1ll << (2 * depth)) * GS_BVH_LEAF < T) ++depth;
     int64_t slots = 1ll << (2 * depth);
     int leaf = (int)gs::cdiv(T, slots);
+    GS_REQUIRE(depth <= BVH_STACK && leaf <= 2, "gs_bvh_build: mesh too large for the traversal stack");
     b->depth = depth;
     b->leaf = leaf;
     b->n_leaf = gs::cdiv(T, leaf);
@@ -227,7 +260,9 @@ extern "C" int gs_bvh_build(gs_bvh* b, const float* verts, int64_t V, const int3
     if (b->n_internal > b->cap_internal) {
         GS_HIP_CHECK(hipStreamSynchronize(stream));
         (void)hipFree(b->groups);
+        (void)hipFree(b->nodes);
         GS_HIP_CHECK(hipMalloc(&b->groups, (size_t)b->n_internal * 96));
+        GS_HIP_CHECK(hipMalloc(&b->nodes, (size_t)b->n_internal * 64));
         b->cap_internal = b->n_internal;
     }
     hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, stream, b->bounds);
@@ -241,6 +276,8 @@ extern "C" int gs_bvh_build(gs_bvh* b, const float* verts, int64_t V, const int3
         int64_t count = 1ll << (2 * lvl), first = (count - 1) / 3;
         hipLaunchKernelGGL(k_level_up, dim3((unsigned)gs::cdiv(count, 256)), dim3(256), 0, stream, first, count, (float*)b->groups);
     }
+    hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)gs::cdiv(b->n_internal, 256)), dim3(256), 0, stream, b->n_internal, (const float*)b->groups,
+                       b->nodes);
     GS_LAUNCH_CHECK();
     return 0;
 }

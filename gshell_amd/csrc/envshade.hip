@@ -536,26 +536,98 @@ __global__ void __launch_bounds__(256) k_shade_samples(ShadeArgs A) {
     }
 }
 
-// Pass 2 (fwd): one lane per shadow ray; 64 consecutive rays share an origin (2S >= 64) or a few origins.
-// A lean kernel (traversal state only) so that 6-8 waves per SIMD hide the BVH fetch latency.
+// Pass 2 (fwd): shadow rays through the implicit 4-ary BVH of bvh.hpp.
+// Rays of one pixel scatter over the hemisphere, so lanes of a wave finish after very different numbers of steps
+// (measured: the longest lane runs 2.1x the mean).  Instead of one ray per lane for the life of the wave, every wave
+// owns a chunk of TRACE_CHUNK consecutive rays and lanes pull the next live ray whenever enough of them are idle:
+//   * 64 rays at a time are staged into LDS by the whole wave (coalesced), dead rays dropped on the way -- a sample whose
+//     unshadowed contribution is exactly zero (direction below the horizon of the shading normal: Lambert and the
+//     front-facing specular test both vanish) cannot reach the outputs or any gradient whatever V is: not traced;
+//   * idle lanes take staged rays by their rank in the idle mask (ballot + mbcnt, no atomics);
+//   * results are bits in LDS (all visible, cleared by an LDS atomic on a hit) copied out as 64-bit words at the end.
+constexpr int TRACE_CHUNK = 1024;  // rays per wave
+#ifndef TRACE_REFILL
+#define TRACE_REFILL 16               // refill when at least this many lanes are idle
+#endif
+
 __global__ void __launch_bounds__(256) k_shade_trace(ShadeArgs A, int64_t n_rays, int rays_per_pixel) {
     __shared__ int32_t stack[BVH_STACK * 256];
-    int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    bool visible = true;
-    if (r < n_rays) {
-        // a sample whose unshadowed contribution is exactly zero (direction below the horizon of the shading normal: Lambert
-        // and the front-facing specular test both vanish) cannot reach the outputs or any gradient whatever V is: not traced.
-        const float* rc = A.ray_contrib + 6 * r;
-        bool live = (rc[0] != 0.f) | (rc[1] != 0.f) | (rc[2] != 0.f) | (rc[3] != 0.f) | (rc[4] != 0.f) | (rc[5] != 0.f);
-        if (live) {
-            int64_t gid = A.pix[r / rays_per_pixel];
-            const float* o = A.ro + 3 * gid;
-            const float* d = A.ray_dir + 3 * r;
-            visible = !bvh_any_hit(A.bvh, o[0], o[1], o[2], d[0], d[1], d[2], stack, threadIdx.x, 256);
+    __shared__ float s_ray[4][6][64];
+    __shared__ int32_t s_id[4][64];
+    __shared__ uint32_t s_vis[4][TRACE_CHUNK / 32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t chunk0 = ((int64_t)blockIdx.x * 4 + wave) * TRACE_CHUNK;
+    if (chunk0 >= n_rays) return;
+    const int chunk_n = (int)min((int64_t)TRACE_CHUNK, n_rays - chunk0);
+    if (lane < TRACE_CHUNK / 32) s_vis[wave][lane] = 0xffffffffu;
+    int32_t* const st = stack + threadIdx.x;
+    int fetched = 0;               // rays of the chunk already staged (wave-uniform)
+    int staged = 0, taken = 0;     // live rays in the stage buffer / handed out so far (wave-uniform)
+    bool active = false;
+    int my = 0;
+    BvhRay ray;
+    const bool any_tris = A.bvh.T > 0;
+    for (;;) {
+        if (taken == staged && fetched < chunk_n) {
+            // stage the next 64 rays, live ones only (order preserved)
+            const int i = fetched + lane;
+            bool live = false;
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+            if (i < chunk_n && any_tris) {
+                const int64_t r = chunk0 + i;
+                const float* rc = A.ray_contrib + 6 * r;
+                live = (rc[0] != 0.f) | (rc[1] != 0.f) | (rc[2] != 0.f) | (rc[3] != 0.f) | (rc[4] != 0.f) | (rc[5] != 0.f);
+                if (live) {
+                    const int64_t gid = A.pix[r / rays_per_pixel];
+                    const float* o = A.ro + 3 * gid;
+                    const float* d = A.ray_dir + 3 * r;
+                    o0 = o[0]; o1 = o[1]; o2 = o[2]; d0 = d[0]; d1 = d[1]; d2 = d[2];
+                    live = (d0 == d0 && d1 == d1 && d2 == d2) && !(d0 == 0.f && d1 == 0.f && d2 == 0.f);
+                }
+            }
+            const uint64_t lm = __ballot(live);
+            if (live) {
+                const int slot = __popcll(lm & ((1ull << lane) - 1ull));
+                s_ray[wave][0][slot] = o0; s_ray[wave][1][slot] = o1; s_ray[wave][2][slot] = o2;
+                s_ray[wave][3][slot] = d0; s_ray[wave][4][slot] = d1; s_ray[wave][5][slot] = d2;
+                s_id[wave][slot] = i;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            fetched = min(fetched + 64, chunk_n);
+            staged = __popcll(lm);
+            taken = 0;
+            continue;
+        }
+        const uint64_t idle = __ballot(!active);
+        const int n_idle = __popcll(idle);
+        if (taken < staged && (n_idle >= TRACE_REFILL || n_idle == 64)) {
+            const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && rank < staged - taken) {
+                const int slot = taken + rank;
+                bvh_ray_init(ray, s_ray[wave][0][slot], s_ray[wave][1][slot], s_ray[wave][2][slot], s_ray[wave][3][slot], s_ray[wave][4][slot],
+                             s_ray[wave][5][slot]);
+                my = s_id[wave][slot];
+                active = true;
+            }
+            taken = min(taken + n_idle, staged);
+            __builtin_amdgcn_wave_barrier();
+        } else if (n_idle == 64) {
+            if (fetched >= chunk_n) break;   // nothing in flight, nothing staged, nothing left
+            continue;
+        }
+        if (active) {
+            const int state = bvh_step(A.bvh, ray, st, 256);
+            if (state != BVH_CONTINUE) {
+                if (state == BVH_HIT) atomicAnd(&s_vis[wave][my >> 5], ~(1u << (my & 31)));
+                active = false;
+            }
         }
     }
-    uint64_t bits = __ballot(visible);
-    if ((threadIdx.x & 63) == 0 && r < n_rays) A.vis_bits[r >> 6] = bits;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < TRACE_CHUNK / 64 && lane * 64 < chunk_n)
+        A.vis_bits[(chunk0 >> 6) + lane] = (uint64_t)s_vis[wave][2 * lane] | ((uint64_t)s_vis[wave][2 * lane + 1] << 32);
 }
 
 // Pass 3 (fwd): per-pixel sum of V * contribution
@@ -695,7 +767,7 @@ extern "C" int gs_env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n
     A.spec = spec;
     int64_t lanes = n_cov * A.G;
     hipLaunchKernelGGL(k_shade_samples<false>, dim3((unsigned)gs::cdiv(lanes, 256)), dim3(256), 0, stream, A);
-    hipLaunchKernelGGL(k_shade_trace, dim3((unsigned)gs::cdiv(n_rays, 256)), dim3(256), 0, stream, A, n_rays, (int)S2);
+    hipLaunchKernelGGL(k_shade_trace, dim3((unsigned)gs::cdiv(n_rays, 4 * TRACE_CHUNK)), dim3(256), 0, stream, A, n_rays, (int)S2);
     if (diff && spec) hipLaunchKernelGGL(k_shade_accumulate, dim3((unsigned)gs::cdiv(lanes, 256)), dim3(256), 0, stream, A);
     GS_LAUNCH_CHECK();
     return 0;
