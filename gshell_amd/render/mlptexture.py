@@ -52,6 +52,36 @@ class _ScaleGrad(torch.autograd.Function):
         return g * ctx.s, None
 
 
+class _TexMlpFn(torch.autograd.Function):
+    """sigmoid(W3 relu(W2 relu(W1 x))) * (hi - lo) + lo over the rows with mask > 0, one fused HIP kernel each way
+    (gshell_amd/csrc/texmlp.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, w1, w2, w3, lo, hi):
+        x_c = x.detach().contiguous().float()
+        m_c = None if mask is None else mask.detach().reshape(-1).contiguous().float()
+        ws = [t.detach().contiguous().float() for t in (w1, w2, w3, lo, hi)]
+        N, C = x_c.shape[0], ws[2].shape[0]
+        out = torch.empty((N, C), dtype=torch.float32, device=x_c.device)
+        with torch.cuda.device(x_c.device):
+            check(_lib.lib().gs_texmlp_fwd(ptr(x_c, torch.float32, "x"), ptr(m_c), c_int64(N), ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), c_int(C),
+                                           ptr(ws[3]), ptr(ws[4]), ptr(out), stream()), "gs_texmlp_fwd")
+        ctx.save_for_backward(x_c, m_c, *ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x_c, m_c, w1, w2, w3, lo, hi = ctx.saved_tensors
+        g = g_out.contiguous().float()
+        N, C = x_c.shape[0], w3.shape[0]
+        g_x = torch.empty_like(x_c) if ctx.needs_input_grad[0] else None
+        g_w1, g_w2, g_w3 = torch.zeros_like(w1), torch.zeros_like(w2), torch.zeros_like(w3)
+        with torch.cuda.device(g.device):
+            check(_lib.lib().gs_texmlp_bwd(ptr(x_c), ptr(m_c), c_int64(N), ptr(w1), ptr(w2), ptr(w3), c_int(C), ptr(lo), ptr(hi), ptr(g),
+                                           ptr(g_x), ptr(g_w1), ptr(g_w2), ptr(g_w3), stream()), "gs_texmlp_bwd")
+        return g_x, None, g_w1, g_w2, g_w3, None, None
+
+
 class HashGridEncoding(torch.nn.Module):
     """Stand-in for `tcnn.Encoding(3, {"otype": "HashGrid", ...})`: same config keys, `.params`,
     `.n_output_dims`; parameters are fp32 and initialised U(-1e-4, 1e-4) like tiny-cuda-nn."""
@@ -91,6 +121,18 @@ class _MLP(torch.nn.Module):
         # reference: full-backward hook scaling the gradient w.r.t. the MLP input by loss_scale (:31)
         return self.net(_ScaleGrad.apply(x.to(torch.float32), self.loss_scale))
 
+    def fusable(self, x):
+        lin = [m for m in self.net if isinstance(m, torch.nn.Linear)]
+        return (x.is_cuda and len(lin) == 3 and tuple(lin[0].weight.shape) == (32, 32) and tuple(lin[1].weight.shape) == (32, 32)
+                and lin[2].weight.shape[1] == 32 and lin[2].weight.shape[0] <= 8)
+
+    def forward_mapped(self, x, mask, lo, hi):
+        """sigmoid(net(x)) * (hi - lo) + lo; rows with mask <= 0 take the value of an all-zero feature row."""
+        if not self.fusable(x):
+            return torch.sigmoid(self.forward(x)) * (hi - lo)[None, :] + lo[None, :]
+        lin = [m for m in self.net if isinstance(m, torch.nn.Linear)]
+        return _TexMlpFn.apply(_ScaleGrad.apply(x.to(torch.float32), self.loss_scale), mask, lin[0].weight, lin[1].weight, lin[2].weight, lo, hi)
+
     @staticmethod
     def _init_weights(m):
         if type(m) == torch.nn.Linear:
@@ -119,8 +161,7 @@ class MLPTexture3D(torch.nn.Module):
         _texc = torch.clamp(_texc, min=0, max=1)
         # reference: encoder backward hook divides the gradient w.r.t. the encoder input by 128 (:74)
         p_enc = self.encoder(_ScaleGrad.apply(_texc.contiguous(), 1.0 / self.gradient_scaling), mask)
-        out = self.net.forward(p_enc)
-        out = torch.sigmoid(out) * (self.min_max[1][None, :] - self.min_max[0][None, :]) + self.min_max[0][None, :]
+        out = self.net.forward_mapped(p_enc, mask, self.min_max[0], self.min_max[1])
         return out.view(*texc.shape[:-1], self.channels)
 
     def clamp_(self):

@@ -327,6 +327,21 @@ int gs_hashgrid_bwd(int n_levels, int F, int log2_T, int base_res, float per_lev
                     const float* g_out, float* g_params, float* g_x_levels, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Texture-field MLP   (replaces the torch `_MLP` + sigmoid range mapping of MLPTexture3D.sample,
+ *   render/mlptexture.py:18-44, :87-99): out = sigmoid(W3 relu(W2 relu(W1 x))) * (hi - lo) + lo
+ *   x [N,32] f32 (hash-grid features), mask [N] f32 or NULL (rows with mask <= 0 get the value of an
+ *   all-zero feature row, 0.5 (hi - lo) + lo, and no gradient), w1, w2 [32,32], w3 [C,32] row-major
+ *   [out][in] (nn.Linear.weight), lo, hi [C], C <= 8, out [N,C].
+ *   bwd: g_x [N,32] WRITTEN (may be NULL); g_w1, g_w2, g_w3 ACCUMULATED (caller zero-fills; may be NULL).
+ * ---------------------------------------------------------------------------------- */
+int gs_texmlp_fwd(const float* x, const float* mask, int64_t N, const float* w1, const float* w2,
+                  const float* w3, int C, const float* lo, const float* hi, float* out,
+                  gs_stream_t stream);
+int gs_texmlp_bwd(const float* x, const float* mask, int64_t N, const float* w1, const float* w2,
+                  const float* w3, int C, const float* lo, const float* hi, const float* g_out,
+                  float* g_x, float* g_w1, float* g_w2, float* g_w3, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * SDF sign-consistency regulariser   (replaces compute_sdf_reg_loss,
  *   geometry/gshell_tets_geometry.py:33-39, evaluated over ALL grid edges every iteration :361-362)
  *   sdf [N] f32, edges [E,2] i32 (the static sorted edge list of gs_mtets_topo).

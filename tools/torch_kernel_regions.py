@@ -1,0 +1,98 @@
+"""Device time of the torch-issued (non gs_*) kernels of a training iteration, attributed to code regions:
+forward ops by the enclosing wrapped function, backward ops through the autograd sequence number of the forward op
+they differentiate.  Run on the GPU box:  python tools/torch_kernel_regions.py"""
+import collections
+import functools
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import ProfilerActivity, profile, record_function
+
+from gshell_amd import workload
+from gshell_amd.geometry import gshell_tets_geometry as G
+from gshell_amd.geometry import mlp as M
+from gshell_amd.render import light, mlptexture, regularizer, render, renderutils
+
+
+def wrap(mod, name, label=None):
+    fn = getattr(mod, name)
+    lab = "R:" + (label or name)
+
+    @functools.wraps(fn)
+    def inner(*a, **k):
+        with record_function(lab):
+            return fn(*a, **k)
+    setattr(mod, name, inner)
+
+
+for name in ("shade", "render_layer", "_sample_texture", "interpolate"):
+    wrap(render, name)
+for name in ("shading_loss", "material_smoothness_grad", "chroma_loss"):
+    wrap(regularizer, name)
+wrap(G, "compute_sdf_reg_loss")
+wrap(G, "sample_points")
+wrap(G.GShellTetsGeometry, "getMesh")
+wrap(G.GShellTetsGeometry, "render", "geometry.render")
+wrap(G.GShellTetsGeometry, "tick")
+wrap(M.MLP, "forward", "MLP.forward(torch)")
+wrap(mlptexture.MLPTexture3D, "sample", "MLPTexture3D.sample")
+wrap(light.EnvironmentLight, "update_pdf")
+wrap(torch.optim.Adam, "step", "Adam.step")
+wrap(renderutils, "image_loss")
+
+ITERS = 3
+tr = workload.build(res=256, n_samples=8, batch=4, train_res=(512, 512), fit_steps=200)
+tg = workload.make_targets(tr, [0, 1, 2, 3], (512, 512))
+for _ in range(3):
+    tr.step(tg)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    for _ in range(ITERS):
+        tr.step(tg)
+    torch.cuda.synchronize()
+
+evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU]
+
+
+def label_of(e):
+    labs = []
+    p = e
+    while p is not None:
+        if p.name.startswith("R:"):
+            labs.append(p.name[2:])
+        p = p.cpu_parent
+    return "/".join(reversed(labs)) if labs else None
+
+
+seq_label = {}
+for e in evs:
+    if e.sequence_nr is not None and e.sequence_nr >= 0 and not e.name.startswith("autograd::engine"):
+        lab = label_of(e)
+        if lab and e.sequence_nr not in seq_label:
+            seq_label[e.sequence_nr] = lab
+
+
+def bwd_label(e):
+    p = e
+    while p is not None:
+        if p.name.startswith("autograd::engine::evaluate_function"):
+            return "bwd of " + seq_label.get(p.sequence_nr, "<unlabelled> " + p.name.split(": ")[-1])
+        p = p.cpu_parent
+    return None
+
+
+agg = collections.defaultdict(lambda: [0.0, 0])
+tot = 0.0
+for e in evs:
+    dt = e.self_device_time_total or 0.0
+    if dt <= 0:
+        continue
+    lab = label_of(e) or bwd_label(e) or "<top level> " + e.name
+    agg[lab][0] += dt
+    agg[lab][1] += 1
+    tot += dt
+print(f"device time per iteration: {tot / ITERS / 1e3:.2f} ms")
+for k, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
+    print(f"{t / ITERS / 1e3:8.3f} ms {n / ITERS:7.1f} launches  {k}")
