@@ -84,6 +84,7 @@ def bwd_label(e):
 
 
 agg = collections.defaultdict(lambda: [0.0, 0])
+kern = collections.defaultdict(lambda: collections.defaultdict(float))
 tot = 0.0
 for e in evs:
     dt = e.self_device_time_total or 0.0
@@ -93,6 +94,11 @@ for e in evs:
     agg[lab][0] += dt
     agg[lab][1] += 1
     tot += dt
+    for k in getattr(e, "kernels", []):
+        kern[lab][k.name[:70]] += k.duration
 print(f"device time per iteration: {tot / ITERS / 1e3:.2f} ms")
-for k, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
+for k, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
     print(f"{t / ITERS / 1e3:8.3f} ms {n / ITERS:7.1f} launches  {k}")
+    if t / ITERS / 1e3 > 1.0:
+        for kn, kt in sorted(kern[k].items(), key=lambda kv: -kv[1])[:6]:
+            print(f"            {kt / ITERS / 1e3:8.3f} ms  {kn}")
