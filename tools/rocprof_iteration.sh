@@ -5,7 +5,7 @@ root="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 out="$root/gpurun_out/$tag"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-timeout 500 rocprofv3 --kernel-trace --stats -d "$out" -o r -- python "$root/bench.py" --no-cpu-baseline "$@" > "$out/run.log" 2>&1 </dev/null
-find "$out" -name "*kernel_trace.csv" -size +60M -delete      # keep the merge under gpurun's size cap
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o r -- python "$root/bench.py" --no-cpu-baseline "$@" > "$out/run.log" 2>&1 </dev/null
+find "$out" \( -name "*kernel_trace.csv" -o -name "*.db" -o -name "*.json" -o -name "*.pftrace" \) -delete   # only the stats summary is kept (traces exceed the merge cap)
 find "$out" -name "*_kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -45 {} | cut -c1-160'
 tail -1 "$out/run.log" | cut -c1-300
