@@ -102,7 +102,7 @@ def main():
         if a.op_times:
             out["op_ms"] = {k: round(v["ms"], 4) for k, v in sorted(op_times.items(), key=lambda kv: -kv[1]["ms"] * kv[1]["n"])}
             out["op_calls_per_step"] = {k: v["n"] / a.steps for k, v in op_times.items()}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # reported at N=1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:

@@ -202,6 +202,28 @@ def render_layer(FLAGS, v_pos_clip, rast, rast_deriv, mesh, view_pos, lgt, resol
     return buffers
 
 
+_layout_cache = {}
+
+
+def _composite_layout(sizes, dev):
+    """Per-channel constants of the stacked composite: index of the alpha channel of each channel's buffer, alpha mask."""
+    key = (sizes, str(dev))
+    lay = _layout_cache.get(key)
+    if lay is None:
+        alpha_of, is_alpha, o = [], [], 0
+        for c in sizes:
+            alpha_of += [o + c - 1] * c
+            is_alpha += [False] * (c - 1) + [True]
+            o += c
+        n = len(alpha_of)
+        pick = torch.zeros(n, n, dtype=torch.float32)
+        pick[torch.tensor(alpha_of), torch.arange(n)] = 1.0                              # column c selects the alpha channel of c's buffer
+        lay = {'pick_alpha': pick.to(dev), 'is_alpha': torch.tensor(is_alpha, dtype=torch.bool, device=dev),
+               'one': torch.ones((), dtype=torch.float32, device=dev)}
+        _layout_cache[key] = lay
+    return lay
+
+
 # ==============================================================================================
 #  render a mesh (single layer)
 # ==============================================================================================
@@ -233,18 +255,26 @@ def render_mesh(FLAGS, ctx, mesh, mtx_in, view_pos, lgt, resolution, spp=1, num_
     else:
         background = torch.zeros(1, full_res[0], full_res[1], 4, dtype=torch.float32, device=dev)
 
-    # composite every buffer over its background, then antialias all of them in one stacked launch
+    # composite every buffer over its background, then antialias all of them in one stacked launch.  The reference loops
+    # over the ~12 buffers (render.py:417-433: alpha, cat, lerp, antialias each); here the buffers are stacked once along
+    # the channel axis and composited with a handful of whole-stack ops: out = lerp(bg, [rgb.., 1], cover * alpha_of_group).
     cover = (rast[..., -1:] > 0).float()
-    keys, comps = [], []
-    for key, buf in buffers.items():
-        if buf is None:
-            continue
-        a = cover * buf[..., -1:]
-        fg = torch.cat((buf[..., :-1], torch.ones_like(buf[..., -1:])), dim=-1)
-        bg = background if key == 'shaded' else torch.zeros_like(fg)
-        comps.append(torch.lerp(bg.expand_as(fg) if bg.shape != fg.shape else bg, fg, a))
-        keys.append(key)
-    out_list = dr.antialias_stacked(comps, rast, v_pos_clip, tri) if len(comps) else []
+    keys = [k for k, b in buffers.items() if b is not None]
+    if keys:
+        sizes = [buffers[k].shape[-1] for k in keys]
+        layout = _composite_layout(tuple(sizes), dev)
+        stacked = torch.cat([buffers[k] for k in keys], dim=-1)                       # [B,H,W,sum C]
+        a = cover * torch.matmul(stacked, layout['pick_alpha'])                        # alpha of each channel's own buffer (0/1 matrix: exact,
+                                                                                       # and its backward is a dense product, not 47 M atomics)
+        fg = torch.where(layout['is_alpha'], layout['one'], stacked)                   # (rgb.., 1)
+        bg = torch.zeros((background.shape[0],) + tuple(stacked.shape[1:]), dtype=torch.float32, device=dev)
+        if 'shaded' in keys:
+            o = sum(sizes[:keys.index('shaded')])
+            bg[..., o:o + background.shape[-1]] = background
+        comp = torch.lerp(bg.expand_as(fg), fg, a)
+        out_list = list(torch.split(dr.antialias_stacked([comp], rast, v_pos_clip, tri)[0], sizes, dim=-1))
+    else:
+        out_list = []
 
     out_buffers = {'visible_triangles': visible_triangles}
     for key, accum in zip(keys, out_list):
