@@ -404,9 +404,11 @@ __device__ __forceinline__ void eval_sample(const ShadeArgs& A, const PixelCtx& 
     if (k == 0.f) return;
     v3 lg = (g_diff * d_ + g_spec * s_) * k;
     float* gl = A.g_light + ((int64_t)ly * A.probe.Wl + lx) * 3;
+#ifndef GS_EXPERIMENT_NO_LIGHT_GRAD
     if (lg.x != 0.f) atomicAdd(&gl[0], lg.x);
     if (lg.y != 0.f) atomicAdd(&gl[1], lg.y);
     if (lg.z != 0.f) atomicAdd(&gl[2], lg.z);
+#endif
     v3 dd = g_diff * light_col * k, ds = g_spec * light_col * k;
     v3 d_nrm = V3(0.f);
     if (A.bsdf == 0) {
