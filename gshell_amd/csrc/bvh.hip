@@ -11,8 +11,8 @@
 #include "common.hpp"
 
 #ifndef GS_BVH_LEAF
-#define GS_BVH_LEAF 2   // max triangles per leaf (measured on the res-256 mesh: leaf<=4 -> 25 triangle tests / ray, 0.42 Grays/s;
-                        // leaf<=2 -> 2.8 tests / ray, 0.76 Grays/s for 20 % more node visits)
+#define GS_BVH_LEAF 2   // max triangles per leaf (measured on the res-256 mesh with the first traversal: leaf<=4 -> 25 triangle
+                        // tests / ray, leaf<=2 -> 2.8 tests / ray for 20 % more node visits); the traversal stack encodes <= 2
 #endif
 
 namespace {

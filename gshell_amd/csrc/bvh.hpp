@@ -10,13 +10,14 @@
 //              parent pointers; the whole rebuild is a handful of launches per iteration.
 //   * layout = per internal node ONE 64-byte-aligned record holding its 4 child boxes in SoA form as
 //              24 half floats (lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4], lo rounded down / hi rounded
-//              up, so the boxes only grow) -> 3 dwordx4 loads inside one cache line per visit.  Traversal is
-//              bound by the texture-addresser rate of divergent loads (every lane visits a different node:
-//              one cache-line lookup per lane per load), so halving the loads is worth ~2x; measured
-//              32 nodes/ray on the bench mesh.  Triangles are stored pre-gathered in sorted order as
-//              (v0, e1, e2) = 3 x float4 and tested in full fp32, so hits are unchanged by the rounding.
-//   * traverse = per-lane short stack in LDS (stack[entry][lane], conflict-free), children tested
-//              4 at a time, leaves intersected immediately (Moeller-Trumbore, t > 0).
+//              up, so the boxes only grow): 48 bytes = the size of a triangle record, so a traversal step
+//              fetches node or triangle with the same three dwordx4 loads.  Triangles are stored pre-gathered
+//              in sorted order as (v0, e1, e2) = 3 x float4 and tested in full fp32: hits are unchanged by the
+//              rounding.  Measured on the bench mesh: 32 node + 2 triangle visits per ray.
+//   * traverse = see BvhRay below: one record per step, branch-free slab test of the 4 children, pending work
+//              kept as (node, child mask) with one 32-bit word per tree level in LDS.  What limited the first
+//              version was occupancy (a 32-entry LDS stack = 32 KB per block), not bytes: narrowing the nodes
+//              alone changed nothing, the 12-word stack took the stand-alone any-hit from 1.7 to 4.3 G rays/s.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>

@@ -13,8 +13,8 @@
 //     (sample i consumes draws 2+5i .. 6+5i), so results do not depend on the lane mapping.
 //   * the work is split "wavefront" style into three launches so that the ray traversal runs in a lean kernel:
 //       k_shade_samples<false>  sampling + BSDF/light/MIS evaluation -> ray directions + unshadowed contributions
-//       k_shade_trace           one lane per shadow ray through the implicit 4-ary BVH of bvh.hpp (LDS stack),
-//                               64 visibility bits per wave by ballot
+//       k_shade_trace           shadow rays through the implicit 4-ary BVH of bvh.hpp: every wave owns 1024 rays and
+//                               refills idle lanes from an LDS stage; 1 visibility bit per ray
 //       k_shade_accumulate      per-pixel sum of V * contribution
 //     (a single fused kernel needed 200-244 VGPRs = 2 waves/SIMD and ran the traversal latency-starved).
 //   * visibility is CACHED: 1 bit per ray (2.5 MB for 20 M rays).  The backward pass re-runs the identical sampling
