@@ -237,6 +237,116 @@ __global__ void __launch_bounds__(256) k_image_loss_bwd(const float* __restrict_
     if (g_target) g_target[i] = tonemap_bwd(y, tm, db);
 }
 
+// ---- whole-frame loss / regulariser sums --------------------------------------------------------------
+// One pass over the stacked, antialiased frame buffers [B*H*W, C] (render.render_mesh keeps every buffer as a channel
+// slice of ONE tensor) producing the nine pixel sums behind the alpha MSE, the two mSDF image terms
+// (gshell_tets_geometry.py:280-285 of the reference), the monochrome-lighting prior (regularizer.py:34-41) and the
+// material / normal smoothness terms (regularizer.py:21-31).  As torch ops these are ~230 launches over 1 M pixels.
+// The scalar combination (means, the specular / diffuse ratio, lambdas) stays in torch on the nine numbers.
+enum { FS_ALPHA = 0, FS_MSDF0, FS_MSDF1, FS_ERR, FS_SPEC, FS_DIFF, FS_KD, FS_KS, FS_NRM, FS_COUNT };
+
+struct FrameOffs {   // channel offset of each buffer inside a pixel record, -1 = absent
+    int shaded, msdf, diff, spec, kdg, ksg, nrmg;
+};
+
+// regularizer._log_srgb with torch's gradient conventions (closed clamp interval, 12.92 slope at and below the knee)
+__device__ __forceinline__ float fl_logsrgb(float x, float* grad) {
+    const float c = fminf(fmaxf(x, 0.0f), 65535.0f);
+    const float L = logf(c + 1.0f);
+    float f, gs;
+    if (L <= 0.0031308f) {
+        f = L * 12.92f;
+        gs = 12.92f;
+    } else {
+        const float b = fmaxf(L, 0.0031308f);
+        f = powf(b, 1.0f / 2.4f) * 1.055f - 0.055f;
+        gs = (1.055f / 2.4f) * powf(b, 1.0f / 2.4f - 1.0f);
+    }
+    if (grad) *grad = (x >= 0.0f && x <= 65535.0f) ? gs / (c + 1.0f) : 0.0f;
+    return f;
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_frame_sums(const float* __restrict__ st, const float* __restrict__ ref, int64_t n, int C, FrameOffs o,
+                                                    float* __restrict__ partial, const float* __restrict__ g9, float* __restrict__ g_st) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float acc[FS_COUNT];
+#pragma unroll
+    for (int k = 0; k < FS_COUNT; ++k) acc[k] = 0.0f;
+    if (i < n) {
+        const float* p = st + i * C;
+        float* g = BWD ? g_st + i * C : nullptr;
+        if (BWD)
+            for (int c = 0; c < C; ++c) g[c] = 0.0f;
+        const float m = ref[4 * i + 3];
+        if (o.shaded >= 0) {
+            const float a = p[o.shaded + 3];
+            acc[FS_ALPHA] = (a - m) * (a - m);
+            if (BWD) g[o.shaded + 3] = g9[FS_ALPHA] * 2.0f * (a - m);
+        }
+        if (o.msdf >= 0) {
+            const float x = p[o.msdf];
+            const float k0 = m == 0.0f ? 1.0f : 0.0f, k1 = m == 1.0f ? 1.0f : 0.0f;
+            acc[FS_MSDF0] = fabsf(fmaxf(x, 0.0f) * k0);                      // | clamp(x, min=0) * [m == 0] - 0 |
+            acc[FS_MSDF1] = fabsf(fminf(x, 0.0f) * k1 - 1.0f);               // | clamp(x, max=0) * [m == 1] - 1 |
+            if (BWD) g[o.msdf] = g9[FS_MSDF0] * (x > 0.0f ? k0 : 0.0f) - g9[FS_MSDF1] * (x <= 0.0f ? k1 : 0.0f);
+        }
+        if (o.diff >= 0 && o.spec >= 0) {
+            const float dl = (p[o.diff] + p[o.diff + 1] + p[o.diff + 2]) / 3.0f;
+            const float sl = (p[o.spec] + p[o.spec + 1] + p[o.spec + 2]) / 3.0f;
+            const float v = fmaxf(fmaxf(ref[4 * i], ref[4 * i + 1]), ref[4 * i + 2]);
+            float gx;
+            const float t1 = fl_logsrgb((dl + sl) * m, &gx), t2 = fl_logsrgb(v * m, nullptr);
+            acc[FS_ERR] = fabsf(t1 - t2);
+            acc[FS_SPEC] = sl;
+            acc[FS_DIFF] = dl;
+            if (BWD) {
+                const float ge = g9[FS_ERR] * sgnf(t1 - t2) * gx * m;
+                const float gd = (ge + g9[FS_DIFF]) / 3.0f, gs = (ge + g9[FS_SPEC]) / 3.0f;
+                g[o.diff] = gd; g[o.diff + 1] = gd; g[o.diff + 2] = gd;
+                g[o.spec] = gs; g[o.spec + 1] = gs; g[o.spec + 2] = gs;
+            }
+        }
+        if (o.kdg >= 0) {
+            const float s3 = (p[o.kdg] + p[o.kdg + 1] + p[o.kdg + 2]) / 3.0f, w = p[o.kdg + 3];
+            acc[FS_KD] = s3 * w;
+            if (BWD) {
+                const float gk = g9[FS_KD] * w / 3.0f;
+                g[o.kdg] = gk; g[o.kdg + 1] = gk; g[o.kdg + 2] = gk;
+                g[o.kdg + 3] = g9[FS_KD] * s3;
+            }
+        }
+        if (o.ksg >= 0) {
+            const float s3 = p[o.ksg] + p[o.ksg + 1] + p[o.ksg + 2], w = p[o.ksg + 3];
+            acc[FS_KS] = s3 * w;
+            if (BWD) {
+                const float gk = g9[FS_KS] * w;
+                g[o.ksg] = gk; g[o.ksg + 1] = gk; g[o.ksg + 2] = gk;
+                g[o.ksg + 3] = g9[FS_KS] * s3;
+            }
+        }
+        if (o.nrmg >= 0) {
+            const float s3 = p[o.nrmg] + p[o.nrmg + 1] + p[o.nrmg + 2], w = p[o.nrmg + 3];
+            acc[FS_NRM] = s3 * w;
+            if (BWD) {
+                const float gk = g9[FS_NRM] * w;
+                g[o.nrmg] = gk; g[o.nrmg + 1] = gk; g[o.nrmg + 2] = gk;
+                g[o.nrmg + 3] = g9[FS_NRM] * s3;
+            }
+        }
+    }
+    if (BWD) return;
+    __shared__ float ws[4][FS_COUNT];
+#pragma unroll
+    for (int k = 0; k < FS_COUNT; ++k) {
+        float v = acc[k];
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+        if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < FS_COUNT) partial[(int64_t)blockIdx.x * FS_COUNT + threadIdx.x] = (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]);
+}
+
 // ---- auto normals -----------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_face_normals_scatter(const float* __restrict__ v, const int32_t* __restrict__ tri, int64_t T,
                                                               float* __restrict__ acc) {
@@ -391,6 +501,32 @@ extern "C" int gs_image_loss_bwd(const float* img, const float* target, int64_t 
     GS_REQUIRE(img && target && g_scalar_dev, "gs_image_loss_bwd: null pointer");
     hipLaunchKernelGGL(k_image_loss_bwd, dim3((unsigned)gs::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, img, target, n, loss, tonemapper,
                        g_scalar_dev, scale, g_img, g_target);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t gs_frame_sums_partials(int64_t n_pixels) { return gs::cdiv(n_pixels, 256); }
+
+static FrameOffs frame_offs(const int32_t* offs) { return FrameOffs{offs[0], offs[1], offs[2], offs[3], offs[4], offs[5], offs[6]}; }
+
+extern "C" int gs_frame_sums_fwd(const float* stacked, const float* color_ref, int64_t n_pixels, int64_t C, const int32_t* offs_host,
+                                 float* partials, gs_stream_t stream) {
+    if (n_pixels == 0) return 0;
+    GS_REQUIRE(stacked && color_ref && offs_host && partials && C > 0, "gs_frame_sums_fwd: null pointer");
+    for (int k = 0; k < 7; ++k) GS_REQUIRE(offs_host[k] < 0 || offs_host[k] + (k == 1 ? 1 : 4) <= C, "gs_frame_sums_fwd: channel offset out of range");
+    hipLaunchKernelGGL(k_frame_sums<false>, dim3((unsigned)gs::cdiv(n_pixels, 256)), dim3(256), 0, (hipStream_t)stream, stacked, color_ref, n_pixels,
+                       (int)C, frame_offs(offs_host), partials, (const float*)nullptr, (float*)nullptr);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_frame_sums_bwd(const float* stacked, const float* color_ref, int64_t n_pixels, int64_t C, const int32_t* offs_host,
+                                 const float* g_sums_dev, float* g_stacked, gs_stream_t stream) {
+    if (n_pixels == 0) return 0;
+    GS_REQUIRE(stacked && color_ref && offs_host && g_sums_dev && g_stacked && C > 0, "gs_frame_sums_bwd: null pointer");
+    for (int k = 0; k < 7; ++k) GS_REQUIRE(offs_host[k] < 0 || offs_host[k] + (k == 1 ? 1 : 4) <= C, "gs_frame_sums_bwd: channel offset out of range");
+    hipLaunchKernelGGL(k_frame_sums<true>, dim3((unsigned)gs::cdiv(n_pixels, 256)), dim3(256), 0, (hipStream_t)stream, stacked, color_ref, n_pixels,
+                       (int)C, frame_offs(offs_host), (float*)nullptr, g_sums_dev, g_stacked);
     GS_LAUNCH_CHECK();
     return 0;
 }

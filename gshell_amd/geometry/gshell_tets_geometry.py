@@ -204,11 +204,21 @@ class GShellTetsGeometry(torch.nn.Module):
         # ---- image losses (reference :275-285)
         color_ref = target['img']
         gt_mask = color_ref[..., 3:]
-        img_loss = F.mse_loss(buffers['shaded'][..., 3:], gt_mask)
+        # pixel sums of the alpha MSE, the mSDF image terms and the image-space regularisers in one fused pass
+        stacked = getattr(buffers, 'stacked', None)
+        fs = regularizer.frame_sums(stacked, color_ref) if (stacked is not None and getattr(FL, "fused_frame_sums", True)) else None
+        n_px = float(gt_mask.numel())
+        if fs is not None:
+            img_loss = fs[0] / n_px
+        else:
+            img_loss = F.mse_loss(buffers['shaded'][..., 3:], gt_mask)
         img_loss = img_loss + loss_fn(buffers['shaded'][..., 0:3] * gt_mask, color_ref[..., 0:3] * gt_mask)
-        msdf_img = buffers['msdf_image']
-        img_loss = img_loss + 5e-1 * F.l1_loss(msdf_img.clamp(min=0) * (gt_mask == 0).float(), torch.zeros_like(gt_mask))
-        img_loss = img_loss + 5e-1 * F.l1_loss(msdf_img.clamp(max=0) * (gt_mask == 1).float(), torch.ones_like(gt_mask))
+        if fs is not None and 'msdf_image' in buffers:
+            img_loss = img_loss + 5e-1 * (fs[1] + fs[2]) / n_px
+        else:
+            msdf_img = buffers['msdf_image']
+            img_loss = img_loss + 5e-1 * F.l1_loss(msdf_img.clamp(min=0) * (gt_mask == 0).float(), torch.zeros_like(gt_mask))
+            img_loss = img_loss + 5e-1 * F.l1_loss(msdf_img.clamp(max=0) * (gt_mask == 1).float(), torch.ones_like(gt_mask))
         depth_loss = torch.zeros((), device=dev)         # use_depth is off in every reference config
 
         # ---- eikonal on the SDF network at surface samples (reference :302-324): double backward stays in torch
@@ -257,12 +267,17 @@ class GShellTetsGeometry(torch.nn.Module):
 
         if 'diffuse_light' not in buffers:
             monochrome = torch.zeros_like(img_loss)
+        elif fs is not None and 'specular_light' in buffers:
+            monochrome = fs[3] / n_px * FL.lambda_diffuse + (fs[4] / n_px) / (fs[5] / n_px).clamp_min(1e-3) * FL.lambda_specular
         else:
             monochrome = regularizer.shading_loss(buffers['diffuse_light'], buffers['specular_light'], color_ref, FL.lambda_diffuse,
                                                   FL.lambda_specular)
-        mtl_smooth = regularizer.material_smoothness_grad(buffers['kd_grad'], buffers['ks_grad'], buffers['normal_grad'], lambda_kd=FL.lambda_kd,
-                                                          lambda_ks=FL.lambda_ks, lambda_nrm=FL.lambda_nrm)
-        chroma = regularizer.chroma_loss(buffers['kd'], color_ref, FL.lambda_chroma)
+        if fs is not None:
+            mtl_smooth = fs[6] / n_px * FL.lambda_kd + fs[7] / (3 * n_px) * FL.lambda_ks + fs[8] / (3 * n_px) * FL.lambda_nrm
+        else:
+            mtl_smooth = regularizer.material_smoothness_grad(buffers['kd_grad'], buffers['ks_grad'], buffers['normal_grad'], lambda_kd=FL.lambda_kd,
+                                                              lambda_ks=FL.lambda_ks, lambda_nrm=FL.lambda_nrm)
+        chroma = regularizer.chroma_loss(buffers['kd'], color_ref, FL.lambda_chroma) if FL.lambda_chroma != 0 else torch.zeros_like(img_loss)
         reg_loss = (sdf_reg + eik_loss + msdf_reg) + (monochrome + mtl_smooth + chroma)
         # decomposition for view-sharded training: per-view means vs. terms that do not depend on the local views
         self.last_terms = {'per_view': img_loss + monochrome + mtl_smooth + chroma, 'global': sdf_reg + eik_loss + msdf_reg}

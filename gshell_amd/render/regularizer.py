@@ -1,8 +1,59 @@
 """Image-space regularisers of the G-Shell loss (semantics of the reference's render/regularizer.py:17-51).
-Inputs are the composited buffers [B,H,W,C]; everything is elementwise + a mean, so it stays torch."""
+Inputs are the composited buffers [B,H,W,C].  The functions below are the term-by-term torch formulation (also the
+reference the fused path is tested against); `frame_sums` evaluates the pixel sums of all of them -- plus the alpha MSE and
+the two mSDF image terms of the training loss -- in ONE pass over the stacked frame (gs_frame_sums_fwd/bwd)."""
+import ctypes
+
 import torch
 
+from .. import _lib
+from .._lib import c_int64, check, ptr, stream
 from . import util
+
+FRAME_SUM_BUFFERS = ('shaded', 'msdf_image', 'diffuse_light', 'specular_light', 'kd_grad', 'ks_grad', 'normal_grad')
+
+
+class _FrameSumsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, stacked, color_ref, offs):
+        st, ref = stacked.detach().contiguous().float(), color_ref.detach().contiguous().float()
+        C = st.shape[-1]
+        n = st.numel() // C
+        if ref.shape[-1] != 4 or ref.numel() != 4 * n:
+            raise _lib.GShellHipError(f"frame_sums: color_ref {tuple(ref.shape)} does not match the frame {tuple(st.shape)}")
+        c_offs = (ctypes.c_int32 * 7)(*offs)
+        L = _lib.lib()
+        partial = torch.empty((int(L.gs_frame_sums_partials(c_int64(n))), 9), dtype=torch.float32, device=st.device)
+        with torch.cuda.device(st.device):
+            check(L.gs_frame_sums_fwd(ptr(st, torch.float32, "stacked"), ptr(ref, torch.float32, "color_ref"), c_int64(n), c_int64(C), c_offs,
+                                      ptr(partial), stream()), "gs_frame_sums_fwd")
+        ctx.save_for_backward(st, ref)
+        ctx.offs = tuple(offs)
+        return partial.sum(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        st, ref = ctx.saved_tensors
+        C = st.shape[-1]
+        n = st.numel() // C
+        g9 = g.contiguous().float()
+        g_st = torch.empty_like(st)
+        c_offs = (ctypes.c_int32 * 7)(*ctx.offs)
+        with torch.cuda.device(st.device):
+            check(_lib.lib().gs_frame_sums_bwd(ptr(st), ptr(ref), c_int64(n), c_int64(C), c_offs, ptr(g9), ptr(g_st), stream()), "gs_frame_sums_bwd")
+        return g_st, None, None
+
+
+def frame_sums(stacked_info, color_ref):
+    """stacked_info = (tensor [B,H,W,C], buffer names, channel counts) = render_mesh(...).stacked.
+    Returns a [9] tensor: sum (a-m)^2, sum |msdf+[m=0]|, sum |msdf-[m=1]-1|, sum |logsrgb((d+s)m) - logsrgb(value(ref)m)|,
+    sum luma(spec), sum luma(diff), sum kd_grad term, sum ks_grad term, sum normal_grad term  (m = reference alpha)."""
+    stacked, keys, sizes = stacked_info
+    offs = []
+    for name in FRAME_SUM_BUFFERS:
+        offs.append(sum(sizes[:keys.index(name)]) if name in keys else -1)
+    return _FrameSumsFn.apply(stacked, color_ref, tuple(offs))
+
 
 _EPS = 1e-3
 

@@ -202,6 +202,12 @@ def render_layer(FLAGS, v_pos_clip, rast, rast_deriv, mesh, view_pos, lgt, resol
     return buffers
 
 
+class FrameBuffers(dict):
+    """The reference's dict of output buffers (render.py:436-444) + `.stacked` = (tensor [B,H,W,sum C], names, channel counts):
+    all buffers are channel slices of that one antialiased tensor, which lets the loss read the frame in a single pass."""
+    stacked = None
+
+
 _layout_cache = {}
 
 
@@ -272,11 +278,14 @@ def render_mesh(FLAGS, ctx, mesh, mtx_in, view_pos, lgt, resolution, spp=1, num_
             o = sum(sizes[:keys.index('shaded')])
             bg[..., o:o + background.shape[-1]] = background
         comp = torch.lerp(bg.expand_as(fg), fg, a)
-        out_list = list(torch.split(dr.antialias_stacked([comp], rast, v_pos_clip, tri)[0], sizes, dim=-1))
+        aa = dr.antialias_stacked([comp], rast, v_pos_clip, tri)[0]
+        out_list = list(torch.split(aa, sizes, dim=-1))
     else:
-        out_list = []
+        aa, sizes, out_list = None, [], []
 
-    out_buffers = {'visible_triangles': visible_triangles}
+    out_buffers = FrameBuffers({'visible_triangles': visible_triangles})
+    if aa is not None and spp == 1:
+        out_buffers.stacked = (aa, keys, sizes)              # every buffer below is a channel slice of this tensor
     for key, accum in zip(keys, out_list):
         out_buffers[key] = util.avg_pool_nhwc(accum, spp) if spp > 1 else accum
     return out_buffers

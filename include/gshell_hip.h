@@ -327,6 +327,25 @@ int gs_hashgrid_bwd(int n_levels, int F, int log2_T, int base_res, float per_lev
                     const float* g_out, float* g_params, float* g_x_levels, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Whole-frame loss / regulariser sums   (replaces the per-term torch expressions of
+ *   geometry/gshell_tets_geometry.py:275-285 (alpha MSE, mSDF image terms) and render/regularizer.py:21-41
+ *   (material / normal smoothness, monochrome-lighting prior) -- ~230 elementwise launches per iteration)
+ *   stacked [n_pixels, C] f32 = the antialiased frame buffers side by side, color_ref [n_pixels,4] f32,
+ *   offs_host[7] (HOST memory) = channel offset of shaded(4), msdf_image(1), diffuse_light(4),
+ *   specular_light(4), kd_grad(4), ks_grad(4), normal_grad(4) inside a pixel record, -1 = absent.
+ *   fwd: partials [gs_frame_sums_partials(n_pixels), 9] f32; the caller sums over rows to get
+ *        (sum (a-m)^2, sum |msdf+ [m=0]|, sum |msdf- [m=1] - 1|, sum |logsrgb((d+s) m) - logsrgb(max(ref) m)|,
+ *         sum luma(spec), sum luma(diff), sum kd_grad, sum ks_grad, sum normal_grad).
+ *   bwd: g_sums_dev [9] f32 (device) -> g_stacked [n_pixels, C] WRITTEN (zeros in untouched channels).
+ * ---------------------------------------------------------------------------------- */
+int64_t gs_frame_sums_partials(int64_t n_pixels);
+int gs_frame_sums_fwd(const float* stacked, const float* color_ref, int64_t n_pixels, int64_t C,
+                      const int32_t* offs_host, float* partials, gs_stream_t stream);
+int gs_frame_sums_bwd(const float* stacked, const float* color_ref, int64_t n_pixels, int64_t C,
+                      const int32_t* offs_host, const float* g_sums_dev, float* g_stacked,
+                      gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Texture-field MLP   (replaces the torch `_MLP` + sigmoid range mapping of MLPTexture3D.sample,
  *   render/mlptexture.py:18-44, :87-99): out = sigmoid(W3 relu(W2 relu(W1 x))) * (hi - lo) + lo
  *   x [N,32] f32 (hash-grid features), mask [N] f32 or NULL (rows with mask <= 0 get the value of an

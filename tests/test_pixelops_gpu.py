@@ -164,3 +164,51 @@ def test_fused_sdf_mlp_forward(n_hidden, skip_in):
     xr = x.clone().requires_grad_(True)
     net.cpu()(xr).backward(g.cpu())
     assert (xg.grad.cpu() - xr.grad).abs().max() <= 1e-4 * xr.grad.abs().max()
+
+
+@pytest.mark.parametrize("with_light", [True, False])
+def test_frame_sums_match_the_torch_terms(with_light):
+    """gs_frame_sums_fwd/bwd vs the term-by-term torch formulation (regularizer.shading_loss / material_smoothness_grad, the
+    alpha MSE and the two mSDF image terms of tick): sums to 1e-5 relative, gradients w.r.t. every buffer to 1e-4 relative."""
+    import torch.nn.functional as F
+    from gshell_amd.render import regularizer as R
+    g = torch.Generator(device="cuda").manual_seed(3 + with_light)
+    B, H, W = 2, 37, 41
+    keys = ['shaded', 'z_grad', 'kd', 'kd_grad', 'ks_grad', 'normal_grad'] + (['diffuse_light', 'specular_light'] if with_light else []) + ['msdf_image']
+    sizes = [4, 4, 4, 4, 4, 4] + ([4, 4] if with_light else []) + [1]
+    stacked = torch.rand(B, H, W, sum(sizes), device="cuda", generator=g)
+    o = sum(sizes[:-1])
+    stacked[..., o] = stacked[..., o] * 2 - 1                           # mSDF image takes both signs
+    stacked[0, 0, :5, o] = 0.0                                          # ... and exact zeros (clamp / abs kinks)
+    if with_light:
+        od = sum(sizes[:keys.index('diffuse_light')])
+        stacked[0, 1, :7, od:od + 8] = 0.0                              # unlit pixels: logsrgb at its knee
+        stacked[0, 2, :7, od:od + 3] *= 30.0
+    stacked.requires_grad_(True)
+    ref = torch.rand(B, H, W, 4, device="cuda", generator=g)
+    ref[..., 3] = (ref[..., 3] > 0.5).float()                           # alpha is exactly 0 or 1 on most pixels
+    ref[1, 3, :9, 3] = 0.37                                             # ... and fractional on antialiased edges
+    w = torch.rand(9, device="cuda", generator=g) + 0.5
+    fs = R.frame_sums((stacked, keys, sizes), ref)
+    (fs * w).sum().backward()
+    got_g = stacked.grad.clone()
+    stacked.grad = None
+    buf = dict(zip(keys, torch.split(stacked, sizes, dim=-1)))
+    m = ref[..., 3:]
+    n = float(m.numel())
+    zero = torch.zeros((), device="cuda")
+    want = [F.mse_loss(buf['shaded'][..., 3:], m) * n,
+            F.l1_loss(buf['msdf_image'].clamp(min=0) * (m == 0).float(), torch.zeros_like(m)) * n,
+            F.l1_loss(buf['msdf_image'].clamp(max=0) * (m == 1).float(), torch.ones_like(m)) * n]
+    if with_light:
+        d, s = R.luma(buf['diffuse_light']), R.luma(buf['specular_light'])
+        want += [(R._log_srgb((d + s) * m) - R._log_srgb(R.value(ref) * m)).abs().mean() * n, s.mean() * n, d.mean() * n]
+    else:
+        want += [zero, zero, zero]
+    want += [(buf['kd_grad'][..., :3].sum(-1) / 3 * buf['kd_grad'][..., -1]).sum(),
+             (buf['ks_grad'][..., :-1] * buf['ks_grad'][..., -1:]).sum(), (buf['normal_grad'][..., :-1] * buf['normal_grad'][..., -1:]).sum()]
+    want = torch.stack([x.reshape(()) for x in want])
+    assert torch.allclose(fs, want, rtol=1e-5, atol=1e-4), (fs, want)
+    (want * w).sum().backward()
+    scale = float(stacked.grad.abs().max())
+    assert float((got_g - stacked.grad).abs().max()) <= 1e-4 * scale
