@@ -25,8 +25,8 @@ import torch.distributed as dist
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--res", type=int, default=256, help="tet grid resolution (64/128/256)")
     ap.add_argument("--views", type=int, default=4, help="views per GPU")
     ap.add_argument("--train-res", type=int, default=512)

@@ -27,6 +27,34 @@ class Embedding(nn.Module):
         return torch.cat((x, sc.reshape(*x.shape[:-1], -1)), -1)
 
 
+def _splitk_tn(a, b, split):
+    """a^T @ b for a [R,m], b [R,n] with R >> m, n: `split` slabs as one batched GEMM + a reduction."""
+    R = a.shape[0]
+    R0 = (R // split) * split
+    out = torch.bmm(a[:R0].reshape(split, R0 // split, -1).transpose(1, 2), b[:R0].reshape(split, R0 // split, -1)).sum(0)
+    if R0 < R:
+        out = out + a[R0:].t() @ b[R0:]
+    return out
+
+
+class _SplitKMatmulFn(torch.autograd.Function):
+    """y = a @ w whose gradient w.r.t. w (again a^T @ gy with K = rows) is split-K.  Used for the input-gradient product
+    inside _SplitKLinearFn.backward so that the DOUBLE backward of the eikonal term does not fall back to a single
+    256 x 256-output GEMM over 50 k rows (measured 1.25 ms as one hipBLASLt call on 32 workgroups)."""
+
+    @staticmethod
+    def forward(ctx, a, w):
+        ctx.save_for_backward(a, w)
+        return a @ w
+
+    @staticmethod
+    def backward(ctx, gy):
+        a, w = ctx.saved_tensors
+        g_a = gy @ w.t() if ctx.needs_input_grad[0] else None
+        g_w = _splitk_tn(a, gy, _SplitKLinearFn.SPLIT) if ctx.needs_input_grad[1] else None
+        return g_a, g_w
+
+
 class _SplitKLinearFn(torch.autograd.Function):
     """F.linear whose weight gradient is a split-K batched GEMM.  dW = g^T x has a 256 x 256 output and K = rows
     (10^5..10^6): as ONE GEMM hipBLASLt covers the output with 32 workgroups (MT32x64) and leaves 7/8 of the chip idle
@@ -43,15 +71,8 @@ class _SplitKLinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
-        g_x = g @ weight if ctx.needs_input_grad[0] else None
-        g_w = None
-        if ctx.needs_input_grad[1]:
-            S = _SplitKLinearFn.SPLIT
-            R = x.shape[0]
-            R0 = (R // S) * S
-            g_w = torch.bmm(g[:R0].reshape(S, R0 // S, -1).transpose(1, 2), x[:R0].reshape(S, R0 // S, -1)).sum(0)
-            if R0 < R:
-                g_w = g_w + g[R0:].t() @ x[R0:]
+        g_x = _SplitKMatmulFn.apply(g, weight) if ctx.needs_input_grad[0] else None
+        g_w = _splitk_tn(g, x, _SplitKLinearFn.SPLIT) if ctx.needs_input_grad[1] else None
         g_b = g.sum(0) if ctx.needs_input_grad[2] else None
         return g_x, g_w, g_b
 

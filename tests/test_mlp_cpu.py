@@ -54,3 +54,27 @@ def test_row_sparse_backward_is_exact():
     # all-zero upstream gradient
     z = torch.autograd.grad(forward_row_sparse_backward(net, x2), [x2] + list(net.parameters()), torch.zeros(500, 1))
     assert all(float(t.abs().max()) == 0.0 for t in z)
+
+
+def test_split_k_linear_matches_plain_linear_through_double_backward():
+    """The split-K weight-gradient formulation (geometry/mlp.py:_SplitKLinearFn) must give the gradients of the plain
+    nn.Linear stack for the eikonal-style loss, which differentiates THROUGH the input gradient (double backward)."""
+    import torch
+    import gshell_amd.geometry.mlp as M
+    torch.manual_seed(0)
+    net = M.MLP(n_freq=6, d_hidden=32, n_hidden=3, skip_in=[2]).double()
+    x = torch.randn(53, 3, dtype=torch.double, requires_grad=True)      # 53 rows: not a multiple of the 16 slabs
+
+    def grads(linear):
+        saved, M._linear = M._linear, linear
+        try:
+            y = net(x)
+            g = torch.autograd.grad(y.sum(), x, create_graph=True)[0]
+            loss = ((g.norm(dim=-1) - 1) ** 2).mean() + y.pow(2).mean()
+            return torch.autograd.grad(loss, list(net.parameters()) + [x])
+        finally:
+            M._linear = saved
+    a = grads(lambda m, h: M._SplitKLinearFn.apply(h, m.weight, m.bias))
+    b = grads(lambda m, h: m(h))
+    for p, q in zip(a, b):
+        assert torch.allclose(p, q, rtol=1e-12, atol=1e-14)

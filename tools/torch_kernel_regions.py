@@ -43,7 +43,16 @@ wrap(torch.optim.Adam, "step", "Adam.step")
 wrap(renderutils, "image_loss")
 
 ITERS = 3
-tr = workload.build(res=256, n_samples=8, batch=4, train_res=(512, 512), fit_steps=200)
+GEOM = sys.argv[1] if len(sys.argv) > 1 else "tets"
+RES = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+if GEOM == "flexicubes":
+    from gshell_amd.geometry import gshell_flexicubes as FC
+    from gshell_amd.geometry import gshell_flexicubes_geometry as FG
+    wrap(FG.GShellFlexiCubesGeometry, "getMesh")
+    wrap(FG.GShellFlexiCubesGeometry, "render", "geometry.render")
+    wrap(FG.GShellFlexiCubesGeometry, "tick")
+    wrap(FC.GShellFlexiCubes, "__call__", "GShellFlexiCubes.__call__")
+tr = workload.build(res=RES, n_samples=8, batch=4, train_res=(512, 512), fit_steps=200, geometry=GEOM)
 tg = workload.make_targets(tr, [0, 1, 2, 3], (512, 512))
 for _ in range(3):
     tr.step(tg)
