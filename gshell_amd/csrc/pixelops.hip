@@ -237,6 +237,31 @@ __global__ void __launch_bounds__(256) k_image_loss_bwd(const float* __restrict_
     if (g_target) g_target[i] = tonemap_bwd(y, tm, db);
 }
 
+// ---- softplus with first and second derivative -------------------------------------------------------------
+// torch.nn.Softplus(beta, threshold = 20) as three elementwise kernels: value, input gradient, and the gradient OF the
+// input gradient (the eikonal term differentiates the SDF network's input gradient again: torch expands that double
+// backward into ~9 launches per layer over [50 k, 256] tensors).  Same formulas as ATen (Activation.cpp softplus_backward,
+// derivatives.yaml softplus_double_backward): z = exp(beta x); s = z / (z + 1).
+__global__ void __launch_bounds__(256) k_softplus(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ gg, int64_t n,
+                                                  float beta, int mode, float* __restrict__ o0, float* __restrict__ o1) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float xv = x[i], bx = xv * beta;
+    const bool lin = bx > 20.0f;
+    if (mode == 0) {                                   // y
+        o0[i] = lin ? xv : log1pf(expf(bx)) / beta;
+        return;
+    }
+    const float z = expf(bx), s = z / (z + 1.0f);
+    if (mode == 1) {                                   // g_x = g * s
+        o0[i] = lin ? g[i] : g[i] * s;
+        return;
+    }
+    const float gv = g[i], ggv = gg[i];                // mode 2: d/dg and d/dx of (g * s) contracted with gg
+    if (o0) o0[i] = lin ? ggv : ggv * s;
+    if (o1) o1[i] = lin ? 0.0f : ggv * gv * beta * z / ((z + 1.0f) * (z + 1.0f));
+}
+
 // ---- whole-frame loss / regulariser sums --------------------------------------------------------------
 // One pass over the stacked, antialiased frame buffers [B*H*W, C] (render.render_mesh keeps every buffer as a channel
 // slice of ONE tensor) producing the nine pixel sums behind the alpha MSE, the two mSDF image terms
@@ -501,6 +526,33 @@ extern "C" int gs_image_loss_bwd(const float* img, const float* target, int64_t 
     GS_REQUIRE(img && target && g_scalar_dev, "gs_image_loss_bwd: null pointer");
     hipLaunchKernelGGL(k_image_loss_bwd, dim3((unsigned)gs::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, img, target, n, loss, tonemapper,
                        g_scalar_dev, scale, g_img, g_target);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_softplus_fwd(const float* x, int64_t n, float beta, float* y, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_REQUIRE(x && y && beta > 0.0f, "gs_softplus_fwd: bad argument");
+    hipLaunchKernelGGL(k_softplus, dim3((unsigned)gs::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr, (const float*)nullptr, n,
+                       beta, 0, y, (float*)nullptr);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_softplus_bwd(const float* x, const float* g, int64_t n, float beta, float* g_x, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_REQUIRE(x && g && g_x && beta > 0.0f, "gs_softplus_bwd: bad argument");
+    hipLaunchKernelGGL(k_softplus, dim3((unsigned)gs::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, g, (const float*)nullptr, n, beta, 1, g_x,
+                       (float*)nullptr);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_softplus_bwd_bwd(const float* x, const float* g, const float* gg, int64_t n, float beta, float* d_g, float* d_x,
+                                   gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_REQUIRE(x && g && gg && (d_g || d_x) && beta > 0.0f, "gs_softplus_bwd_bwd: bad argument");
+    hipLaunchKernelGGL(k_softplus, dim3((unsigned)gs::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, g, gg, n, beta, 2, d_g, d_x);
     GS_LAUNCH_CHECK();
     return 0;
 }

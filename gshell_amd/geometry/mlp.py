@@ -77,6 +77,63 @@ class _SplitKLinearFn(torch.autograd.Function):
         return g_x, g_w, g_b
 
 
+class _SoftplusBwdFn(torch.autograd.Function):
+    """g * softplus'(x) as one kernel, with a one-kernel backward of its own (the eikonal term differentiates it again)."""
+
+    @staticmethod
+    def forward(ctx, x, g, beta):
+        from .. import _lib
+        x_c, g_c = x.detach().contiguous(), g.detach().contiguous()
+        out = torch.empty_like(x_c)
+        with torch.cuda.device(x_c.device):
+            _lib.check(_lib.lib().gs_softplus_bwd(_lib.ptr(x_c, torch.float32, "x"), _lib.ptr(g_c, torch.float32, "g"), _lib.c_int64(x_c.numel()),
+                                                  _lib.c_float(beta), _lib.ptr(out), _lib.stream()), "gs_softplus_bwd")
+        ctx.save_for_backward(x_c, g_c)
+        ctx.beta = beta
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gg):
+        from .. import _lib
+        x_c, g_c = ctx.saved_tensors
+        gg_c = gg.contiguous()
+        d_g = torch.empty_like(x_c) if ctx.needs_input_grad[1] else None
+        d_x = torch.empty_like(x_c) if ctx.needs_input_grad[0] else None
+        if d_g is not None or d_x is not None:
+            with torch.cuda.device(x_c.device):
+                _lib.check(_lib.lib().gs_softplus_bwd_bwd(_lib.ptr(x_c), _lib.ptr(g_c), _lib.ptr(gg_c, torch.float32, "gg"), _lib.c_int64(x_c.numel()),
+                                                          _lib.c_float(ctx.beta), _lib.ptr(d_g), _lib.ptr(d_x), _lib.stream()), "gs_softplus_bwd_bwd")
+        return d_x, d_g, None
+
+
+class _SoftplusFn(torch.autograd.Function):
+    """nn.Softplus(beta, threshold=20) on the HIP elementwise kernels (value / gradient / gradient of the gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, beta):
+        from .. import _lib
+        x_c = x.detach().contiguous()
+        y = torch.empty_like(x_c)
+        with torch.cuda.device(x_c.device):
+            _lib.check(_lib.lib().gs_softplus_fwd(_lib.ptr(x_c, torch.float32, "x"), _lib.c_int64(x_c.numel()), _lib.c_float(beta), _lib.ptr(y),
+                                                  _lib.stream()), "gs_softplus_fwd")
+        ctx.save_for_backward(x)
+        ctx.beta = beta
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return _SoftplusBwdFn.apply(x, g, ctx.beta), None
+
+
+def _softplus(module, h):
+    if h.is_cuda and h.dtype == torch.float32 and module.threshold == 20 and h.numel() >= (1 << 16):
+        return _SoftplusFn.apply(h, float(module.beta))
+    return module(h)
+
+
 def _linear(module, h):
     if h.dim() == 2 and h.shape[0] >= _SplitKLinearFn.MIN_ROWS and h.is_cuda:
         return _SplitKLinearFn.apply(h, module.weight, module.bias)
@@ -103,7 +160,7 @@ class MLP(nn.Module):
         h = emb
         for i, module in enumerate(self.net):
             hin = torch.cat([h, emb], dim=-1) if i in self.skip_count else h
-            h = _linear(module, hin) if isinstance(module, nn.Linear) else module(hin)
+            h = _linear(module, hin) if isinstance(module, nn.Linear) else (_softplus(module, hin) if isinstance(module, nn.Softplus) else module(hin))
         return h
 
 

@@ -327,6 +327,18 @@ int gs_hashgrid_bwd(int n_levels, int F, int log2_T, int base_res, float per_lev
                     const float* g_out, float* g_params, float* g_x_levels, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Softplus with first and second derivative   (the activation of geometry/mlp.py:19-33, nn.Softplus(beta=100);
+ *   replaces ATen's softplus / softplus_backward / the ~9-op expansion of softplus_double_backward on the torch
+ *   formulation of the SDF network: row-sparse backward and the eikonal term's double backward)
+ *   y = x if beta x > 20 else log1p(exp(beta x)) / beta;   g_x = g s,  s = sigmoid(beta x) (1 if beta x > 20);
+ *   bwd_bwd: d_g = gg s,  d_x = gg g beta s (1 - s)  (0 if beta x > 20);  either output may be NULL.
+ * ---------------------------------------------------------------------------------- */
+int gs_softplus_fwd(const float* x, int64_t n, float beta, float* y, gs_stream_t stream);
+int gs_softplus_bwd(const float* x, const float* g, int64_t n, float beta, float* g_x, gs_stream_t stream);
+int gs_softplus_bwd_bwd(const float* x, const float* g, const float* gg, int64_t n, float beta,
+                        float* d_g, float* d_x, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Whole-frame loss / regulariser sums   (replaces the per-term torch expressions of
  *   geometry/gshell_tets_geometry.py:275-285 (alpha MSE, mSDF image terms) and render/regularizer.py:21-41
  *   (material / normal smoothness, monochrome-lighting prior) -- ~230 elementwise launches per iteration)

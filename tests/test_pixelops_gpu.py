@@ -212,3 +212,30 @@ def test_frame_sums_match_the_torch_terms(with_light):
     (want * w).sum().backward()
     scale = float(stacked.grad.abs().max())
     assert float((got_g - stacked.grad).abs().max()) <= 1e-4 * scale
+
+
+def test_sdf_net_torch_formulation_fast_paths_match_plain_modules():
+    """geometry/mlp.py swaps in a split-K Linear and HIP softplus kernels (value / gradient / gradient of the gradient) for
+    large row counts.  Against the plain nn.Linear / nn.Softplus modules: outputs 1e-6, eikonal-style double-backward
+    gradients 1e-4 relative (fp32, different summation order)."""
+    import gshell_amd.geometry.mlp as M
+    torch.manual_seed(0)
+    net = M.MLP(n_freq=6, d_hidden=256, n_hidden=6, skip_in=[3]).cuda()
+    x = (torch.rand(70001, 3, device="cuda") - 0.5).requires_grad_(True)
+
+    def run():
+        y = net(x)
+        g = torch.autograd.grad(y.sum(), x, create_graph=True)[0]
+        loss = ((g.pow(2).sum(-1).sqrt() - 1) ** 2).mean() + y.pow(2).mean()
+        return y.detach(), g.detach(), torch.autograd.grad(loss, list(net.parameters()))
+    y1, g1, p1 = run()
+    saved = M._linear, M._softplus
+    M._linear, M._softplus = (lambda m, h: m(h)), (lambda m, h: m(h))
+    try:
+        y0, g0, p0 = run()
+    finally:
+        M._linear, M._softplus = saved
+    assert torch.allclose(y1, y0, rtol=1e-5, atol=1e-6)
+    assert float((g1 - g0).abs().max()) <= 1e-4 * float(g0.abs().max())
+    for a, b in zip(p1, p0):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-9
