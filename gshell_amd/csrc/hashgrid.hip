@@ -51,16 +51,21 @@ __global__ void __launch_bounds__(256) k_hashgrid(GridMeta M, const float* __res
                                                   float* __restrict__ g_params, float* __restrict__ g_x_lvl) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int l = blockIdx.y;
-    if (i >= N) return;
     const int F = M.F;
     const int C = M.n_levels * F;
-    if (mask && !(mask[i] > 0.0f)) {
+    const bool in_range = i < N;
+    const bool active = in_range && !(mask && !(mask[i] > 0.0f));
+    if (in_range && !active) {
         if (!BWD)
             for (int f = 0; f < F; ++f) out[i * C + l * F + f] = 0.f;
         else if (g_x_lvl)
             for (int k = 0; k < 3; ++k) g_x_lvl[((int64_t)l * N + i) * 3 + k] = 0.f;
-        return;
     }
+    // forward: inactive lanes are done.  backward: they stay for the wave-level run combining below (as empty lanes),
+    // unless the whole wave is empty.
+    if (!BWD && !active) return;
+    if (BWD && __ballot(active) == 0ull) return;
+    const int lane = threadIdx.x & 63;
     float scale = M.scale[l];
     uint32_t res = M.res[l];
     uint32_t size = M.offset[l + 1] - M.offset[l];
@@ -68,7 +73,7 @@ __global__ void __launch_bounds__(256) k_hashgrid(GridMeta M, const float* __res
     uint32_t g0[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        p[k] = x[3 * i + k] * scale + 0.5f;
+        p[k] = (active ? x[3 * i + k] : 0.0f) * scale + 0.5f;
         float fl = floorf(p[k]);
         w[k] = p[k] - fl;
         g0[k] = (uint32_t)(int)fl;
@@ -79,7 +84,7 @@ __global__ void __launch_bounds__(256) k_hashgrid(GridMeta M, const float* __res
     float gx[3] = {0.f, 0.f, 0.f};
     float go[8];
     if (BWD)
-        for (int f = 0; f < F && f < 8; ++f) go[f] = g_out[i * C + l * F + f];
+        for (int f = 0; f < F && f < 8; ++f) go[f] = active ? g_out[i * C + l * F + f] : 0.0f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         uint32_t cx = g0[0] + (c & 1), cy = g0[1] + ((c >> 1) & 1), cz = g0[2] + ((c >> 2) & 1);
@@ -92,16 +97,33 @@ __global__ void __launch_bounds__(256) k_hashgrid(GridMeta M, const float* __res
         if (!BWD) {
             for (int f = 0; f < F && f < 8; ++f) acc[f] += wgt * e[f];
         } else {
+            // Lanes are consecutive pixels of a scan line, so up to the mid levels neighbouring lanes fall into the same
+            // cell and would each fire an atomic at the same table entry (the backward is bound by the float-atomic rate:
+            // 38 M atomics per call).  Runs of equal entries along the wave are summed by a segmented shuffle reduction
+            // (suffix sums inside a run: no cancellation) and only the first lane of a run issues the atomic.
+            const uint32_t key = active ? idx : (0x80000000u | (uint32_t)lane);          // empty lanes never merge
+            const uint32_t prev = __shfl_up(key, 1, 64);
+            const bool head = lane == 0 || key != prev;
+            const uint64_t heads = __ballot(head);
+            const uint64_t after = lane == 63 ? 0ull : (heads & ~((2ull << lane) - 1ull));
+            const int end = after ? (__ffsll((long long)after) - 2) : 63;                 // last lane of this lane's run
             float dotp = 0.f;
             for (int f = 0; f < F && f < 8; ++f) {
-                dotp += go[f] * e[f];
-                if (g_params && go[f] != 0.f) atomicAdd(&g_params[((int64_t)M.offset[l] + idx) * F + f], wgt * go[f]);
+                if (active) dotp += go[f] * e[f];
+                float v = active ? wgt * go[f] : 0.0f;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const float ov = __shfl_down(v, d, 64);
+                    if (lane + d <= end) v += ov;
+                }
+                if (g_params && head && active && v != 0.f) atomicAdd(&g_params[((int64_t)M.offset[l] + idx) * F + f], v);
             }
             gx[0] += ((c & 1) ? 1.f : -1.f) * wy * wz * dotp;
             gx[1] += ((c & 2) ? 1.f : -1.f) * wx * wz * dotp;
             gx[2] += ((c & 4) ? 1.f : -1.f) * wx * wy * dotp;
         }
     }
+    if (!active) return;
     if (!BWD) {
         for (int f = 0; f < F && f < 8; ++f) out[i * C + l * F + f] = acc[f];
     } else if (g_x_lvl) {
