@@ -249,10 +249,10 @@ __global__ void __launch_bounds__(256) k_softplus(const float* __restrict__ x, c
     const float xv = x[i], bx = xv * beta;
     const bool lin = bx > 20.0f;
     if (mode == 0) {                                   // y
-        o0[i] = lin ? xv : log1pf(expf(bx)) / beta;
+        o0[i] = lin ? xv : __logf(1.0f + __expf(bx)) / beta;      // hardware exp / log: |error| <= 1e-9 on the value (as in mlp.hip)
         return;
     }
-    const float z = expf(bx), s = z / (z + 1.0f);
+    const float z = __expf(bx), s = z / (z + 1.0f);
     if (mode == 1) {                                   // g_x = g * s
         o0[i] = lin ? g[i] : g[i] * s;
         return;
