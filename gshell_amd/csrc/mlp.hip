@@ -37,6 +37,10 @@ constexpr int EMAX = 40;        // max embedding width handled (3 (2*6 + 1) = 39
 constexpr int LDE = EMAX + 1;
 constexpr int KC = 8;           // weight rows per register-prefetch chunk
 constexpr int MAX_LAYERS = 16;
+#ifndef GS_MLP_INPLACE
+#define GS_MLP_INPLACE 1
+#endif
+#define GS_MLP_INPLACE_TILES (GS_MLP_INPLACE ? 1 : 2)
 
 struct MlpArgs {
     const float* x;       // [N,3]
@@ -95,8 +99,8 @@ __device__ __forceinline__ void gemm_segment(v16f (&acc)[2], const float* __rest
 __global__ void __launch_bounds__(NT, 2) k_sdf_mlp_fwd(MlpArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xa = smem;                       // [TM][LDX]
-    float* xb = xa + TM * LDX;              // [TM][LDX]
-    float* emb = xb + TM * LDX;             // [TM][LDE]
+    float* xb = xa + TM * LDX;              // [TM][LDX]   (absent with GS_MLP_INPLACE)
+    float* emb = xa + (GS_MLP_INPLACE_TILES) * TM * LDX;   // [TM][LDE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * TM;
 
@@ -118,8 +122,15 @@ __global__ void __launch_bounds__(NT, 2) k_sdf_mlp_fwd(MlpArgs A) {
     }
     __syncthreads();
 
+#ifndef GS_MLP_INPLACE
+#define GS_MLP_INPLACE 1
+#endif
+    // GS_MLP_INPLACE: ONE activation tile, overwritten in place after a barrier (k-loop of layer l done by all waves ->
+    // epilogue writes layer l's outputs over its inputs).  76 KB of LDS instead of 142 KB, so TWO workgroups share a CU
+    // (4 waves per SIMD) and the epilogue of one overlaps the k-loop of the other: in-phase execution of two co-resident
+    // workgroups is unstable (whoever leaves the k-loop first lets the other run it at full rate), so they drift apart.
     float* xin = xa;
-    float* xout = xb;
+    float* xout = GS_MLP_INPLACE ? xa : xb;
     for (int l = 0; l < A.n_layers; ++l) {
         v16f acc[2];
 #pragma unroll
@@ -132,6 +143,7 @@ __global__ void __launch_bounds__(NT, 2) k_sdf_mlp_fwd(MlpArgs A) {
             gemm_segment(acc, xin, LDX, D, A.wt[l], tid);
             if (l == A.skip_layer) gemm_segment(acc, emb, LDE, A.Epad, A.wt[l] + (int64_t)D * D, tid);
         }
+        if (GS_MLP_INPLACE) __syncthreads();     // every wave is done reading the tile
         // epilogue: bias + softplus, accumulator layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
         int col = wave * 32 + (lane & 31);
         float bj = A.bias[l][col];
@@ -162,7 +174,7 @@ __global__ void __launch_bounds__(NT, 2) k_sdf_mlp_fwd(MlpArgs A) {
     }
 }
 
-constexpr size_t SMEM_BYTES = (size_t)(2 * TM * LDX + TM * LDE) * sizeof(float);
+constexpr size_t SMEM_BYTES = (size_t)((GS_MLP_INPLACE ? 1 : 2) * TM * LDX + TM * LDE) * sizeof(float);
 
 }  // namespace
 
