@@ -29,8 +29,12 @@ namespace {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int TM = 64;          // rows per workgroup
-constexpr int NT = 512;         // threads per workgroup: 8 waves, each owns 64 rows x 32 columns (2 accumulators); 2 waves / SIMD
+#ifndef GS_MLP_SUB
+#define GS_MLP_SUB 2
+#endif
+constexpr int SUB = GS_MLP_SUB; // 32-row sub-tiles per workgroup = accumulators per wave
+constexpr int TM = 32 * SUB;    // rows per workgroup
+constexpr int NT = 512;         // threads per workgroup: 8 waves, each owns TM rows x 32 columns (SUB accumulators)
 constexpr int D = 256;          // hidden width (fixed by the kernel)
 constexpr int LDX = D + 1;      // activation tile row stride (floats)
 constexpr int EMAX = 40;        // max embedding width handled (3 (2*6 + 1) = 39, padded to even)
@@ -65,7 +69,7 @@ __device__ __forceinline__ float softplus100(float x) {
 // same rows, so the per-CU L1 serves most of them): no LDS staging and therefore NO barrier inside the k-loop -- the
 // waves of a workgroup drift freely and keep the matrix pipes busy.  Loads for the next 8 k-rows are issued
 // before the MFMAs of the current 8 (register double buffer, 16 VGPRs); sched_barrier pins that order.
-__device__ __forceinline__ void gemm_segment(v16f (&acc)[2], const float* __restrict__ a_lds, int lda, int K, const float* __restrict__ wt, int tid) {
+__device__ __forceinline__ void gemm_segment(v16f (&acc)[SUB], const float* __restrict__ a_lds, int lda, int K, const float* __restrict__ wt, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const int arow = lane & 31, ak = lane >> 5;
     const int nchunks = K / KC;
@@ -84,9 +88,8 @@ __device__ __forceinline__ void gemm_segment(v16f (&acc)[2], const float* __rest
         const float* acur = a_lds + arow * lda + c * KC + ak;
 #pragma unroll
         for (int s = 0; s < KC / 2; ++s) {
-            float a0 = acur[2 * s], a1 = acur[32 * lda + 2 * s];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[s], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[s], acc[1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < SUB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[i * 32 * lda + 2 * s], b[s], acc[i], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (more) {
@@ -132,9 +135,9 @@ __global__ void __launch_bounds__(NT, 2) k_sdf_mlp_fwd(MlpArgs A) {
     float* xin = xa;
     float* xout = GS_MLP_INPLACE ? xa : xb;
     for (int l = 0; l < A.n_layers; ++l) {
-        v16f acc[2];
+        v16f acc[SUB];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < SUB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         if (l == 0) {
@@ -148,7 +151,7 @@ __global__ void __launch_bounds__(NT, 2) k_sdf_mlp_fwd(MlpArgs A) {
         int col = wave * 32 + (lane & 31);
         float bj = A.bias[l][col];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < SUB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(NT, 2) k_sdf_mlp_fwd(MlpArgs A) {
         xout = t;
     }
     // output layer: 8 lanes per row, 32 columns each
-    {
+    if (tid < TM * 8) {
         int row = tid >> 3, q = tid & 7;
         float s = 0.f;
         const float* h = xin + row * LDX + q * 32;
