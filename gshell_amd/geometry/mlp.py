@@ -7,6 +7,9 @@ This file is the plain-torch (rocBLAS) formulation; the fused MFMA kernel path i
 import torch
 import torch.nn as nn
 
+from .. import _lib
+from .._lib import c_int, c_int64, check, ptr, stream
+
 
 class Embedding(nn.Module):
     def __init__(self, in_channels, N_freqs, logscale=True):
@@ -82,7 +85,6 @@ class _SoftplusBwdFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, g, beta):
-        from .. import _lib
         x_c, g_c = x.detach().contiguous(), g.detach().contiguous()
         out = torch.empty_like(x_c)
         with torch.cuda.device(x_c.device):
@@ -95,7 +97,6 @@ class _SoftplusBwdFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gg):
-        from .. import _lib
         x_c, g_c = ctx.saved_tensors
         gg_c = gg.contiguous()
         d_g = torch.empty_like(x_c) if ctx.needs_input_grad[1] else None
@@ -112,7 +113,6 @@ class _SoftplusFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, beta):
-        from .. import _lib
         x_c = x.detach().contiguous()
         y = torch.empty_like(x_c)
         with torch.cuda.device(x_c.device):
@@ -191,8 +191,6 @@ def pack_weights(net):
 
 def fused_forward(net, x):
     """sdf = net(x) through the fused MFMA kernel (no autograd)."""
-    from .. import _lib
-    from .._lib import c_int, c_int64, check, ptr, stream
     packed, n_hidden, skip = pack_weights(net)
     L = _lib.lib()
     assert packed.numel() == L.gs_sdf_mlp_packed_floats(c_int(net.emb.N_freqs), c_int(n_hidden), c_int(skip))
