@@ -103,6 +103,7 @@ def main():
         roof = roofline(op_times, N, Ftets, V_aug, T, B_local, H, W, a.n_samples)
         if roof:
             out["roofline"] = roof
+        out["hbm_kernels"] = hbm_kernels(op_times, N, Ftets, V_aug, T, B_local, H, W)
         if a.op_times:
             out["op_ms"] = {k: round(v["ms"], 4) for k, v in sorted(op_times.items(), key=lambda kv: -kv[1]["ms"] * kv[1]["n"])}
             out["op_calls_per_step"] = {k: v["n"] / a.steps for k, v in op_times.items()}
@@ -123,6 +124,39 @@ def pmc_traffic(kernel):
         return None
 
 
+def algorithmic_bytes(N, Ftets, V_aug, T, B, H, W):
+    """Algorithmic HBM bytes per launch of the HBM-bound kernel families (DESIGN.md "Kernels": inputs read once + outputs
+    written once; E = 16 M edges at res 256 is folded into the per-tet / per-vertex figures of the extraction)."""
+    npix = B * H * W
+    return {
+        "gs_env_shade_fwd": npix * (4 + 6 * 12 + 24),
+        "gs_env_shade_bwd": npix * (4 + 6 * 12 + 24 + 48),
+        "gs_mtets_count": 16 * Ftets + 20 * N, "gs_mtets_fill": 16 * Ftets + 20 * N + 20 * V_aug + 12 * T,
+        "gs_bilateral_fwd": npix * (12 + 12 + 8 + 16), "gs_bilateral_bwd": npix * (12 + 8 + 16 + 12),
+        "gs_hashgrid_fwd": npix * (12 + 4 + 128), "gs_hashgrid_bwd": npix * (12 + 4 + 128 + 12 * 16),
+        "gs_rasterize_fwd": B * (16 * V_aug + 12 * T) + npix * 40, "gs_aa_apply_fwd": npix * 8 * 45, "gs_aa_apply_bwd": npix * 12 * 45,
+        "gs_sdf_reg_fwd": 8 * int(1.19 * Ftets) + 4 * N, "gs_texmlp_fwd": npix * 152, "gs_texmlp_bwd": npix * (152 + 128 + 24),
+        "gs_frame_sums_fwd": npix * 4 * 49, "gs_frame_sums_bwd": npix * 8 * 49,
+        "gs_interpolate_fwd": npix * (16 + 4 * 7), "gs_auto_normals_fwd": 36 * T + 24 * V_aug,
+    }
+
+
+def hbm_kernels(op_times, N, Ftets, V_aug, T, B, H, W):
+    """Achieved algorithmic GB/s of every HBM-bound kernel family of the iteration (HIP events around the C-ABI launch),
+    as a fraction of the 8 TB/s HBM3E peak.  Ray traversal, hash-grid gathers and the bilateral taps are latency / ALU /
+    L2 bound: their fractions are reported, not targeted."""
+    out = []
+    masked = ("gs_env_shade_fwd", "gs_env_shade_bwd", "gs_hashgrid_fwd", "gs_hashgrid_bwd", "gs_texmlp_fwd", "gs_texmlp_bwd")   # covered pixels only
+    for name, alg in algorithmic_bytes(N, Ftets, V_aug, T, B, H, W).items():
+        if name in masked:
+            continue
+        rec = op_times.get(name)
+        if rec and rec["ms"] > 0:
+            gbps = alg / (rec["ms"] * 1e-3) / 1e9
+            out.append({"op": name, "ms": round(rec["ms"], 4), "GB/s": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4)})
+    return sorted(out, key=lambda r: -r["ms"])
+
+
 def roofline(op_times, N, Ftets, V_aug, T, B, H, W, n):
     """Roofline of the dominant hand-written kernel family of the iteration (HIP events around its C-ABI launch)."""
     if not op_times:
@@ -136,15 +170,7 @@ def roofline(op_times, N, Ftets, V_aug, T, B, H, W, n):
         return {"kernel": "k_sdf_mlp_fwd (gs_sdf_mlp_fwd)", "bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
                 "frac": round(tf / 157.3, 4), "traffic": pmc_traffic("k_sdf_mlp_fwd") if N == 2282489 else None, "avg_launch_ms": round(rec["ms"], 4), "algorithmic_flops": flops,
                 "note": "fp32-in/fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32); HBM traffic is 16 B/vertex by construction"}
-    # algorithmic HBM bytes per launch (DESIGN.md "Kernels"): inputs read once + outputs written once
-    alg = {
-        "gs_env_shade_fwd": npix * (4 + 6 * 12 + 24),
-        "gs_env_shade_bwd": npix * (4 + 6 * 12 + 24 + 48),
-        "gs_mtets_count": 16 * Ftets + 20 * N, "gs_mtets_fill": 16 * Ftets + 20 * N + 20 * V_aug + 12 * T,
-        "gs_bilateral_fwd": npix * (12 + 12 + 8 + 16), "gs_bilateral_bwd": npix * (12 + 8 + 16 + 12),
-        "gs_hashgrid_fwd": npix * (12 + 4 + 128), "gs_hashgrid_bwd": npix * (12 + 4 + 128 + 12 * 16),
-        "gs_rasterize_fwd": B * (16 * V_aug + 12 * T) + npix * 40, "gs_aa_apply_fwd": npix * 8 * 45, "gs_aa_apply_bwd": npix * 12 * 45,
-    }.get(name)
+    alg = algorithmic_bytes(N, Ftets, V_aug, T, B, H, W).get(name)
     if alg is None:
         return {"kernel": name, "bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
                 "avg_launch_ms": round(rec["ms"], 4)}
