@@ -1,0 +1,1 @@
+"""Bilateral denoiser module with the reference interface (denoiser/denoiser.py)."""
