@@ -6,11 +6,22 @@ One "step" = one full optimisation iteration (train_gshelltet_deepfashion.py:395
 geometry.tick (SDF MLP over the whole tet grid -> G-MarchingTets extraction -> BVH rebuild -> rasterise -> interpolate ->
 hash-grid texture -> Monte-Carlo env shading with shadow rays -> bilateral denoise -> composite + antialias -> losses),
 backward, 3 Adam steps, clamps -- on synthetic inputs of BASELINE.json configs[2]: tet-res256, 4 views of 512x512 per GPU,
-n_samples = 8 (128 shadow rays / covered pixel / pass).  Views are sharded across ranks (weak scaling: 4 views per GPU);
-geometry is replicated; one RCCL all-reduce of the flat gradient per iteration.
+n_samples = 8 (128 shadow rays / covered pixel / pass).  Views are sharded across ranks; one RCCL all-reduce of the flat
+gradient per iteration.
+
+  --gpus N            N ranks on N devices.  If this process was NOT started by torch.distributed.run (no WORLD_SIZE in the
+                      environment) and N > 1, bench.py re-launches ITSELF under `python -m torch.distributed.run
+                      --nproc-per-node N`; it fails loudly if fewer than N devices exist.  `n_gpus` in the JSON line is the
+                      world size the process group reports, never the flag.
+  --global-batch G    fixed global batch (strong scaling): G views dealt round-robin over the ranks, e.g.
+                      `--gpus 8 --global-batch 8` = BASELINE.json configs[3] (1 view / GPU).  Default: 4 views per GPU (weak).
+  --schedule-it I     iteration counter the timed steps start from (default 1000 = steady state of the reference's
+                      schedule: shadow_scale 1, denoiser sigma 2 => 23 x 23 bilateral taps; gshell_tets_geometry.py:264-268,
+                      denoiser.py:26-29).  The it = 0 figure (sigma ~ 0, 7 x 7 taps) is measured beside it (`early_schedule`).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -29,7 +40,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--res", type=int, default=256, help="tet grid resolution (64/128/256)")
-    ap.add_argument("--views", type=int, default=4, help="views per GPU")
+    ap.add_argument("--views", type=int, default=4, help="views per GPU (weak scaling; ignored with --global-batch)")
+    ap.add_argument("--global-batch", type=int, default=None, help="fixed global batch dealt over the ranks (strong scaling); --gpus 8 --global-batch 8 = configs[3]")
+    ap.add_argument("--schedule-it", type=int, default=1000, help="iteration counter at the start of the warm-up (1000 = steady-state schedule)")
+    ap.add_argument("--early-steps", type=int, default=5, help="timed steps of the extra it=0 measurement (0 = skip)")
     ap.add_argument("--train-res", type=int, default=512)
     ap.add_argument("--n-samples", type=int, default=8)
     ap.add_argument("--fit-steps", type=int, default=400)
@@ -40,20 +54,48 @@ def parse():
     return ap.parse_args()
 
 
+def relaunch_multi_rank(n):
+    """`python bench.py --gpus N` typed by hand: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node -- refusing to run fewer ranks than asked")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        relaunch_multi_rank(a.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()             # what RCCL actually sees
     from gshell_amd import _lib, workload
     from gshell_amd.train import ViewShard
     _lib.lib()                                     # fail loudly if the HIP library is missing
     shard = ViewShard(rank, world)
-    B_local, B_global = a.views, a.views * world
+    if a.global_batch is not None:
+        if a.global_batch % world:
+            raise SystemExit(f"bench.py: --global-batch {a.global_batch} does not divide over {world} ranks")
+        B_global = a.global_batch
+    else:
+        B_global = a.views * world
+    B_local = len(shard.local_views(B_global))
     H = W = a.train_res
     import ast
     overrides = {kv.split('=', 1)[0]: ast.literal_eval(kv.split('=', 1)[1]) for kv in a.set}
@@ -70,37 +112,49 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for it in range(a.warmup):
-        trainer.step(targets[it % len(targets)], global_batch=B_global)
-    barrier()
-    _lib.reset_op_timing()
-    t0 = time.perf_counter()
-    for it in range(a.steps):
-        trainer.step(targets[(a.warmup + it) % len(targets)], global_batch=B_global)
-    barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    op_times = _lib.op_timing_summary()
+    def timed(schedule_it, warmup, steps):
+        """`warmup` untimed + `steps` timed iterations with the schedule counter starting at `schedule_it`; max over ranks."""
+        trainer.it = schedule_it
+        for it in range(warmup):
+            trainer.step(targets[it % len(targets)], global_batch=B_global)
+        barrier()
+        _lib.reset_op_timing()
+        t0 = time.perf_counter()
+        for it in range(steps):
+            trainer.step(targets[(warmup + it) % len(targets)], global_batch=B_global)
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), _lib.op_timing_summary()
+
+    early = None
+    if a.early_steps > 0 and a.schedule_it != 0:       # it = 0 schedule beside the headline (sigma ~ 0: 7 x 7 taps, shadow_scale ~ 0)
+        dt0, _ = timed(0, 2, a.early_steps)
+        early = {"schedule_it": 0, "steps": a.early_steps, "ms_per_step": round(dt0 / a.early_steps * 1e3, 3),
+                 "value": round(B_global * H * W * a.early_steps / dt0 / 1e6, 4), "bilateral_radius": 2 * math.ceil(2.5 * trainer.denoiser.sigma) + 1 if trainer.denoiser else None}
+    dt, op_times = timed(a.schedule_it, a.warmup, a.steps)
     if rank == 0:
         g = trainer.geometry
-        with torch.no_grad():
-            d = g.getMesh(trainer.mat)
         N, Ftets = g.verts.shape[0], g.indices.shape[0]
-        V_aug, T = d['imesh'].v_pos.shape[0], d['imesh'].t_pos_idx.shape[0]
+        V_aug, T = g.last_mesh_sizes            # mesh of the last timed step (a getMesh here would be a one-rank collective)
         ms = dt / a.steps * 1e3
         mpix = B_global * H * W * a.steps / dt / 1e6
         out = {
             "metric": "train iters/sec + rendered Mpixels/sec, tet-res256 @512², batch=4",
             "value": round(mpix, 4), "unit": "Mpixels/s", "iters_per_sec": round(a.steps / dt, 4),
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "strong" if a.global_batch is not None else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{'G-FlexiCubes res' if a.geometry == 'flexicubes' else 'tet-res'}{a.res} ({'voxel grid' if a.geometry == 'flexicubes' else 'BCC'} {N} verts / {Ftets} cells), {B_local} views/GPU x {H}x{W}, n_samples={a.n_samples} "
                                    f"({2 * a.n_samples ** 2} shadow rays/px/pass), full train iteration fwd+bwd+3xAdam",
-                       "global_batch": B_global, "mesh": {"V_aug": V_aug, "T": T}, "parallelism": f"view-shard dp{world}, geometry replicated"},
+                       "global_batch": B_global, "views_per_gpu": B_local, "schedule_it": a.schedule_it,
+                       "bilateral_radius": (2 * math.ceil(2.5 * trainer.denoiser.sigma) + 1) if trainer.denoiser else None,
+                       "shadow_scale": min((trainer.it - 1) / 1000, 1.0),
+                       "mesh": {"V_aug": V_aug, "T": T}, "parallelism": trainer.parallelism()},
         }
+        if early is not None:
+            out["early_schedule"] = early
         roof = roofline(op_times, N, Ftets, V_aug, T, B_local, H, W, a.n_samples)
         if roof:
             out["roofline"] = roof

@@ -362,6 +362,7 @@ struct ShadeArgs {
     int64_t HW;
     int bsdf, n, G;  // G lanes per pixel
     uint32_t seed;
+    int64_t view_offset, view_stride;  // RNG pixel index uses the GLOBAL view id b*view_stride + view_offset (view-sharded jobs)
     float shadow_scale;
     // ray buffers, slot r = k*2S + which*S + i  (which: 0 light sample, 1 BSDF sample)
     float* ray_dir;            // [n_cov*2S, 3]
@@ -478,7 +479,9 @@ __global__ void __launch_bounds__(256) k_shade_samples(ShadeArgs A) {
     c.pD = (diffuse_w + specular_w) > 0.0f ? diffuse_w / (diffuse_w + specular_w) : 1.0f;
     c.pS = 1.0f - c.pD;
 
-    uint32_t rng0 = pcg_out(A.seed) ^ pcg_out((uint32_t)gid);   // pixel linear index (z*H + y)*W + x == gid
+    // pixel linear index (z*H + y)*W + x of the reference (kernel.cu:504), with z = the view's index in the GLOBAL batch:
+    // rank r of a view-sharded job holds global views r, r + world, ... so an N-GPU step draws the 1-GPU step's samples
+    uint32_t rng0 = pcg_out(A.seed) ^ pcg_out((uint32_t)(gid + (b * (A.view_stride - 1) + A.view_offset) * A.HW));
     uint32_t light_idx = pcg_out(rng0) % (uint32_t)A.P;
     uint32_t bsdf_idx = pcg_out(lcg_next(rng0)) % (uint32_t)A.P;
     const int32_t* perm_l = A.perms + (int64_t)light_idx * S;
@@ -663,8 +666,8 @@ int cdf_iters(int size) { return (int)std::ceil(std::log2((float)(size - 1))) + 
 
 int fill_args(ShadeArgs& A, const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* ro, const float* pos, const float* nrm,
               const float* view_pos, const float* kd, const float* ks, const float* light, const float* pdf, const float* rows, const float* cols,
-              int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B, int64_t H, int64_t W, int bsdf, int n, uint32_t seed,
-              float shadow_scale, uint64_t* vis_bits) {
+              int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B, int64_t H, int64_t W, int64_t view_offset, int64_t view_stride,
+              int bsdf, int n, uint32_t seed, float shadow_scale, uint64_t* vis_bits) {
     GS_REQUIRE(bvh != nullptr, "env_shade: bvh is null");
     GS_REQUIRE(pix && ro && pos && nrm && view_pos && kd && ks && light && pdf && rows && cols && perms && vis_bits, "env_shade: null pointer");
     GS_REQUIRE(bsdf >= 0 && bsdf <= 2, "env_shade: BSDF id must be 0 (pbr), 1 (diffuse) or 2 (white)");
@@ -677,6 +680,8 @@ int fill_args(ShadeArgs& A, const gs_bvh* bvh, const int32_t* pix, int64_t n_cov
     int G = 1;
     while (G * 2 <= std::min(n * n, 64)) G *= 2;
     A.G = G;
+    GS_REQUIRE(view_offset >= 0 && view_stride >= 1, "env_shade: view_offset >= 0 and view_stride >= 1 (1-GPU: 0, 1)");
+    A.view_offset = view_offset; A.view_stride = view_stride;
     A.seed = seed; A.shadow_scale = shadow_scale; A.vis_bits = vis_bits;
     return 0;
 }
@@ -750,8 +755,8 @@ extern "C" int64_t gs_env_shade_scratch_bytes(int64_t n_cov, int n_samples_x) {
 extern "C" int gs_env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* ro, const float* gb_pos, const float* gb_normal,
                                 const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
                                 const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
-                                int64_t H, int64_t W, int bsdf, int n_samples_x, uint32_t rnd_seed, float shadow_scale, void* scratch,
-                                uint64_t* vis_bits, float* diff, float* spec, gs_stream_t stream_) {
+                                int64_t H, int64_t W, int64_t view_offset, int64_t view_stride, int bsdf, int n_samples_x, uint32_t rnd_seed,
+                                float shadow_scale, void* scratch, uint64_t* vis_bits, float* diff, float* spec, gs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (B * H * W == 0) return 0;
     if (diff) GS_HIP_CHECK(hipMemsetAsync(diff, 0, (size_t)B * H * W * 12, stream));
@@ -759,8 +764,8 @@ extern "C" int gs_env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n
     if (n_cov == 0) return 0;
     GS_REQUIRE(scratch != nullptr, "gs_env_shade_fwd: null scratch");
     ShadeArgs A{};
-    int rc = fill_args(A, bvh, pix, n_cov, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl, perms, P, B, H, W, bsdf,
-                       n_samples_x, rnd_seed, shadow_scale, vis_bits);
+    int rc = fill_args(A, bvh, pix, n_cov, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl, perms, P, B, H, W, view_offset,
+                       view_stride, bsdf, n_samples_x, rnd_seed, shadow_scale, vis_bits);
     if (rc) return rc;
     const int64_t S2 = 2ll * n_samples_x * n_samples_x, n_rays = n_cov * S2;
     A.ray_dir = (float*)scratch;
@@ -778,8 +783,8 @@ extern "C" int gs_env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n
 extern "C" int gs_env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* gb_pos, const float* gb_normal,
                                 const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
                                 const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
-                                int64_t H, int64_t W, int bsdf, int n_samples_x, uint32_t rnd_seed, float shadow_scale, const uint64_t* vis_bits,
-                                const float* g_diff, const float* g_spec, float* g_pos, float* g_normal, float* g_kd, float* g_ks, float* g_light,
+                                int64_t H, int64_t W, int64_t view_offset, int64_t view_stride, int bsdf, int n_samples_x, uint32_t rnd_seed,
+                                float shadow_scale, const uint64_t* vis_bits, const float* g_diff, const float* g_spec, float* g_pos, float* g_normal, float* g_kd, float* g_ks, float* g_light,
                                 gs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (B * H * W == 0) return 0;
@@ -792,7 +797,7 @@ extern "C" int gs_env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n
     if (n_cov == 0) return 0;
     ShadeArgs A{};
     int rc = fill_args(A, bvh, pix, n_cov, gb_pos /* ro unused in bwd */, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl,
-                       perms, P, B, H, W, bsdf, n_samples_x, rnd_seed, shadow_scale, const_cast<uint64_t*>(vis_bits));
+                       perms, P, B, H, W, view_offset, view_stride, bsdf, n_samples_x, rnd_seed, shadow_scale, const_cast<uint64_t*>(vis_bits));
     if (rc) return rc;
     A.g_diff = g_diff; A.g_spec = g_spec; A.g_pos = g_pos; A.g_nrm = g_normal; A.g_kd = g_kd; A.g_ks = g_ks; A.g_light = g_light;
     hipLaunchKernelGGL(k_shade_samples<true>, dim3((unsigned)gs::cdiv(n_cov * A.G, 256)), dim3(256), 0, stream, A);

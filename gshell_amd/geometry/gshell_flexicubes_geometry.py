@@ -6,7 +6,7 @@ import torch
 from ..render import mesh, optixutils as ou, render, util
 from .gshell_flexicubes import GShellFlexiCubes
 from .gshell_tets_geometry import GShellTetsGeometry, compute_sdf_reg_loss, sample_points   # noqa: F401  (same losses)
-from .mlp import MLP, forward_row_sparse_backward
+from .mlp import MLP, forward_row_sharded, forward_row_sparse_backward
 
 
 class GShellFlexiCubesGeometry(GShellTetsGeometry):
@@ -53,7 +53,7 @@ class GShellFlexiCubesGeometry(GShellTetsGeometry):
 
     def getMesh(self, material, _training=False):
         v_deformed = self.verts + self.max_displacement * self.deform
-        sdf = forward_row_sparse_backward(self.sdf_net, v_deformed) if self.FLAGS.use_sdf_mlp else self.sdf
+        sdf = self._sdf_values(v_deformed)
         w = self.per_cube_weights
         out = self.gflexicubes(v_deformed, sdf, self.msdf, self.indices, self.grid_res, w[:, :12], w[:, 12:20], w[:, 20], training=_training)
         if len(out) == 3:
@@ -64,6 +64,7 @@ class GShellFlexiCubesGeometry(GShellTetsGeometry):
         with torch.no_grad():
             ou.optix_build_bvh(self.optix_ctx, imesh.v_pos.contiguous(), imesh.faces_i32(), rebuild=1)
         imesh = mesh.auto_normals(imesh)
+        self.last_mesh_sizes = (int(imesh.v_pos.shape[0]), int(imesh.t_pos_idx.shape[0]))
         d = {'imesh': imesh, 'sdf': sdf, 'msdf': extra['msdf'], 'msdf_watertight': extra['msdf_watertight'],
              'msdf_boundary': extra['msdf_boundary'], 'n_verts_watertight': extra['n_verts_watertight']}
         if getattr(self.FLAGS, "visualize_watertight", False):

@@ -9,7 +9,7 @@ from .. import _lib
 from .._lib import c_int64, check, ptr, stream
 from ..render import mesh, optixutils as ou, regularizer, render
 from .gshell_tets import GShell_Tets
-from .mlp import MLP, forward_row_sparse_backward
+from .mlp import MLP, forward_row_sharded, forward_row_sparse_backward
 
 
 class _SdfRegFn(torch.autograd.Function):
@@ -58,6 +58,15 @@ def sample_points(v_pos, faces, n, generator=None):
     r = torch.rand(n, 2, device=v_pos.device, generator=generator)
     u, v = r[:, 0:1].sqrt(), r[:, 1:2]
     return (1 - u) * v0[fid] + u * (1 - v) * v1[fid] + u * v * v2[fid], fid
+
+
+def eikonal_sq_sum(sdf_net, pts):
+    """sum_i (|d sdf / d x_i| - 1)^2 over the sample points (reference :318-324, before the mean), differentiable w.r.t.
+    the network parameters (torch double backward; the samples are detached as in the reference)."""
+    v = pts.detach().requires_grad_(True)
+    sdf_eik = sdf_net(v)
+    grad = torch.autograd.grad(sdf_eik.sum(), v, create_graph=True)[0]
+    return (grad.pow(2).sum(dim=-1).sqrt() - 1).pow(2).sum()
 
 
 class GShellTetsGeometry(torch.nn.Module):
@@ -155,10 +164,20 @@ class GShellTetsGeometry(torch.nn.Module):
             self._gshell_tets_full = ext
         return ext
 
+    def _sdf_values(self, v_deformed):
+        """SDF of every grid vertex; backward only through the rows that receive gradient (geometry/mlp.py).  In a
+        view-sharded job the rows are split over the ranks and the values all-gathered (FLAGS.shard_mlp_rows)."""
+        if not self.FLAGS.use_sdf_mlp:
+            return self.sdf
+        shard = getattr(self.FLAGS, "view_shard", None)
+        if shard is not None and shard.world > 1 and getattr(self.FLAGS, "shard_mlp_rows", False):
+            return forward_row_sharded(self.sdf_net, v_deformed, shard)
+        return forward_row_sparse_backward(self.sdf_net, v_deformed)
+
     def getMesh(self, material):
         v_deformed = self.verts + self.max_displacement * self.deform
         # SDF of every grid vertex; backward only through the rows that receive gradient (see geometry/mlp.py)
-        sdf = forward_row_sparse_backward(self.sdf_net, v_deformed) if self.FLAGS.use_sdf_mlp else self.sdf
+        sdf = self._sdf_values(v_deformed)
         msdf = self.msdf
         v_deformed = v_deformed + self.offset
         verts, faces, uvs, uv_idx, v_tng, extra = self.gshell_tets(v_deformed, sdf, msdf, self.indices)
@@ -167,6 +186,7 @@ class GShellTetsGeometry(torch.nn.Module):
         with torch.no_grad():
             ou.optix_build_bvh(self.optix_ctx, imesh.v_pos.contiguous(), imesh.faces_i32(), rebuild=1)
         imesh = mesh.auto_normals(imesh)
+        self.last_mesh_sizes = (int(imesh.v_pos.shape[0]), int(imesh.t_pos_idx.shape[0]))
         out = {'imesh': imesh, 'sdf': sdf, 'msdf': extra['msdf'], 'msdf_watertight': extra['msdf_watertight'],
                'msdf_boundary': extra['msdf_boundary'], 'n_verts_watertight': extra['n_verts_watertight']}
         if getattr(self.FLAGS, "visualize_watertight", False):
@@ -178,7 +198,9 @@ class GShellTetsGeometry(torch.nn.Module):
         d = self.getMesh(opt_material)
         opt_mesh = d['imesh']
         if opt_mesh.v_pos.size(0) != 0 and opt_mesh.t_pos_idx.size(0) != 0:
-            d['sampled_pts'] = sample_points(opt_mesh.v_pos, opt_mesh.t_pos_idx, 50000)[0]
+            ns = getattr(self.FLAGS, 'noise_stream', None)       # seeded by (iteration) on every rank of a view-sharded job
+            gen = ns.generator('eikonal', opt_mesh.v_pos.device) if ns is not None else None
+            d['sampled_pts'] = sample_points(opt_mesh.v_pos, opt_mesh.t_pos_idx, 50000, generator=gen)[0]
         else:
             d['sampled_pts'] = None
         d['buffers'] = render.render_mesh(self.FLAGS, glctx, opt_mesh, target['mvp'], target['campos'], lgt, target['resolution'], spp=target['spp'],
@@ -221,16 +243,26 @@ class GShellTetsGeometry(torch.nn.Module):
             img_loss = img_loss + 5e-1 * F.l1_loss(msdf_img.clamp(max=0) * (gt_mask == 1).float(), torch.ones_like(gt_mask))
         depth_loss = torch.zeros((), device=dev)         # use_depth is off in every reference config
 
-        # ---- eikonal on the SDF network at surface samples (reference :302-324): double backward stays in torch
+        shard = getattr(FL, "view_shard", None)
+        world = shard.world if shard is not None else 1
+        presharded = torch.zeros((), device=dev)      # terms whose SUM over ranks is the single-GPU term (weight 1 in the sharded loss)
+
+        # ---- eikonal on the SDF network at surface samples (reference :302-324)
         if FL.use_sdf_mlp and FL.use_eikonal and d['sampled_pts'] is not None:
-            v = d['sampled_pts'].detach().requires_grad_(True)
-            sdf_eik = self.sdf_net(v)
+            pts = d['sampled_pts'].detach()
+            n_total = pts.shape[0]
+            if world > 1:      # identical sample set on every rank (seeded): rank r differentiates samples r, r + world, ...
+                pts = pts[shard.rank::world]
             if FL.eikonal_scale is None:
                 eik_coeff = 3e-1 if iteration < 500 else (1e-1 if iteration < 2000 else 1e-2)
             else:
                 eik_coeff = FL.eikonal_scale
-            grad = torch.autograd.grad(sdf_eik.sum(), v, create_graph=True)[0]
-            eik_loss = eik_coeff * (grad.pow(2).sum(dim=-1).sqrt() - 1).pow(2).mean()
+            eik_sum = eikonal_sq_sum(self.sdf_net, pts)
+            if world > 1:
+                presharded = presharded + eik_coeff * eik_sum / n_total
+                eik_loss = torch.zeros((), device=dev)
+            else:
+                eik_loss = eik_coeff * eik_sum / n_total
         else:
             eik_loss = torch.zeros((), device=dev)
 
@@ -247,8 +279,7 @@ class GShellTetsGeometry(torch.nn.Module):
                 with torch.no_grad():
                     nwt = d['n_verts_watertight']
                     vis_tris = buffers['visible_triangles']
-                    shard = getattr(FL, "view_shard", None)
-                    if shard is not None and shard.world > 1:     # union of the triangles seen by ANY view of the global batch
+                    if world > 1:     # union of the triangles seen by ANY view of the global batch
                         flags = torch.zeros(d['imesh'].t_pos_idx.size(0), dtype=torch.int32, device=dev)
                         flags[vis_tris] = 1
                         shard.all_reduce_max(flags)
@@ -267,6 +298,18 @@ class GShellTetsGeometry(torch.nn.Module):
 
         if 'diffuse_light' not in buffers:
             monochrome = torch.zeros_like(img_loss)
+        elif fs is not None and 'specular_light' in buffers and world > 1:
+            # the specular / diffuse energy ratio is a ratio of GLOBAL-batch means (regularizer.py:43-51): all-reduce the two
+            # luma sums (no_grad) and back-propagate the linearisation  d(S4/S5) = ds4_r / S5 - S4 / S5^2 ds5_r  per rank;
+            # the values sum to the global ratio over the ranks, the gradients sum to its gradient
+            with torch.no_grad():
+                S = torch.stack((fs[4], fs[5]))
+                shard.all_reduce_sum(S)
+            n_glob = n_px * world
+            ratio = fs[4] / S[1] - (S[0] / (S[1] * S[1])) * (fs[5] - fs[5].detach())
+            clamped = fs[4] / (1e-3 * n_glob)
+            presharded = presharded + torch.where(S[1] / n_glob >= 1e-3, ratio, clamped) * FL.lambda_specular
+            monochrome = fs[3] / n_px * FL.lambda_diffuse
         elif fs is not None and 'specular_light' in buffers:
             monochrome = fs[3] / n_px * FL.lambda_diffuse + (fs[4] / n_px) / (fs[5] / n_px).clamp_min(1e-3) * FL.lambda_specular
         else:
@@ -278,7 +321,9 @@ class GShellTetsGeometry(torch.nn.Module):
             mtl_smooth = regularizer.material_smoothness_grad(buffers['kd_grad'], buffers['ks_grad'], buffers['normal_grad'], lambda_kd=FL.lambda_kd,
                                                               lambda_ks=FL.lambda_ks, lambda_nrm=FL.lambda_nrm)
         chroma = regularizer.chroma_loss(buffers['kd'], color_ref, FL.lambda_chroma) if FL.lambda_chroma != 0 else torch.zeros_like(img_loss)
-        reg_loss = (sdf_reg + eik_loss + msdf_reg) + (monochrome + mtl_smooth + chroma)
-        # decomposition for view-sharded training: per-view means vs. terms that do not depend on the local views
-        self.last_terms = {'per_view': img_loss + monochrome + mtl_smooth + chroma, 'global': sdf_reg + eik_loss + msdf_reg}
+        reg_loss = (sdf_reg + eik_loss + msdf_reg) + (monochrome + mtl_smooth + chroma) + presharded
+        # decomposition for view-sharded training: per-view means, terms that do not depend on the local views (identical on
+        # every rank), and terms already split over the ranks (eikonal samples, linearised energy ratio)
+        self.last_terms = {'per_view': img_loss + monochrome + mtl_smooth + chroma, 'global': sdf_reg + eik_loss + msdf_reg,
+                           'presharded': presharded}
         return img_loss, depth_loss, reg_loss

@@ -153,6 +153,8 @@ class MLP(nn.Module):
             layers += [nn.Linear(d_hidden + (self.emb.out_channels if wide else 0), d_hidden), nn.Softplus(beta=100)]
         layers.append(nn.Linear(d_hidden, d_out))
         self.net = nn.ModuleList(layers)
+        if use_float16:     # reference geometry/mlp.py:36-38 autocasts; this path computes fp32 only -- never ignore the flag silently
+            raise NotImplementedError("use_float16=True is not supported by the fp32 MFMA path (the G-Shell scripts set it False)")
         self.use_float16 = use_float16
 
     def forward(self, x):
@@ -223,21 +225,71 @@ class _RowSparseBackward(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_y):
         (x,) = ctx.saved_tensors
-        net = ctx.net
-        params = [p for p in net.parameters()]
-        rows = torch.nonzero(g_y.reshape(x.shape[0], -1).abs().sum(dim=1) != 0).reshape(-1)      # one host sync
+        g_x, g_params = row_sparse_backward(ctx.net, x, g_y, ctx.needs_input_grad[0])
+        return (g_x, None) + tuple(g_params)
+
+
+def row_sparse_backward(net, x, g_y, need_x):
+    """(d loss / d x [N,3] or None, [d loss / d p for p in net.parameters()]) from the upstream gradient g_y [N,1],
+    touching only the rows where g_y != 0 (they are recomputed; the forward pass keeps no activations)."""
+    params = [p for p in net.parameters()]
+    rows = torch.nonzero(g_y.reshape(x.shape[0], -1).abs().sum(dim=1) != 0).reshape(-1)      # one host sync
+    g_x = torch.zeros_like(x) if need_x else None
+    if rows.numel() == 0:
+        return g_x, [torch.zeros_like(p) for p in params]
+    x_a = x[rows].detach().requires_grad_(need_x)
+    with torch.enable_grad():
+        y_a = net(x_a)
+        grads = torch.autograd.grad(y_a, ([x_a] if need_x else []) + params, g_y[rows], allow_unused=True)
+    if need_x:
+        g_x[rows] = grads[0]
+        grads = grads[1:]
+    return g_x, [torch.zeros_like(p) if g is None else g for p, g in zip(params, grads)]
+
+
+class _RowShardedForward(torch.autograd.Function):
+    """View-sharded jobs ("shard MLP rows across ranks + all-gather sdf [N]"): rank r evaluates the grid rows
+    [r * per, (r + 1) * per) through the fused kernel and all-gathers the N signed distances (8.8 MB at tet-res 256) -- the
+    16 ms full-grid forward stops being replicated.  Backward: the upstream gradients of all ranks are reduce-scattered
+    (sum) onto the owning rank, which runs the row-sparse backward on ITS rows; the parameter / input gradients are partial
+    sums that the trainer's flat all-reduce completes.  Every rank sees bit-identical sdf values (gathered, not recomputed),
+    so the replicated extraction still yields identical meshes."""
+
+    @staticmethod
+    def forward(ctx, x, net, shard, *params):
+        N, world, rank = x.shape[0], shard.world, shard.rank
+        per = (N + world - 1) // world
+        lo, hi = min(rank * per, N), min((rank + 1) * per, N)
+        with torch.no_grad():
+            x_loc = x[lo:hi].contiguous()
+            y_loc = (fused_forward(net, x_loc) if _fusable(net, x_loc) else net(x_loc)).reshape(-1)
+            pad = torch.zeros(per, dtype=y_loc.dtype, device=y_loc.device)
+            pad[:hi - lo] = y_loc
+            y_full = shard.all_gather_rows(pad)
+        ctx.net, ctx.shard, ctx.range = net, shard, (lo, hi, per)
+        ctx.save_for_backward(x)
+        return y_full[:N, None].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_y):
+        (x,) = ctx.saved_tensors
+        lo, hi, per = ctx.range
+        N, world = x.shape[0], ctx.shard.world
+        g_pad = torch.zeros(per * world, dtype=g_y.dtype, device=g_y.device)
+        g_pad[:N] = g_y.reshape(-1)
+        g_loc = ctx.shard.reduce_scatter_sum(g_pad)[:hi - lo]
         need_x = ctx.needs_input_grad[0]
-        g_x = torch.zeros_like(x) if need_x else None
-        if rows.numel() == 0:
-            return (g_x, None) + tuple(torch.zeros_like(p) for p in params)
-        x_a = x[rows].detach().requires_grad_(need_x)
-        with torch.enable_grad():
-            y_a = net(x_a)
-            grads = torch.autograd.grad(y_a, ([x_a] if need_x else []) + params, g_y[rows], allow_unused=True)
+        g_x_loc, g_params = row_sparse_backward(ctx.net, x[lo:hi].contiguous(), g_loc[:, None], need_x)
+        g_x = None
         if need_x:
-            g_x[rows] = grads[0]
-            grads = grads[1:]
-        return (g_x, None) + tuple(torch.zeros_like(p) if g is None else g for p, g in zip(params, grads))
+            g_x = torch.zeros_like(x)
+            g_x[lo:hi] = g_x_loc
+        return (g_x, None, None) + tuple(g_params)
+
+
+def forward_row_sharded(net, x, shard):
+    """net(x) with rows sharded over the ranks of `shard` (see _RowShardedForward)."""
+    return _RowShardedForward.apply(x, net, shard, *list(net.parameters()))
 
 
 def forward_row_sparse_backward(net, x):

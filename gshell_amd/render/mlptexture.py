@@ -142,6 +142,8 @@ class _MLP(torch.nn.Module):
 class MLPTexture3D(torch.nn.Module):
     def __init__(self, AABB, channels=3, internal_dims=32, hidden=2, min_max=None, use_float16=False):
         super().__init__()
+        if use_float16:
+            raise NotImplementedError("use_float16=True is not supported (fp32 hash grid + fp32 texture MLP)")
         self.channels, self.internal_dims, self.AABB, self.min_max, self.use_float16 = channels, internal_dims, AABB, min_max, use_float16
         desired_resolution, base_grid_resolution, num_levels = 4096, 16, 16
         per_level_scale = np.exp(np.log(desired_resolution / base_grid_resolution) / (num_levels - 1))

@@ -82,20 +82,20 @@ def set_random_perm(n_samples_x, table):
 
 class _optix_env_shade_func(torch.autograd.Function):
     @staticmethod
-    def _launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n, seed, shadow_scale, dims, vis, diff, spec):
+    def _launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n, seed, shadow_scale, dims, vis, diff, spec, view_map=(0, 1)):
         L = _lib.lib()
         B, H, W = dims
         n_cov = pix.shape[0]
         scratch = torch.empty((max(int(L.gs_env_shade_scratch_bytes(c_int64(n_cov), c_int(n))), 8) + 7) // 8, dtype=torch.int64, device=pix.device)
         check(L.gs_env_shade_fwd(optix_ctx.handle, ptr(pix, torch.int32), c_int64(n_cov), ptr(t["ro"]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view),
                                  ptr(t["kd"]), ptr(t["ks"]), ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]), c_int64(lgt.shape[1]),
-                                 ptr(perms, torch.int32), c_int64(perms.shape[0]), c_int64(B), c_int64(H), c_int64(W), c_int(BSDF), c_int(n),
-                                 c_uint32(seed & 0xFFFFFFFF), c_float(shadow_scale), ptr(scratch), ptr(vis), ptr(diff), ptr(spec), stream()),
+                                 ptr(perms, torch.int32), c_int64(perms.shape[0]), c_int64(B), c_int64(H), c_int64(W), c_int64(view_map[0]), c_int64(view_map[1]),
+                                 c_int(BSDF), c_int(n), c_uint32(seed & 0xFFFFFFFF), c_float(shadow_scale), ptr(scratch), ptr(vis), ptr(diff), ptr(spec), stream()),
               "gs_env_shade_fwd")
 
     @staticmethod
     def forward(ctx, optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, BSDF, n_samples_x, rnd_seed,
-                shadow_scale):
+                shadow_scale, view_map=(0, 1)):
         L = _lib.lib()
         _rnd_seed = int(np.random.randint(2 ** 31)) if rnd_seed is None else int(rnd_seed)
         B, H, W, _ = gb_pos.shape
@@ -117,8 +117,9 @@ class _optix_env_shade_func(torch.autograd.Function):
         vis = torch.empty((int(L.gs_env_shade_vis_words(c_int64(pix.shape[0]), c_int(n_samples_x))),), dtype=torch.int64, device=dev)
         with torch.cuda.device(dev):
             _optix_env_shade_func._launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, _rnd_seed, shadow_scale,
-                                              (B, H, W), vis, diff, spec)
+                                              (B, H, W), vis, diff, spec, view_map)
         ctx.args = (optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, rnd_seed, _rnd_seed, shadow_scale, vis)
+        ctx.view_map = view_map
         ctx.shapes = (gb_pos.shape, gb_normal.shape, gb_kd.shape, gb_ks.shape, light.shape)
         return diff, spec
 
@@ -136,13 +137,13 @@ class _optix_env_shade_func(torch.autograd.Function):
                 _rnd_seed = int(np.random.randint(2 ** 31))
                 vis = torch.empty_like(vis)
                 _optix_env_shade_func._launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, _rnd_seed,
-                                                  shadow_scale, (B, H, W), vis, None, None)
+                                                  shadow_scale, (B, H, W), vis, None, None, ctx.view_map)
             else:
                 _rnd_seed = _fwd_seed      # same seed -> same rays -> the cached visibility bits are exact
             check(_lib.lib().gs_env_shade_bwd(optix_ctx.handle, ptr(pix), c_int64(pix.shape[0]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view), ptr(t["kd"]),
                                               ptr(t["ks"]), ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]),
                                               c_int64(lgt.shape[1]), ptr(perms), c_int64(perms.shape[0]), c_int64(B), c_int64(H), c_int64(W),
-                                              c_int(BSDF), c_int(n_samples_x), c_uint32(_rnd_seed & 0xFFFFFFFF), c_float(shadow_scale), ptr(vis),
+                                              c_int64(ctx.view_map[0]), c_int64(ctx.view_map[1]), c_int(BSDF), c_int(n_samples_x), c_uint32(_rnd_seed & 0xFFFFFFFF), c_float(shadow_scale), ptr(vis),
                                               ptr(gd), ptr(gs), ptr(g_pos), ptr(g_nrm), ptr(g_kd), ptr(g_ks), ptr(g_light), stream()),
                   "gs_env_shade_bwd")
         s = ctx.shapes
@@ -150,15 +151,17 @@ class _optix_env_shade_func(torch.autograd.Function):
         def red(g, shape):
             return g if tuple(shape) == tuple(g.shape) else g.sum_to_size(shape)
         return (None, None, None, red(g_pos, s[0]), red(g_nrm, s[1]), None, red(g_kd, s[2]), red(g_ks, s[3]), g_light, None, None, None, None, None,
-                None, None)
+                None, None, None)
 
 
 def optix_env_shade(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, BSDF='pbr', n_samples_x=8,
-                    rnd_seed=None, shadow_scale=1.0):
-    """-> (diffuse [B,H,W,3], specular [B,H,W,3]) demodulated radiance (ops.py:141-143)."""
+                    rnd_seed=None, shadow_scale=1.0, view_offset=0, view_stride=1):
+    """-> (diffuse [B,H,W,3], specular [B,H,W,3]) demodulated radiance (ops.py:141-143).
+    `view_offset`, `view_stride` (not in the reference, which is single-GPU): local view b is view b*stride + offset of the
+    global batch -- the sampler hashes the GLOBAL pixel index so that view-sharded ranks draw the single-GPU samples."""
     iBSDF = _BSDF_IDS.index(BSDF)
     return _optix_env_shade_func.apply(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, iBSDF,
-                                       n_samples_x, rnd_seed, shadow_scale)
+                                       n_samples_x, rnd_seed, shadow_scale, (int(view_offset), int(view_stride)))
 
 
 class _bilateral_denoiser_func(torch.autograd.Function):

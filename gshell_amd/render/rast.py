@@ -260,21 +260,29 @@ class _AntialiasFn(torch.autograd.Function):
         return g_color, g_pos, None, None, None, None
 
 
-_aa_cache = {"key": None, "topo": None, "alpha": None}
+_aa_cache = {"key": None, "refs": None, "topo": None, "alpha": None}
 
 
 def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):
-    """dr.antialias drop-in.  The adjacency table and the silhouette analysis are cached across the
-    per-buffer calls of one render (same rast / pos / tri tensors)."""
+    """dr.antialias drop-in.  The adjacency table and the silhouette analysis are cached across the per-buffer calls of
+    ONE render: the entry is keyed on the identity of the rast / pos / tri tensor OBJECTS and holds strong references to
+    them, so the caching allocator cannot hand their addresses to the next iteration's tensors while the entry is alive
+    (data_ptr / _version alone can collide across iterations: kernel-written tensors keep _version 0)."""
     if pos_gradient_boost != 1.0:
         raise NotImplementedError("pos_gradient_boost is not used by the reference")
     if tri.shape[0] == 0:
         return color
-    key = (rast.data_ptr(), rast._version, pos.data_ptr(), pos._version, tri.data_ptr(), tuple(rast.shape), tuple(tri.shape))
-    if _aa_cache["key"] != key:
+    key = (id(rast), rast._version, id(pos), pos._version, id(tri), tri._version, tuple(rast.shape), tuple(pos.shape), tuple(tri.shape))
+    refs = _aa_cache["refs"]
+    if _aa_cache["key"] != key or refs is None or refs[0] is not rast or refs[1] is not pos or refs[2] is not tri:
         topo = topology_hash if isinstance(topology_hash, AATopology) else AATopology(tri, pos.shape[1])
-        _aa_cache.update(key=key, topo=topo, alpha=aa_analyze(rast, pos, tri, topo))
+        _aa_cache.update(key=key, refs=(rast, pos, tri), topo=topo, alpha=aa_analyze(rast, pos, tri, topo))
     return _AntialiasFn.apply(color, pos, rast, tri, _aa_cache["topo"], _aa_cache["alpha"])
+
+
+def antialias_cache_clear():
+    """Drop the cached analysis (and the references that keep its rast / pos / tri alive)."""
+    _aa_cache.update(key=None, refs=None, topo=None, alpha=None)
 
 
 def antialias_stacked(colors, rast, pos, tri, topo=None):

@@ -25,9 +25,48 @@ rnd_seed = 0
 noise_override = None
 
 
-def _noise(name, draw):
+class NoiseStream:
+    """Counter-based source of the render noise (jitter / texture / tangent tensors) and of the eikonal surface samples for
+    view-sharded training (SURVEY.md 8e ii, iv): every draw is a function of (seed, iteration, name, GLOBAL view index),
+    so rank r of an N-GPU job sees exactly the rows r, r + N, ... of the tensor the single-GPU job draws.  The reference
+    is single-GPU and draws from the global torch RNG (render/render.py:55, :68, :265); that stays the default when
+    FLAGS carries no `noise_stream`."""
+    _IDS = {'jitter': 1, 'texture': 2, 'tangent': 3, 'eikonal': 4}
+
+    def __init__(self, seed=0, rank=0, world=1):
+        self.seed, self.rank, self.world, self.it = int(seed), int(rank), int(world), 0
+        self._gens = {}
+
+    def set_iteration(self, it):
+        self.it = int(it)
+
+    def generator(self, name, device):
+        g = self._gens.get(str(device))
+        if g is None:
+            g = self._gens[str(device)] = torch.Generator(device=device)
+        g.manual_seed((self.seed * 1000003 + self.it) * 16 + self._IDS[name])
+        return g
+
+    def normal(self, name, std, size, device):
+        """[B_local, ...] rows of the [B_local * world, ...] global-batch draw."""
+        full = torch.randn((size[0] * self.world,) + tuple(size[1:]), device=device, generator=self.generator(name, device))
+        if self.world > 1:
+            full = full[self.rank::self.world]
+        return (full * std).contiguous() if std != 1.0 else full.contiguous()
+
+    def state_dict(self):
+        return {'seed': self.seed, 'it': self.it}
+
+    def load_state_dict(self, sd):
+        self.seed, self.it = int(sd['seed']), int(sd['it'])
+
+
+def _noise(name, draw, FLAGS=None, std=1.0, size=None, device=None):
     if noise_override is not None and name in noise_override:
         return noise_override[name]
+    ns = getattr(FLAGS, 'noise_stream', None) if FLAGS is not None else None
+    if ns is not None:
+        return ns.normal(name, std, size, device)
     return draw()
 
 
@@ -40,6 +79,12 @@ def _const_011(dev):
     if key not in _consts:
         _consts[key] = torch.tensor([0, 1, 1], dtype=torch.float32, device=dev)[None, None, None, :]
     return _consts[key]
+
+
+def _view_map(FLAGS):
+    """Global view index of local view b = b * world + rank under the round-robin view shard (train.ViewShard)."""
+    sh = getattr(FLAGS, 'view_shard', None)
+    return {'view_offset': sh.rank, 'view_stride': sh.world} if sh is not None and sh.world > 1 else {}
 
 
 def interpolate(attr, rast, attr_idx, rast_db=None):
@@ -61,7 +106,7 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
           mesh, bsdf, denoiser, shadow_scale, use_uv=True, finetune_normal=True, xfm_lgt=None, shade_data=False):
     dev = gb_pos.device
     B, H, W = gb_depth.shape[0], gb_depth.shape[1], gb_depth.shape[2]
-    offset = _noise('jitter', lambda: torch.normal(mean=0, std=0.005, size=(B, H, W, 2), device=dev))
+    offset = _noise('jitter', lambda: torch.normal(mean=0, std=0.005, size=(B, H, W, 2), device=dev), FLAGS, 0.005, (B, H, W, 2), dev)
     jitter = (util.pixel_grid(W, H, device=dev)[None, ...] + offset).contiguous()
 
     mask = (rast[..., -1:] > 0).float()
@@ -71,7 +116,7 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
     # ---- texture lookups ------------------------------------------------------------------------
     perturbed_nrm = None
     if 'kd_ks' in material:
-        noise = _noise('texture', lambda: torch.normal(mean=0, std=0.01, size=gb_pos.shape, device=dev))
+        noise = _noise('texture', lambda: torch.normal(mean=0, std=0.01, size=gb_pos.shape, device=dev), FLAGS, 0.01, tuple(gb_pos.shape), dev)
         all_tex_jitter = _sample_texture(material['kd_ks'], gb_pos + noise, mask)
         all_tex = _sample_texture(material['kd_ks'], gb_pos, mask)
         assert all_tex.shape[-1] == 6, "Combined kd_ks must be 6 channels"
@@ -105,7 +150,8 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
         global rnd_seed
         diffuse_accum, specular_accum = ou.optix_env_shade(optix_ctx, rast[..., -1], ro, gb_pos, gb_normal, view_pos, kd, ks, lgt.base, lgt._pdf,
                                                            lgt.rows[:, 0], lgt.cols, BSDF=bsdf, n_samples_x=FLAGS.n_samples,
-                                                           rnd_seed=None if FLAGS.decorrelated else rnd_seed, shadow_scale=shadow_scale)
+                                                           rnd_seed=None if FLAGS.decorrelated else rnd_seed, shadow_scale=shadow_scale,
+                                                           **_view_map(FLAGS))
         rnd_seed += 1
         if denoiser is not None and FLAGS.denoiser_demodulate:
             diffuse_accum = denoiser.forward(torch.cat((diffuse_accum, gb_normal, gb_depth), dim=-1))
@@ -176,7 +222,7 @@ def render_layer(FLAGS, v_pos_clip, rast, rast_deriv, mesh, view_pos, lgt, resol
     gb_geometric_normal = dr.face_normals(mesh.v_pos, tri, rast_out_s)
 
     with torch.no_grad():
-        noise = _noise('tangent', lambda: torch.randn_like(gb_normal))
+        noise = _noise('tangent', lambda: torch.randn_like(gb_normal), FLAGS, 1.0, tuple(gb_normal.shape), gb_normal.device)
         noise = noise / noise.norm(dim=-1, keepdim=True)
     gb_tangent = torch.cross(noise, gb_normal, dim=-1)       # only used to add isotropic noise (no uv maps)
     gb_texc, gb_texc_deriv = None, None

@@ -9,12 +9,13 @@ RCCL all-reduce of the flattened gradient per iteration.
 """
 import types
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 from .denoiser.denoiser import BilateralDenoiser
 from .geometry.gshell_tets_geometry import GShellTetsGeometry
-from .render import light, mlptexture
+from .render import light, mlptexture, render
 from .render import rast as dr
 from .render import renderutils as ru
 
@@ -30,7 +31,7 @@ def default_flags(**overrides):
         lambda_kd=0.1, lambda_ks=0.05, lambda_nrm=0.025, lambda_chroma=0.0, lambda_diffuse=0.15, lambda_specular=0.0025,
         use_tanh_deform=False, use_sdf_mlp=True, use_msdf_mlp=False, use_eikonal=True, sdf_mlp_pretrain_steps=1000, use_mesh_msdf_reg=True,
         sphere_init=False, sphere_init_norm=0.5, n_hidden=6, d_hidden=256, n_freq=6, skip_in=[3], use_float16=False, visualize_watertight=False,
-        boxscale=[1, 1, 1], use_depth=False, use_img_2nd_layer=False, view_shard=None)
+        boxscale=[1, 1, 1], use_depth=False, use_img_2nd_layer=False, view_shard=None, shard_mlp_rows=True, seed=0)
     for k, v in overrides.items():
         setattr(F, k, v)
     return F
@@ -61,6 +62,33 @@ class ViewShard:
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
+
+    def _backend(self):
+        return dist.get_backend(self.group) if self.world > 1 else None
+
+    def all_gather_rows(self, local):
+        """[per] on every rank -> [per * world] (rank-major).  One RCCL all-gather; list form on gloo (CPU tests)."""
+        if self.world == 1:
+            return local
+        out = torch.empty(local.numel() * self.world, dtype=local.dtype, device=local.device)
+        if self._backend() == "nccl":
+            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+        else:
+            dist.all_gather(list(out.chunk(self.world)), local.contiguous(), group=self.group)
+        return out
+
+    def reduce_scatter_sum(self, full):
+        """[per * world] on every rank -> sum over ranks of this rank's [per] slice."""
+        if self.world == 1:
+            return full
+        per = full.numel() // self.world
+        if self._backend() == "nccl":
+            out = torch.empty(per, dtype=full.dtype, device=full.device)
+            dist.reduce_scatter_tensor(out, full.contiguous(), op=dist.ReduceOp.SUM, group=self.group)
+            return out
+        full = full.clone()
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
+        return full[self.rank * per:(self.rank + 1) * per]
 
     def broadcast(self, tensors, src=0):
         """Make replicated state bit-identical on every rank (parameters after a pre-fit whose GPU reductions are not
@@ -100,10 +128,12 @@ def flat_all_reduce_grads(params, shard, buf=None):
     return buf
 
 
-def sharded_total_loss(per_view, global_terms, B_local, B_global, world):
+def sharded_total_loss(per_view, global_terms, B_local, B_global, world, presharded=None):
     """Loss a rank back-propagates so that the SUM of all ranks' gradients equals the single-GPU gradient of
-    mean-over-global-batch(per-view terms) + view-independent terms."""
-    return per_view * (B_local / B_global) + global_terms / world
+    mean-over-global-batch(per-view terms) + view-independent terms.  `presharded` terms are already
+    divided over the ranks by construction (each rank owns a disjoint part of a sum) and enter with weight 1."""
+    total = per_view * (B_local / B_global) + global_terms / world
+    return total if presharded is None else total + presharded
 
 
 def initial_guess_material(geometry, FLAGS):
@@ -119,6 +149,8 @@ class Trainer:
         self.FLAGS = FLAGS
         self.shard = shard or ViewShard()
         FLAGS.view_shard = self.shard
+        # render noise + eikonal samples as functions of (seed, iteration, global view) -- 1-GPU step == N-GPU step
+        FLAGS.noise_stream = render.NoiseStream(getattr(FLAGS, 'seed', 0), self.shard.rank, self.shard.world)
         self.glctx = dr.RasterizeGLContext()
         self.lgt = light.create_trainable_env_rnd(FLAGS.probe_res, scale=0.0, bias=0.5)      # train script :656
         self.denoiser = BilateralDenoiser().cuda() if FLAGS.denoiser == 'bilateral' else None
@@ -152,33 +184,49 @@ class Trainer:
         self.shard.broadcast(self.all_params())
         self.lgt.update_pdf()
 
+    def parallelism(self):
+        w = self.shard.world
+        if w == 1:
+            return "single GPU"
+        rows = "SDF-MLP rows + eikonal samples sharded (all-gather sdf[N])" if getattr(self.FLAGS, "shard_mlp_rows", False) else "geometry replicated"
+        return f"view-shard dp{w}, {rows}, one flat RCCL all-reduce of the gradient"
+
     def all_params(self):
         return [p for g in self.opt_mesh.param_groups for p in g['params']] + self.mat_params + list(self.lgt.parameters())
 
     def _all_reduce_grads(self):
         self._flat = flat_all_reduce_grads([p for p in self.all_params() if p.requires_grad], self.shard, self._flat)
 
-    def step(self, target, global_batch=None):
-        """`target` holds THIS rank's views; `global_batch` = number of views over all ranks (default: local)."""
+    def forward_backward(self, target, global_batch=None):
+        """zero_grad -> update_pdf -> tick -> backward (-> gradient all-reduce): leaves the GLOBAL-batch gradient in .grad
+        on every rank.  `target` holds THIS rank's views; `global_batch` = views over all ranks (default: local x world)."""
         for o in (self.opt_mat, self.opt_mesh, self.opt_light):
             o.zero_grad()
         self.lgt.update_pdf()
+        self.FLAGS.noise_stream.set_iteration(self.it)
         img_loss, depth_loss, reg_loss = self.geometry.tick(self.glctx, target, self.lgt, self.mat, self.loss_fn, self.it, denoiser=self.denoiser)
         if self.shard.world > 1:
             B_local = target['mvp'].shape[0]
             B = global_batch or B_local * self.shard.world
             t = self.geometry.last_terms
-            total = sharded_total_loss(t['per_view'], t['global'], B_local, B, self.shard.world)
+            total = sharded_total_loss(t['per_view'], t['global'], B_local, B, self.shard.world, t.get('presharded'))
         else:
             total = img_loss + reg_loss
         total.backward()
         if self.shard.world > 1:
             self._all_reduce_grads()
+        return img_loss, reg_loss
+
+    def step(self, target, global_batch=None):
+        img_loss, reg_loss = self.forward_backward(target, global_batch)
         if self.lgt.base.grad is not None:
             self.lgt.base.grad *= 64                                   # train script :433
         enc = self.mat['kd_ks'].encoder.params
         if enc.grad is not None:
             enc.grad /= 8.0                                            # train script :435
+        if self.FLAGS.clip_max_norm > 0.0:                            # train script :440-444 (after the all-reduce: global gradient)
+            torch.nn.utils.clip_grad_norm_(self.geometry.parameters(), self.FLAGS.clip_max_norm)
+            torch.nn.utils.clip_grad_norm_(self.mat_params, self.FLAGS.clip_max_norm)
         self.opt_mat.step(); self.scheds[0].step()
         self.opt_mesh.step(); self.scheds[1].step()
         self.opt_light.step(); self.scheds[2].step()
@@ -197,6 +245,9 @@ class Trainer:
             'light': self.lgt.base.detach().clone(),       # [H,W,3] probe texels (the reference stores an .hdr, light.py:118-123)
             'opt': [o.state_dict() for o in (self.opt_mat, self.opt_mesh, self.opt_light)],
             'sched': [s.state_dict() for s in self.scheds],
+            # sampler / noise state: without it a resumed run restarts the shadow-ray seed and the noise streams at 0
+            'rnd_seed': render.rnd_seed, 'noise_stream': self.FLAGS.noise_stream.state_dict(),
+            'rng': {'torch': torch.get_rng_state(), 'cuda': torch.cuda.get_rng_state(self.geometry.verts.device), 'numpy': np.random.get_state()},
         }
 
     def load_state_dict(self, sd):
@@ -208,6 +259,12 @@ class Trainer:
         for o, s in zip(self.scheds, sd['sched']):
             o.load_state_dict(s)
         self.it = int(sd['it'])
+        if 'rnd_seed' in sd:
+            render.rnd_seed = int(sd['rnd_seed'])
+            self.FLAGS.noise_stream.load_state_dict(sd['noise_stream'])
+            torch.set_rng_state(sd['rng']['torch'].cpu())
+            torch.cuda.set_rng_state(sd['rng']['cuda'].cpu(), self.geometry.verts.device)
+            np.random.set_state(sd['rng']['numpy'])
         self.lgt.update_pdf()
 
     def save_checkpoint(self, path):

@@ -281,6 +281,9 @@ int gs_bvh_any_hit_stats(const gs_bvh* bvh, const float* origins, const float* d
  *   bwd: identical sampling with the cached visibility (no rays are traced):
  *        g_pos, g_normal, g_kd, g_ks [B,H,W,3] WRITTEN; g_light [Hl,Wl,3] ACCUMULATED (atomics).
  *   ro and view_pos receive no gradient, as in the reference (ops.py:108).
+ *   view_offset / view_stride: local view b is view  b*view_stride + view_offset  of the GLOBAL batch; the per-pixel
+ *        RNG stream hashes that global pixel index (kernel.cu:504), so a view-sharded N-GPU step draws exactly the
+ *        samples of the single-GPU step.  Single GPU: (0, 1).
  * ---------------------------------------------------------------------------------- */
 int64_t gs_env_shade_scratch_bytes(int64_t n_cov, int n_samples_x);
 int64_t gs_env_shade_vis_words(int64_t n_cov, int n_samples_x);
@@ -288,14 +291,16 @@ int gs_env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const
                      const float* gb_pos, const float* gb_normal, const float* view_pos,
                      const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
                      const float* rows, const float* cols, int64_t Hl, int64_t Wl,
-                     const int32_t* perms, int64_t P, int64_t B, int64_t H, int64_t W, int bsdf,
+                     const int32_t* perms, int64_t P, int64_t B, int64_t H, int64_t W,
+                     int64_t view_offset, int64_t view_stride, int bsdf,
                      int n_samples_x, uint32_t rnd_seed, float shadow_scale, void* scratch,
                      uint64_t* vis_bits, float* diff, float* spec, gs_stream_t stream);
 int gs_env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* gb_pos,
                      const float* gb_normal, const float* view_pos, const float* gb_kd,
                      const float* gb_ks, const float* light, const float* pdf, const float* rows,
                      const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P,
-                     int64_t B, int64_t H, int64_t W, int bsdf, int n_samples_x, uint32_t rnd_seed,
+                     int64_t B, int64_t H, int64_t W, int64_t view_offset, int64_t view_stride,
+                     int bsdf, int n_samples_x, uint32_t rnd_seed,
                      float shadow_scale, const uint64_t* vis_bits, const float* g_diff,
                      const float* g_spec, float* g_pos, float* g_normal, float* g_kd, float* g_ks,
                      float* g_light, gs_stream_t stream);
