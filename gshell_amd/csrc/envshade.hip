@@ -687,12 +687,102 @@ int fill_args(ShadeArgs& A, const gs_bvh* bvh, const int32_t* pix, int64_t n_cov
 }
 
 // ---- bilateral denoiser (denoising.cu:14-130) ---------------------------------------------------------
+// out(p) = sum_t w(p,t) col(t),  w = exp(-|p-t|^2 / 2 sigma^2) * clamp(n_p . n_t, 1e-4, 1)^128 * exp(-|z_t - z_p| / max(dz * |p-t|, 1e-4))
+// over the (2R+1)^2 window, R = 2 ceil(2.5 sigma) + 1 = 11 at the steady-state sigma = 2 (529 taps / pixel, 0.55 G taps per
+// 4 x 512^2 call).  The reference kernel re-fetches 8 floats per tap through the texture path and evaluates powf + 2 expf +
+// sqrtf per tap.  Here a 32 x 16 output tile is owned by a 512-thread workgroup that stages its (32+2R) x (16+2R) halo ONCE
+// into LDS as two float4 planes (normal.xyz, z | dz, rgb) -- 68 KB at R = 11, two workgroups per CU -- and then every tap is two
+// conflict-free ds_read_b128 (a wave = 2 tile rows of 32 consecutive pixels; the row stride is padded to 8 mod 16 pixels so the
+// two half-rows of a 16-lane service group land on different halves of the 256-byte bank row), x^128 as seven squarings, ONE
+// v_exp_f32 (the spatial Gaussian is folded into the exponent from a per-window-row LDS table) and ONE v_rcp_f32.
+// Pixels outside the image are staged with a zero normal: their weight is clamp(0)^128 = 0 exactly, as if skipped.
 constexpr float FLT_EPS_D = 0.0001f;
+constexpr int BIL_TX = 32, BIL_TY = 16, BIL_NT = BIL_TX * BIL_TY;
+constexpr float LOG2E = 1.4426950408889634f;
+
+__host__ __device__ inline int bil_row_stride(int R) {   // pixels; >= 32 + 2R, == 8 (mod 16)
+    int w = BIL_TX + 2 * R;
+    return w + ((8 - (w & 15)) & 15);
+}
 
 template <bool BWD>
-__global__ void __launch_bounds__(256) k_bilateral(const float* __restrict__ col, const float* __restrict__ nrm, const float* __restrict__ zdz,
-                                                   int64_t B, int H, int W, float sigma, int rad, float* __restrict__ out,
-                                                   const float* __restrict__ g_out, float* __restrict__ g_col) {
+__global__ void __launch_bounds__(BIL_NT, 2) k_bilateral_tile(const float* __restrict__ col, const float* __restrict__ nrm, const float* __restrict__ zdz,
+                                                               int H, int W, float sigma, int R, float* __restrict__ out,
+                                                               const float* __restrict__ g_out, float* __restrict__ g_col) {
+    extern __shared__ __attribute__((aligned(16))) float4 bil_smem[];
+    const int RS = bil_row_stride(R), TH = BIL_TY + 2 * R, TW = BIL_TX + 2 * R;
+    float4* sA = bil_smem;                 // [TH][RS]  (nx, ny, nz, z)
+    float4* sB = sA + TH * RS;             // [TH][RS]  (dz, c0, c1, c2)   c = colour (fwd) / upstream gradient (bwd)
+    float2* sT = reinterpret_cast<float2*>(sB + TH * RS);     // [(R+1)^2]  (log2e * d^2 / (2 sigma^2), d) for d^2 = fx^2 + fy^2
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * BIL_TX, y0 = blockIdx.y * BIL_TY;
+    const int64_t base = (int64_t)blockIdx.z * H * W;
+    for (int i = tid; i < (R + 1) * (R + 1); i += BIL_NT) {
+        int fy = i / (R + 1), fx = i - fy * (R + 1);
+        float d2 = (float)(fx * fx + fy * fy);
+        sT[i] = make_float2(d2 / (2.0f * sigma * sigma) * LOG2E, sqrtf(d2));
+    }
+    for (int i = tid; i < TH * TW; i += BIL_NT) {
+        int ty = i / TW, tx = i - ty * TW;
+        int x = x0 + tx - R, y = y0 + ty - R;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x >= 0 && x < W && y >= 0 && y < H) {
+            int64_t p = base + (int64_t)y * W + x;
+            float2 zz = *reinterpret_cast<const float2*>(zdz + 2 * p);
+            a = make_float4(nrm[3 * p], nrm[3 * p + 1], nrm[3 * p + 2], zz.x);
+            if (BWD) {
+                float4 g = *reinterpret_cast<const float4*>(g_out + 4 * p);
+                b = make_float4(zz.y, g.x, g.y, g.z);
+            } else
+                b = make_float4(zz.y, col[3 * p], col[3 * p + 1], col[3 * p + 2]);
+        }
+        sA[ty * RS + tx] = a;
+        sB[ty * RS + tx] = b;
+    }
+    __syncthreads();
+    const int lx = tid & (BIL_TX - 1), ly = tid / BIL_TX;
+    const int x = x0 + lx, y = y0 + ly;
+    const float4 ca = sA[(ly + R) * RS + lx + R];
+    const float cdz = sB[(ly + R) * RS + lx + R].x;
+    float acc_w = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    for (int fy = -R; fy <= R; ++fy) {
+        const float4* rowA = sA + (ly + R + fy) * RS + lx + R;
+        const float4* rowB = sB + (ly + R + fy) * RS + lx + R;
+        const float2* rowT = sT + (fy < 0 ? -fy : fy) * (R + 1);
+#pragma unroll 2
+        for (int fx = -R; fx <= R; ++fx) {
+            const float4 ta = rowA[fx];
+            const float4 tb = rowB[fx];
+            const float2 tt = rowT[fx < 0 ? -fx : fx];       // wave-uniform address: LDS broadcast
+            float d = __builtin_fmaf(ta.x, ca.x, __builtin_fmaf(ta.y, ca.y, ta.z * ca.z));
+            float wn = fminf(fmaxf(d, FLT_EPS_D), 1.0f);
+            wn *= wn; wn *= wn; wn *= wn; wn *= wn; wn *= wn; wn *= wn; wn *= wn;          // ^128
+            // the reference's backward uses the TAP's dz in the depth weight (denoising.cu:118); replicated
+            float den = fmaxf((BWD ? tb.x : cdz) * tt.y, FLT_EPS_D);
+            float q = fabsf(ta.w - ca.w) * __builtin_amdgcn_rcpf(den);
+            float w = wn * __builtin_amdgcn_exp2f(-__builtin_fmaf(q, LOG2E, tt.x));
+            ax = __builtin_fmaf(tb.y, w, ax);
+            ay = __builtin_fmaf(tb.z, w, ay);
+            az = __builtin_fmaf(tb.w, w, az);
+            if (!BWD) acc_w += w;
+        }
+    }
+    if (x >= W || y >= H) return;
+    const int64_t ci = base + (int64_t)y * W + x;
+    if (!BWD) {
+        *reinterpret_cast<float4*>(out + 4 * ci) = make_float4(ax, ay, az, fmaxf(acc_w, 0.0001f));
+    } else {
+        g_col[3 * ci] = ax;
+        g_col[3 * ci + 1] = ay;
+        g_col[3 * ci + 2] = az;
+    }
+}
+
+// Windows too wide for the LDS tile (sigma > ~3.5): one thread per pixel, taps through L1/L2 (the reference's structure).
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_bilateral_direct(const float* __restrict__ col, const float* __restrict__ nrm, const float* __restrict__ zdz,
+                                                          int64_t B, int H, int W, float sigma, int rad, float* __restrict__ out,
+                                                          const float* __restrict__ g_out, float* __restrict__ g_col) {
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     int64_t b = blockIdx.z;
     if (x >= W || y >= H) return;
@@ -715,7 +805,6 @@ __global__ void __launch_bounds__(256) k_bilateral(const float* __restrict__ col
             float dist = sqrtf(dist_sqr);
             float w_xy = expf(-dist_sqr / (2.0f * variance));
             float w_normal = powf(fminf(fmaxf(tnx * cnx + tny * cny + tnz * cnz, FLT_EPS_D), 1.0f), 128.0f);
-            // the reference's backward uses the TAP's dz in the depth weight (denoising.cu:118); replicated
             float w_depth = expf(-(fabsf(tz - cz) / fmaxf((BWD ? tdz : cdz) * dist, FLT_EPS_D)));
             float w = w_xy * w_normal * w_depth;
             if (!BWD) {
@@ -740,6 +829,30 @@ __global__ void __launch_bounds__(256) k_bilateral(const float* __restrict__ col
         g_col[3 * ci + 1] = ay;
         g_col[3 * ci + 2] = az;
     }
+}
+
+int bilateral_radius(float sigma) { return 2 * (int)std::ceil(sigma * 2.5f) + 1; }
+
+size_t bilateral_smem_bytes(int R) {
+    return (size_t)2 * (BIL_TY + 2 * R) * bil_row_stride(R) * sizeof(float4) + (size_t)(R + 1) * (R + 1) * sizeof(float2);
+}
+
+template <bool BWD>
+int launch_bilateral(const float* col, const float* nrm, const float* zdz, int64_t B, int64_t H, int64_t W, float sigma, float* out, const float* g_out,
+                     float* g_col, hipStream_t stream) {
+    const int R = bilateral_radius(sigma);
+    const size_t smem = bilateral_smem_bytes(R);
+    if (smem <= 80 * 1024) {      // two workgroups per CU (160 KB of LDS)
+        // set on every launch: the attribute is per device / per function, and a per-process flag would be neither
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bilateral_tile<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        dim3 grid((unsigned)gs::cdiv(W, BIL_TX), (unsigned)gs::cdiv(H, BIL_TY), (unsigned)B);
+        hipLaunchKernelGGL(k_bilateral_tile<BWD>, grid, dim3(BIL_NT), smem, stream, col, nrm, zdz, (int)H, (int)W, sigma, R, out, g_out, g_col);
+    } else {
+        dim3 grid((unsigned)gs::cdiv(W, 16), (unsigned)gs::cdiv(H, 16), (unsigned)B);
+        hipLaunchKernelGGL(k_bilateral_direct<BWD>, grid, dim3(256), 0, stream, col, nrm, zdz, B, (int)H, (int)W, sigma, R, out, g_out, g_col);
+    }
+    GS_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace
@@ -805,26 +918,16 @@ extern "C" int gs_env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n
     return 0;
 }
 
-static int bilateral_radius(float sigma) { return 2 * (int)std::ceil(sigma * 2.5f) + 1; }
-
 extern "C" int gs_bilateral_fwd(const float* col, const float* nrm, const float* zdz, int64_t B, int64_t H, int64_t W, float sigma, float* out,
                                 gs_stream_t stream) {
     if (B * H * W == 0) return 0;
     GS_REQUIRE(col && nrm && zdz && out && sigma > 0.f, "gs_bilateral_fwd: null pointer / sigma <= 0");
-    dim3 grid((unsigned)gs::cdiv(W, 16), (unsigned)gs::cdiv(H, 16), (unsigned)B);
-    hipLaunchKernelGGL(k_bilateral<false>, grid, dim3(256), 0, (hipStream_t)stream, col, nrm, zdz, B, (int)H, (int)W, sigma, bilateral_radius(sigma),
-                       out, (const float*)nullptr, (float*)nullptr);
-    GS_LAUNCH_CHECK();
-    return 0;
+    return launch_bilateral<false>(col, nrm, zdz, B, H, W, sigma, out, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int gs_bilateral_bwd(const float* nrm, const float* zdz, int64_t B, int64_t H, int64_t W, float sigma, const float* g_out, float* g_col,
                                 gs_stream_t stream) {
     if (B * H * W == 0) return 0;
     GS_REQUIRE(nrm && zdz && g_out && g_col && sigma > 0.f, "gs_bilateral_bwd: null pointer / sigma <= 0");
-    dim3 grid((unsigned)gs::cdiv(W, 16), (unsigned)gs::cdiv(H, 16), (unsigned)B);
-    hipLaunchKernelGGL(k_bilateral<true>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, nrm, zdz, B, (int)H, (int)W, sigma,
-                       bilateral_radius(sigma), (float*)nullptr, g_out, g_col);
-    GS_LAUNCH_CHECK();
-    return 0;
+    return launch_bilateral<true>(nullptr, nrm, zdz, B, H, W, sigma, nullptr, g_out, g_col, (hipStream_t)stream);
 }

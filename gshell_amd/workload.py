@@ -80,9 +80,10 @@ def make_targets(trainer, view_ids, res, seed=1):
     dev = trainer.geometry.verts.device
     H, W = res
     mvp, campos = views(view_ids, dev)
-    g = torch.Generator(device=dev).manual_seed(seed)
     B = len(view_ids)
-    bg = torch.rand(B, 1, 1, 3, device=dev, generator=g).expand(B, H, W, 3).contiguous()
+    g = torch.Generator(device=dev)
+    # background colour = function of the VIEW id (not of its position in this rank's shard)
+    bg = torch.stack([torch.rand(1, 1, 3, device=dev, generator=g.manual_seed(seed * 7919 + int(v))) for v in view_ids]).expand(B, H, W, 3).contiguous()
     target = {'mvp': mvp, 'campos': campos, 'resolution': [H, W], 'spp': 1, 'background': bg}
     with torch.no_grad():
         base = trainer.lgt.base.detach().clone()
