@@ -210,11 +210,8 @@ extern "C" int gs_sdf_mlp_fwd(const float* x, int64_t N, const float* packed, in
         A.bias[i] = p; p += D;
     }
     A.w_out = p;
-    static bool attr_set = false;
-    if (!attr_set) {
-        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sdf_mlp_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES));
-        attr_set = true;
-    }
+    // per launch: the attribute is per device, and a process-wide "done" flag would be neither per-device nor thread-safe
+    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sdf_mlp_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES));
     hipLaunchKernelGGL(k_sdf_mlp_fwd, dim3((unsigned)gs::cdiv(N, TM)), dim3(NT), SMEM_BYTES, (hipStream_t)stream, A);
     GS_LAUNCH_CHECK();
     return 0;

@@ -191,13 +191,58 @@ def pack_weights(net):
     return torch.cat(parts).contiguous().float(), len(lin) - 2, skip
 
 
-def fused_forward(net, x):
-    """sdf = net(x) through the fused MFMA kernel (no autograd)."""
-    packed, n_hidden, skip = pack_weights(net)
+# Arithmetic of the fused full-grid forward pass:
+#   "h2"   (default) csrc/mlp_h2.hip -- fp16-pair operands on the f16 matrix path, three MFMAs per product, fp32 accumulate;
+#          operands represented to 2^-22, measured max |err| vs float64 within 2x of the fp32 kernel's own
+#   "fp32" csrc/mlp.hip -- v_mfma_f32_32x32x2_f32, bitwise a k-ordered fmaf chain, 4x slower; kept as the oracle of "h2"
+SDF_MLP_PRECISION = "h2"
+
+
+def _layer_structure(net):
+    lin = [m for m in net.net if isinstance(m, nn.Linear)]
+    skip = -1
+    if net.skip_count:
+        skip = [i for i, m in enumerate(net.net) if isinstance(m, nn.Linear)].index(net.skip_count[0])
+    return lin, len(lin) - 2, skip
+
+
+def pack_weights_h2(net):
+    """Device buffer in the layout of gs_sdf_mlp_fwd_h2: ONE launch that reads the module's parameters in place."""
+    import ctypes
+    lin, n_hidden, skip = _layer_structure(net)
     L = _lib.lib()
-    assert packed.numel() == L.gs_sdf_mlp_packed_floats(c_int(net.emb.N_freqs), c_int(n_hidden), c_int(skip))
+    nf = net.emb.N_freqs
+    dev = lin[0].weight.device
+    nbytes = int(L.gs_sdf_mlp_h2_packed_bytes(c_int(nf), c_int(n_hidden), c_int(skip)))
+    packed = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
+    ws = [m.weight.detach() for m in lin]
+    bs = [m.bias.detach() for m in lin]
+    for t in ws + bs:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise _lib.GShellHipError("SDF network parameters must be contiguous fp32 tensors in HBM")
+    PtrArr = ctypes.c_void_p * len(ws)
+    with torch.cuda.device(dev):
+        check(L.gs_sdf_mlp_h2_pack(PtrArr(*[t.data_ptr() for t in ws]), PtrArr(*[t.data_ptr() for t in bs]), c_int(nf), c_int(n_hidden), c_int(skip),
+                                   ptr(packed), stream()), "gs_sdf_mlp_h2_pack")
+    return packed, n_hidden, skip
+
+
+def fused_forward(net, x, precision=None):
+    """sdf = net(x) through the fused MFMA kernel (no autograd)."""
+    precision = precision or SDF_MLP_PRECISION
+    L = _lib.lib()
     xc = x.detach().contiguous()
     out = torch.empty((xc.shape[0],), dtype=torch.float32, device=xc.device)
+    if precision == "h2":
+        packed, n_hidden, skip = pack_weights_h2(net)
+        with torch.cuda.device(xc.device):
+            check(L.gs_sdf_mlp_fwd_h2(ptr(xc, torch.float32, "x"), c_int64(xc.shape[0]), ptr(packed), c_int(net.emb.N_freqs), c_int(n_hidden), c_int(skip),
+                                      ptr(out), stream()), "gs_sdf_mlp_fwd_h2")
+        return out[:, None]
+    if precision != "fp32":
+        raise ValueError(f"unknown SDF-MLP precision {precision!r} (h2 | fp32)")
+    packed, n_hidden, skip = pack_weights(net)
+    assert packed.numel() == L.gs_sdf_mlp_packed_floats(c_int(net.emb.N_freqs), c_int(n_hidden), c_int(skip))
     with torch.cuda.device(xc.device):
         check(L.gs_sdf_mlp_fwd(ptr(xc, torch.float32, "x"), c_int64(xc.shape[0]), ptr(packed), c_int(net.emb.N_freqs), c_int(n_hidden), c_int(skip),
                                ptr(out), stream()), "gs_sdf_mlp_fwd")

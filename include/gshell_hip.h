@@ -418,6 +418,22 @@ int gs_sdf_mlp_fwd(const float* x, int64_t N, const float* packed, int n_freq, i
                    int skip_layer, float* out, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * SDF network on the f16 matrix path with fp32-class accuracy ("h2": every operand is a pair of fp16 pieces
+ *   v = hi + lo/2048, every product three v_mfma_f32_32x32x16_f16 with fp32 accumulation; csrc/mlp_h2.hip).
+ *   Same function as gs_sdf_mlp_fwd (geometry/mlp.py:32-40 over the whole grid), ~4x faster; the exact-fp32 kernel
+ *   above stays as its oracle.
+ *   gs_sdf_mlp_h2_pack: weights / biases = HOST arrays of n_hidden + 2 DEVICE pointers in torch's own layout
+ *   (Linear.weight [out,in] row-major, Linear.bias), hidden-producing layers first, the output layer last ->
+ *   packed (gs_sdf_mlp_h2_packed_bytes bytes, 16-byte aligned) WRITTEN: fragment-major fp16 pairs + fp32 biases.
+ *   One launch per optimisation step (the weights change every step).
+ * ---------------------------------------------------------------------------------- */
+int64_t gs_sdf_mlp_h2_packed_bytes(int n_freq, int n_hidden, int skip_layer);
+int gs_sdf_mlp_h2_pack(const float* const* weights, const float* const* biases, int n_freq, int n_hidden,
+                       int skip_layer, void* packed, gs_stream_t stream);
+int gs_sdf_mlp_fwd_h2(const float* x, int64_t N, const void* packed, int n_freq, int n_hidden,
+                      int skip_layer, float* out, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * G-FlexiCubes topology   (replaces the index machinery of GShellFlexiCubes.__call__,
  *   geometry/gshell_flexicubes.py:136-230: _identify_surf_cubes :334, _get_case_id :266, _identify_surf_edges :309,
  *   the edge-group tables of _compute_vd :406-485 and the quad gathering / splitting of _triangulate :493-522)
