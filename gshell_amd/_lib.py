@@ -92,7 +92,7 @@ class _TimedLib:
 
     def __getattr__(self, name):
         fn = getattr(self._real, name)
-        if not _timing["on"] or not name.startswith("gs_") or name.endswith(("_bytes", "_partials", "_params", "_info", "_create", "_destroy", "last_error", "version")):
+        if not _timing["on"] or not name.startswith("gs_") or name.endswith(("_bytes", "_partials", "_params", "_info", "_create", "_destroy", "_padded", "_words", "last_error", "version")):
             return fn
 
         def timed(*args):

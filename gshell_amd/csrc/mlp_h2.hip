@@ -45,10 +45,29 @@ constexpr int MAX_LAYERS = 16;
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
 constexpr float H_MIN_NORMAL = 6.103515625e-05f;   // 2^-14
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+#ifndef GS_H2_FLUSH
+#define GS_H2_FLUSH 0   // 1: values below the fp16 normal range go entirely into the scaled low piece.  Not needed: v_mfma_f32_32x32x16_f16 honours fp16 denormal inputs on gfx950 (tools/micro/mfma_f16_denorm.hip: exact products down to 6e-8)
+#endif
+
+// Row sources of the chain kernels.
+//   GRID: row r of x [N,3]                              (full-grid forward, nothing saved)
+//   ROWS: row rows[r] of x, r < R                       (row-sparse backward: recompute + save)
+//   EIK : 16 samples per tile, 4 VIRTUAL rows each: tile row 16 c + i = (value | d/dx | d/dy | d/dz) of sample 16 tile + i.
+//         The tangent rows carry the forward-mode derivative of the network w.r.t. the input point through the same GEMMs
+//         (no bias; activation a' = sigma'(z) z'), so that |grad f| of the eikonal term costs one pass over 4 n rows.
+enum { MODE_GRID = 0, MODE_ROWS = 1, MODE_EIK = 2 };
+
 struct H2Args {
-    const float* x;       // [N,3]
-    float* out;           // [N]
-    int64_t N;
+    const float* x;       // [N,3] points
+    const int32_t* rows;  // MODE_ROWS: [R]
+    float* out;           // MODE_GRID: [N] sdf;  MODE_EIK: [tiles*64] per virtual row (value rows: f - b_out; tangent rows: df/dx_d)
+    float* A;             // saved activations [n_layers][Rpad][256] fp32 (value rows a_l, tangent rows a'_l)   (ROWS / EIK)
+    float* EMB;           // saved encoding [Rpad][EK] fp32 (tangent rows: d enc / dx_d)                            (ROWS / EIK)
+    int64_t N;            // GRID: rows; ROWS: active rows R; EIK: samples
+    int64_t Rpad;         // tiles * 64
     int n_freq, E;
     int n_layers;         // hidden-producing layers (first + n_hidden)
     int skip_layer;       // index (>= 1) of the layer whose input is [h | emb], or -1
@@ -60,220 +79,700 @@ struct H2Args {
 __device__ __forceinline__ void split_h2(float v, _Float16& hi, _Float16& lo) {
     v = fminf(fmaxf(v, -60000.0f), 60000.0f);
     _Float16 h = (_Float16)v;                              // round to nearest even
-    if (fabsf(v) < H_MIN_NORMAL) h = (_Float16)0.0f;       // no reliance on fp16 denormals in the matrix pipe
+    if (GS_H2_FLUSH && fabsf(v) < H_MIN_NORMAL) h = (_Float16)0.0f;
     hi = h;
     lo = (_Float16)((v - (float)h) * LO_SCALE);
 }
 
-__device__ __forceinline__ float softplus100(float x) {
-    // hardware exp/log (v_exp_f32 / v_log_f32): absolute error <= 1e-9 on the softplus value (same formula as csrc/mlp.hip)
-    float bx = x * 100.0f;
-    return bx > 20.0f ? x : __logf(1.0f + __expf(bx)) * 0.01f;
+// two values at a time: v_pk_* fp32 ops and v_cvt_pk_f16_f32 (the epilogue is VALU bound: see DESIGN.md)
+__device__ __forceinline__ void split_h2_pair(f2 v, h2& hi, h2& lo) {
+    f2 vh = v;
+    if (GS_H2_FLUSH) {
+        vh.x = fabsf(v.x) < H_MIN_NORMAL ? 0.0f : v.x;
+        vh.y = fabsf(v.y) < H_MIN_NORMAL ? 0.0f : v.y;
+    }
+    hi = __builtin_convertvector(vh, h2);
+    const f2 hf = __builtin_convertvector(hi, f2);
+    lo = __builtin_convertvector((v - hf) * LO_SCALE, h2);
 }
 
-// hi/lo += W[32 features of this wave][K] . P[64 rows][K]^T over `nsteps` k-steps of 16.
-// Weight fragments for step s+1 are in flight while the six MFMAs of step s issue (register double buffer); the LDS
-// fragments of a step are read just before its MFMAs -- the other three waves of the SIMD cover that latency.
-template <int STRIDE>
+// Softplus(beta = 100, threshold 20) on the raw v_exp_f32 / v_log_f32 (base 2, constants folded):
+// absolute error <= 1e-9 on the value (log2(1 + e) flushes e < 6e-8, i.e. softplus < 6e-10, to 0)
+constexpr float SP_C1 = 144.26950408889634f;      // 100 log2(e)
+constexpr float SP_C2 = 0.006931471805599453f;    // ln(2) / 100
+constexpr float SP_T = 28.853900817779268f;       // 20 log2(e)
+__device__ __forceinline__ f2 softplus100_pair(f2 z) {
+    const f2 t = z * SP_C1;
+    f2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    e = e + 1.0f;
+    f2 l = {__builtin_amdgcn_logf(e.x), __builtin_amdgcn_logf(e.y)};
+    l = l * SP_C2;
+    return f2{t.x > SP_T ? z.x : l.x, t.y > SP_T ? z.y : l.y};
+}
+// sigma'(z) of that softplus = logistic(100 z)
+__device__ __forceinline__ f2 logistic100_pair(f2 z) {
+    const f2 t = z * (-SP_C1);
+    f2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    e = e + 1.0f;
+    return f2{__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+}
+// the same derivative from the SAVED softplus value a = softplus(z) >= 0:  sigma' = 1 - exp(-100 a)   (exact identity)
+__device__ __forceinline__ float slope_from_value(float a) {
+    const float x = 100.0f * a;
+    return x < 0.01f ? x * (1.0f - 0.5f * x + 0.16666667f * x * x) : 1.0f - __builtin_amdgcn_exp2f(-SP_C1 * a);
+}
+
+#ifndef GS_H2_PD
+#define GS_H2_PD 1      // weight-fragment prefetch distance in k-steps (register ring of PD + 1 stages x 8 VGPRs); measured flat 1..4
+#endif
+
+// hi/lo += W[32 output features of block `blk`][K] . P[64 rows][K]^T over NSTEPS k-steps of 16 (compile-time: fully unrolled,
+// the register ring rotates for free).  `wf` is fragment-major with `nblk` 32-feature blocks per k-step.
+template <int STRIDE, int NSTEPS>
 __device__ __forceinline__ void gemm_seg(v16f (&hi)[2], v16f (&lo)[2], const _Float16* __restrict__ P1, const _Float16* __restrict__ P2,
-                                         int nsteps, const h8* __restrict__ wf, int wave, int lane) {
+                                         const h8* __restrict__ wf, int blk, int nblk, int lane) {
+    constexpr int PD = GS_H2_PD < NSTEPS ? GS_H2_PD : NSTEPS - 1;
     const int row = lane & 31, kq = lane >> 5;
     const _Float16* b1p = P1 + row * STRIDE + kq * 8;
     const _Float16* b2p = P2 + row * STRIDE + kq * 8;
-    const h8* wp = wf + wave * 128 + lane;       // + step * 1024 (+64 for the low piece)
-    h8 a1 = wp[0], a2 = wp[64];
-    for (int st = 0; st < nsteps; ++st) {
+    const h8* wp = wf + blk * 128 + lane;       // + step * nblk * 128 (+64 for the low piece)
+    const int sstride = nblk * 128;
+    h8 a1[PD + 1], a2[PD + 1];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) {
+        a1[i] = wp[i * sstride];
+        a2[i] = wp[i * sstride + 64];
+    }
+#pragma unroll
+    for (int st = 0; st < NSTEPS; ++st) {
+        if (st + PD < NSTEPS) {
+            a1[(st + PD) % (PD + 1)] = wp[(st + PD) * sstride];
+            a2[(st + PD) % (PD + 1)] = wp[(st + PD) * sstride + 64];
+        }
         const h8 b10 = *reinterpret_cast<const h8*>(b1p + st * 16);
         const h8 b11 = *reinterpret_cast<const h8*>(b1p + 32 * STRIDE + st * 16);
         const h8 b20 = *reinterpret_cast<const h8*>(b2p + st * 16);
         const h8 b21 = *reinterpret_cast<const h8*>(b2p + 32 * STRIDE + st * 16);
-        h8 n1 = a1, n2 = a2;
-        if (st + 1 < nsteps) {
-            n1 = wp[(st + 1) * 1024];
-            n2 = wp[(st + 1) * 1024 + 64];
-        }
+        const h8 w1 = a1[st % (PD + 1)], w2 = a2[st % (PD + 1)];
         __builtin_amdgcn_sched_barrier(0);
-        hi[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b10, hi[0], 0, 0, 0);
-        hi[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b11, hi[1], 0, 0, 0);
-        lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b20, lo[0], 0, 0, 0);
-        lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b21, lo[1], 0, 0, 0);
-        lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b10, lo[0], 0, 0, 0);
-        lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b11, lo[1], 0, 0, 0);
+        hi[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b10, hi[0], 0, 0, 0);
+        hi[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b11, hi[1], 0, 0, 0);
+        lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b20, lo[0], 0, 0, 0);
+        lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b21, lo[1], 0, 0, 0);
+        lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, b10, lo[0], 0, 0, 0);
+        lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, b11, lo[1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        a1 = n1;
-        a2 = n2;
     }
 }
 
-__global__ void __launch_bounds__(NT, 4) k_sdf_mlp_fwd_h2(H2Args A) {
+__device__ __forceinline__ void zero_acc(v16f (&hi)[2], v16f (&lo)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hi[s][r] = lo[s][r] = 0.f;
+}
+
+// Point of tile row `row` (and, for EIK, which virtual row it is: c = 0 value, 1..3 tangent d = c - 1).
+template <int MODE>
+__device__ __forceinline__ bool tile_point(const H2Args& A, int64_t tile, int row, float (&p)[3], int& c) {
+    int64_t src;
+    c = 0;
+    if (MODE == MODE_EIK) {
+        src = tile * 16 + (row & 15);
+        c = row >> 4;
+        if (src >= A.N) return false;
+    } else {
+        src = tile * TM + row;
+        if (src >= A.N) return false;
+        if (MODE == MODE_ROWS) src = A.rows[src];
+    }
+    p[0] = A.x[3 * src]; p[1] = A.x[3 * src + 1]; p[2] = A.x[3 * src + 2];
+    return true;
+}
+
+// (x, sin(2^k x), cos(2^k x))_k  /  its derivative w.r.t. x_d   (geometry/embedding.py:22-39)
+__device__ __forceinline__ float encoding_entry(const float (&p)[3], int f, int c) {
+    if (f < 3) return c == 0 ? p[f] : (f == c - 1 ? 1.0f : 0.0f);
+    const int g = f - 3, k = g / 6, sc = (g % 6) / 3, cc = g % 3;
+    const float fr = (float)(1 << k), arg = fr * p[cc];
+    if (c == 0) return sc ? cosf(arg) : sinf(arg);
+    if (cc != c - 1) return 0.0f;
+    return sc ? -fr * sinf(arg) : fr * cosf(arg);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(NT, 4) k_h2_fwd(H2Args A) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
     _Float16* H1 = smem_h;                   // [TM][LDH]
     _Float16* H2 = H1 + TM * LDH;            // [TM][LDH]
     _Float16* E1 = H2 + TM * LDH;            // [TM][LDEH]
     _Float16* E2 = E1 + TM * LDEH;           // [TM][LDEH]   (the output reduction scratch is overlaid on E1/E2 at the end)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t r0 = (int64_t)blockIdx.x * TM;
+    const int64_t tile = blockIdx.x, r0 = tile * TM;
 
-    // positional encoding of the tile (x, sin(2^k x), cos(2^k x))_k, zero padded to EK columns, zero rows past N
+    // encoding of the tile, zero padded to EK columns, zero rows past the end
     for (int idx = tid; idx < TM * EK; idx += NT) {
         int row = idx / EK, f = idx - row * EK;
-        int64_t r = r0 + row;
+        float p[3];
+        int c;
         float v = 0.f;
-        if (r < A.N && f < A.E) {
-            if (f < 3)
-                v = A.x[3 * r + f];
-            else {
-                int g = f - 3, k = g / 6, sc = (g % 6) / 3, c = g % 3;
-                float arg = (float)(1 << k) * A.x[3 * r + c];
-                v = sc ? cosf(arg) : sinf(arg);
-            }
-        }
+        if (f < A.E && tile_point<MODE>(A, tile, row, p, c)) v = encoding_entry(p, f, c);
         _Float16 hi, lo;
         split_h2(v, hi, lo);
         E1[row * LDEH + f] = hi;
         E2[row * LDEH + f] = lo;
+        if (MODE != MODE_GRID) A.EMB[(r0 + row) * EK + f] = v;
     }
     __syncthreads();
 
     const int n_base = wave * 32 + 4 * (lane >> 5);      // + 8 g + j  (g = reg >> 2, j = reg & 3)
     const int m_lane = lane & 31;                        // + 32 s
+    const bool low16 = (lane & 16) == 0;                 // EIK: this lane holds (value, d/dy) rows; the other half (d/dx, d/dz)
     for (int l = 0; l < A.n_layers; ++l) {
         v16f hi[2], lo[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hi[s][r] = lo[s][r] = 0.f;
+        zero_acc(hi, lo);
         if (l == 0) {
-            gemm_seg<LDEH>(hi, lo, E1, E2, EK / 16, A.wfrag[0], wave, lane);
+            gemm_seg<LDEH, EK / 16>(hi, lo, E1, E2, A.wfrag[0], wave, 8, lane);
         } else {
-            gemm_seg<LDH>(hi, lo, H1, H2, D / 16, A.wfrag[l], wave, lane);
-            if (l == A.skip_layer) gemm_seg<LDEH>(hi, lo, E1, E2, EK / 16, A.wfrag[l] + (D / 16) * 1024, wave, lane);
+            gemm_seg<LDH, D / 16>(hi, lo, H1, H2, A.wfrag[l], wave, 8, lane);
+            if (l == A.skip_layer) gemm_seg<LDEH, EK / 16>(hi, lo, E1, E2, A.wfrag[l] + (D / 16) * 1024, wave, 8, lane);
         }
         __syncthreads();     // every wave is done reading the planes: they are overwritten in place
         const float* bl = A.bias[l] + n_base;
         const bool last = l + 1 == A.n_layers;
-        float part[2] = {0.f, 0.f};
+        f2 part[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 b4 = *reinterpret_cast<const float4*>(bl + 8 * g);
-            const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
-            float wj[4] = {0.f, 0.f, 0.f, 0.f};
+            const f2 bj[2] = {f2{b4.x, b4.y}, f2{b4.z, b4.w}};
+            f2 wj[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
             if (last) {
                 const float4 w4 = *reinterpret_cast<const float4*>(A.w_out + n_base + 8 * g);
-                wj[0] = w4.x; wj[1] = w4.y; wj[2] = w4.z; wj[3] = w4.w;
+                wj[0] = f2{w4.x, w4.y};
+                wj[1] = f2{w4.z, w4.w};
+            }
+            f2 v[2][2];          // [row half s][pair]
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = 4 * g + 2 * q;
+                const f2 z0 = f2{hi[0][r], hi[0][r + 1]} + f2{lo[0][r], lo[0][r + 1]} * LO_INV;
+                const f2 z1 = f2{hi[1][r], hi[1][r + 1]} + f2{lo[1][r], lo[1][r + 1]} * LO_INV;
+                if (MODE != MODE_EIK) {
+                    v[0][q] = softplus100_pair(z0 + bj[q]);
+                    v[1][q] = softplus100_pair(z1 + bj[q]);
+                } else {
+                    // lanes with (lane & 16) == 0: acc 0 = value row, acc 1 = d/dy row of the SAME sample; the lanes 16 above
+                    // hold that sample's d/dx (acc 0) and d/dz (acc 1) rows: a' = sigma'(z) z' with sigma' from the value row
+                    const f2 zb = z0 + bj[q];
+                    f2 sl = logistic100_pair(zb);
+                    f2 so = f2{__shfl_xor(sl.x, 16, 64), __shfl_xor(sl.y, 16, 64)};
+                    const f2 s = low16 ? sl : so;
+                    v[0][q] = low16 ? softplus100_pair(zb) : s * z0;
+                    v[1][q] = s * z1;
+                }
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                h4 o1, o2;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * g + j;
-                    float v = softplus100(__builtin_fmaf(lo[s][r], LO_INV, hi[s][r]) + bj[j]);
-                    if (last) {
-                        part[s] = __builtin_fmaf(v, wj[j], part[s]);
-                    } else {
-                        _Float16 a, b;
-                        split_h2(v, a, b);
-                        o1[j] = a;
-                        o2[j] = b;
-                    }
-                }
-                if (!last) {
+                if (MODE != MODE_GRID)
+                    *reinterpret_cast<float4*>(A.A + ((int64_t)l * A.Rpad + r0 + 32 * s + m_lane) * D + n_base + 8 * g) =
+                        make_float4(v[s][0].x, v[s][0].y, v[s][1].x, v[s][1].y);
+                if (last) {
+                    part[s] = part[s] + v[s][0] * wj[0] + v[s][1] * wj[1];
+                } else {
+                    h2 a0, b0, a1, b1;
+                    split_h2_pair(v[s][0], a0, b0);
+                    split_h2_pair(v[s][1], a1, b1);
                     const int off = (32 * s + m_lane) * LDH + n_base + 8 * g;
-                    *reinterpret_cast<h4*>(H1 + off) = o1;
-                    *reinterpret_cast<h4*>(H2 + off) = o2;
+                    *reinterpret_cast<h4*>(H1 + off) = h4{a0.x, a0.y, a1.x, a1.y};
+                    *reinterpret_cast<h4*>(H2 + off) = h4{b0.x, b0.y, b1.x, b1.y};
                 }
             }
         }
-        if (last) {
-            // output layer: this lane holds sum over its 16 features; add the other 16 of the wave's 32 (lane ^ 32), then
+        if (last && MODE != MODE_ROWS) {
+            // output layer: this lane holds the sum over its 16 features; add the other 16 of the wave's 32 (lane ^ 32), then
             // the 8 waves through LDS in a fixed order (deterministic)
-            float* red = reinterpret_cast<float*>(E1);       // [8 waves][64 rows] fp32 = 2 KB (the embedding planes are dead now)
+            float* red = reinterpret_cast<float*>(E1);       // [8 waves][64 rows] fp32 = 2 KB (the encoding planes are dead now)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                float p = part[s] + __shfl_xor(part[s], 32, 64);
+                float p = part[s].x + part[s].y;
+                p += __shfl_xor(p, 32, 64);
                 if (lane < 32) red[wave * TM + 32 * s + lane] = p;
             }
         }
         __syncthreads();
     }
-    if (tid < TM) {
+    if (MODE != MODE_ROWS && tid < TM) {
         const float* red = reinterpret_cast<const float*>(E1);
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) s += red[w * TM + tid];
         int64_t r = r0 + tid;
-        if (r < A.N) A.out[r] = s + A.w_out[D];
+        if (MODE == MODE_GRID) {
+            if (r < A.N) A.out[r] = s + A.w_out[D];
+        } else {
+            A.out[r] = s;                                    // virtual rows: value rows lack b_out (unused), tangent rows = df/dx_d
+        }
     }
 }
 
+// ---- backward chain ------------------------------------------------------------------------------------------------
+// Per 64-row tile, from the top: G = g_out (x) w_out;  for l = L-1 .. 0:  D_l = (dL/dz_l) from G and the saved activations
+// (elementwise, in the accumulator layout);  D_l -> HBM (fp32, for the weight-gradient kernel) and -> LDS as fp16 pairs;
+// G = W_l^T D_l  (the same transposed MFMA with the transposed fragment set).  The adjoint of the encoding (layer 0 and the
+// skip layer) is accumulated in LDS and turned into dL/dx at the end (ROWS).  Every row is scaled by a power of two so that
+// |g_out| is in [1,2) inside the chain (the chain is linear in g_out; gradients of 1e-7 would otherwise sit in the fp16
+// denormal range of the pair split) and unscaled on the way out (exact).
+struct BwdArgs {
+    const float* g_out;   // [Rpad] upstream gradient per (virtual) row; 0 on padding rows
+    const float* A;       // [n_layers][Rpad][256]
+    const float* EMB;     // [Rpad][EK]
+    float* Dsave;         // [n_layers][Rpad][256]  WRITTEN
+    const int32_t* rows;  // ROWS: [R]
+    float* g_x;           // ROWS: [N,3] scatter target (rows are unique), or null
+    int64_t R, Rpad;
+    int E, n_layers, skip_layer;
+    const h8* wfragT[MAX_LAYERS];   // [n-step 16][block nbT(l)][piece 2][lane 64]
+    int nblkT[MAX_LAYERS];
+    const float* w_out;
+};
+
+__device__ __forceinline__ float pow2_scale_for(float gmax) {      // 2^-floor(log2 gmax), 1 for zero / tiny rows
+    const int e = (__float_as_int(gmax) >> 23) & 0xff;
+    return (e < 32 || e > 222) ? 1.0f : __int_as_float((254 - e) << 23);
+}
+
+constexpr int LDG = EK + 1;      // fp32 encoding-adjoint tile row stride
+
+template <int MODE>
+__global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
+    _Float16* H1 = smem_h;                    // [TM][LDH]   D_l pieces
+    _Float16* H2 = H1 + TM * LDH;
+    float* GE = reinterpret_cast<float*>(H2 + TM * LDH);      // [TM][LDG] adjoint of the encoding (ROWS)
+    float* SC = GE + TM * LDG;                                 // [TM] 1 / row scale
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * TM;
+    const int n_base = wave * 32 + 4 * (lane >> 5);
+    const int m_lane = lane & 31;
+    const bool low16 = (lane & 16) == 0;
+    const bool need_x = MODE == MODE_ROWS && B.g_x != nullptr;
+
+    float go[2] = {B.g_out[r0 + m_lane], B.g_out[r0 + 32 + m_lane]};
+    float sc[2];
+    if (MODE == MODE_EIK) {
+        float gm = fmaxf(fabsf(go[0]), fabsf(go[1]));
+        gm = fmaxf(gm, __shfl_xor(gm, 16, 64));              // the four virtual rows of a sample share one scale
+        sc[0] = sc[1] = pow2_scale_for(gm);
+    } else {
+        sc[0] = pow2_scale_for(fabsf(go[0]));
+        sc[1] = pow2_scale_for(fabsf(go[1]));
+    }
+    const float isc[2] = {1.0f / sc[0], 1.0f / sc[1]};       // exact (powers of two)
+    go[0] *= sc[0];
+    go[1] *= sc[1];
+    if (need_x) {
+        for (int i = tid; i < TM * LDG; i += NT) GE[i] = 0.f;
+        if (wave == 0 && lane < 32) { SC[lane] = isc[0]; SC[32 + lane] = isc[1]; }
+    }
+    // adjoint of the last hidden activation, in the accumulator layout: G[s][4 g + j] <-> feature n_base + 8 g + j of row 32 s + m
+    v16f G[2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 w4 = *reinterpret_cast<const float4*>(B.w_out + n_base + 8 * g);
+        const float wj[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            G[0][4 * g + j] = go[0] * wj[j];
+            G[1][4 * g + j] = go[1] * wj[j];
+        }
+    }
+    if (need_x) __syncthreads();
+
+    for (int l = B.n_layers - 1; l >= 0; --l) {
+        // ---- dL/dz_l from G (adjoint of the layer's OUTPUT) and the saved outputs
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 a0 = *reinterpret_cast<const float4*>(B.A + ((int64_t)l * B.Rpad + r0 + m_lane) * D + n_base + 8 * g);
+            const float4 a1 = *reinterpret_cast<const float4*>(B.A + ((int64_t)l * B.Rpad + r0 + 32 + m_lane) * D + n_base + 8 * g);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            float d0[4], d1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g + j;
+                if (MODE != MODE_EIK) {
+                    d0[j] = G[0][r] * slope_from_value(av0[j]);
+                    d1[j] = G[1][r] * slope_from_value(av1[j]);
+                } else {
+                    // low16 lanes: (value a, d/dy a') of the sample; the lanes 16 above: (d/dx a', d/dz a').
+                    //   D_tangent = s G_tangent;   D_value = s G_value + 100 (1 - s) sum_d G_d a'_d        (a'_d = s z'_d)
+                    const float sl = slope_from_value(av0[j]);                   // meaningful on low16 lanes only
+                    const float pl = G[0][r] * av0[j] + G[1][r] * av1[j];        // meaningful on the upper lanes: G_x a'_x + G_z a'_z
+                    const float so = __shfl_xor(low16 ? sl : pl, 16, 64);        // low16 receives p of its partner, upper receives s
+                    if (low16) {
+                        d0[j] = G[0][r] * sl + 100.0f * (1.0f - sl) * (so + G[1][r] * av1[j]);
+                        d1[j] = sl * G[1][r];
+                    } else {
+                        d0[j] = so * G[0][r];
+                        d1[j] = so * G[1][r];
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(B.Dsave + ((int64_t)l * B.Rpad + r0 + m_lane) * D + n_base + 8 * g) =
+                make_float4(d0[0] * isc[0], d0[1] * isc[0], d0[2] * isc[0], d0[3] * isc[0]);
+            *reinterpret_cast<float4*>(B.Dsave + ((int64_t)l * B.Rpad + r0 + 32 + m_lane) * D + n_base + 8 * g) =
+                make_float4(d1[0] * isc[1], d1[1] * isc[1], d1[2] * isc[1], d1[3] * isc[1]);
+            if (l > 0 || need_x) {
+                h2 p0, q0, p1, q1;
+                split_h2_pair(f2{d0[0], d0[1]}, p0, q0);
+                split_h2_pair(f2{d0[2], d0[3]}, p1, q1);
+                int off = m_lane * LDH + n_base + 8 * g;
+                *reinterpret_cast<h4*>(H1 + off) = h4{p0.x, p0.y, p1.x, p1.y};
+                *reinterpret_cast<h4*>(H2 + off) = h4{q0.x, q0.y, q1.x, q1.y};
+                split_h2_pair(f2{d1[0], d1[1]}, p0, q0);
+                split_h2_pair(f2{d1[2], d1[3]}, p1, q1);
+                off += 32 * LDH;
+                *reinterpret_cast<h4*>(H1 + off) = h4{p0.x, p0.y, p1.x, p1.y};
+                *reinterpret_cast<h4*>(H2 + off) = h4{q0.x, q0.y, q1.x, q1.y};
+            }
+        }
+        if (l == 0 && !need_x) break;
+        __syncthreads();
+        // ---- G = W_l^T D_l
+        v16f hi[2], lo[2];
+        if (l > 0) {
+            zero_acc(hi, lo);
+            gemm_seg<LDH, D / 16>(hi, lo, H1, H2, B.wfragT[l], wave, B.nblkT[l], lane);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) G[s][r] = __builtin_fmaf(lo[s][r], LO_INV, hi[s][r]);
+        }
+        if (need_x && (l == 0 || l == B.skip_layer) && wave < 2) {     // adjoint of the encoding: two 32-feature blocks (48 used)
+            zero_acc(hi, lo);
+            gemm_seg<LDH, D / 16>(hi, lo, H1, H2, B.wfragT[l], (l == 0 ? 0 : 8) + wave, B.nblkT[l], lane);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = 32 * wave + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+                    if (f < EK) GE[(32 * s + m_lane) * LDG + f] += __builtin_fmaf(lo[s][r], LO_INV, hi[s][r]);
+                }
+        }
+        __syncthreads();
+    }
+    if (need_x) {
+        // dL/dx_c = G[c] + sum_k 2^k (cos(2^k x_c) G[sin_k,c] - sin(2^k x_c) G[cos_k,c]); sin / cos are the saved encoding
+        if (tid < TM * 3) {
+            const int row = tid / 3, c = tid - 3 * row;
+            const int64_t r = r0 + row;
+            if (r < B.R) {
+                const float* ge = GE + row * LDG;
+                const float* em = B.EMB + r * EK;
+                float acc = ge[c];
+                const int nf = (B.E - 3) / 6;
+                for (int k = 0; k < nf; ++k) {
+                    const float fr = (float)(1 << k);
+                    acc += fr * (em[3 + 6 * k + 3 + c] * ge[3 + 6 * k + c] - em[3 + 6 * k + c] * ge[3 + 6 * k + 3 + c]);
+                }
+                B.g_x[3 * (int64_t)B.rows[r] + c] = acc * SC[row];
+            }
+        }
+    }
+}
+
+// ---- weight gradients ----------------------------------------------------------------------------------------------
+// dW_l[n][k] = sum_rows D_l[row][n] X_l[row][k],  X_l = the layer's input ([a_{l-1} | enc] for the skip layer, enc for layer 0),
+// db_l[n] = sum over VALUE rows of D_l[row][n],  over ~4 10^5 (virtual) rows: a 256 x 256 output with the rows as the reduction
+// dimension.  One workgroup owns the whole [256 x K] output of ONE layer for a strip of rows (grid = strips x layers), streams
+// 32-row slabs of D_l and X_l through a double-buffered LDS image (registers in between) and accumulates on the matrix cores
+// with the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: both fragments are single floats, so the row-major fp32 slabs are read as
+// they lie -- no transposition).  Wave w owns features [32 w, 32 w + 32) x all K: up to 10 accumulator blocks.
+// The bias gradient is the column sum of the D slab, taken from the staging registers (each thread always holds the same four
+// features); partial results of the strips are combined with float atomics into the (zeroed) torch-layout gradient tensors.
+struct WgradArgs {
+    const float* A;       // [n_layers][Rpad][256]
+    const float* EMB;     // [Rpad][EK]
+    const float* D;       // [n_layers][Rpad][256]
+    const float* g_out;   // [Rpad]
+    int64_t Rpad;
+    int E, n_layers, skip_layer, mode;
+    int slabs_per_strip;  // 32-row slabs per workgroup
+    float* dW[MAX_LAYERS + 1];     // torch layout [256][K_l]; [n_layers] = output layer [1][256]
+    float* db[MAX_LAYERS + 1];     // [256]; the output layer's bias gradient is the caller's
+};
+
+constexpr int WS = 32;                       // rows per slab
+constexpr int WG_D = WS * D;                 // floats of the D / X_h slab
+constexpr int WG_E = WS * 64;                // encoding slab, padded to 64 columns
+constexpr int WG_BUF = 2 * WG_D + WG_E;      // one LDS buffer (floats)
+
+template <int NB, bool HAS_H, bool HAS_E>
+__device__ __forceinline__ void wgrad_layer(const WgradArgs& W, int l, float* smem, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t slab0 = (int64_t)blockIdx.x * W.slabs_per_strip;
+    const int64_t nslabs_total = W.Rpad / WS;
+    const int64_t nslab = min((int64_t)W.slabs_per_strip, nslabs_total - slab0);
+    if (nslab <= 0) return;
+    const float* Dl = W.D + (int64_t)l * W.Rpad * D;
+    const float* Xh = HAS_H ? W.A + (int64_t)(l - 1) * W.Rpad * D : nullptr;
+    v16f acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    float4 dreg[4], xreg[4], ereg;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    // thread t stages float4 chunk c = t + 512 i of a [32][256] slab: row = c / 64 = t / 64 + 8 i, feature quad = t % 64 (fixed)
+    auto load_slab = [&](int64_t slab) {
+        const int64_t rbase = slab * WS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = rbase + (tid >> 6) + 8 * i;
+            dreg[i] = *reinterpret_cast<const float4*>(Dl + row * D + 4 * (tid & 63));
+            if (HAS_H) xreg[i] = *reinterpret_cast<const float4*>(Xh + row * D + 4 * (tid & 63));
+        }
+        if (HAS_E && tid < WS * (EK / 4)) ereg = *reinterpret_cast<const float4*>(W.EMB + (rbase + tid / (EK / 4)) * EK + 4 * (tid % (EK / 4)));
+    };
+    auto store_slab = [&](float* buf, int64_t slab) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 6) + 8 * i;
+            *reinterpret_cast<float4*>(buf + row * D + 4 * (tid & 63)) = dreg[i];
+            if (HAS_H) *reinterpret_cast<float4*>(buf + WG_D + row * D + 4 * (tid & 63)) = xreg[i];
+            // bias gradient: value rows only (EIK: tile rows 0..15 of every 64)
+            const bool value_row = W.mode != MODE_EIK || (((slab * WS + row) & 63) < 16);
+            if (value_row) { bsum.x += dreg[i].x; bsum.y += dreg[i].y; bsum.z += dreg[i].z; bsum.w += dreg[i].w; }
+        }
+        if (HAS_E && tid < WS * (EK / 4)) *reinterpret_cast<float4*>(buf + 2 * WG_D + (tid / (EK / 4)) * 64 + 4 * (tid % (EK / 4))) = ereg;
+    };
+    if (HAS_E)      // columns EK..63 of both encoding slabs stay zero
+        for (int i = tid; i < 2 * WS * 16; i += NT) smem[(i / (WS * 16)) * WG_BUF + 2 * WG_D + ((i / 16) % WS) * 64 + EK + (i & 15)] = 0.f;
+    load_slab(slab0);
+    store_slab(smem, slab0);
+    __syncthreads();
+    for (int64_t s = 0; s < nslab; ++s) {
+        float* cur = smem + (s & 1) * WG_BUF;
+        const bool more = s + 1 < nslab;
+        if (more) load_slab(slab0 + s + 1);
+        const float* ap = cur + (lane >> 5) * D + wave * 32 + (lane & 31);            // D[row = 2 ks + (lane >> 5)][n]
+        const float* xp = cur + WG_D + (lane >> 5) * D + (lane & 31);
+        const float* ep = cur + 2 * WG_D + (lane >> 5) * 64 + (lane & 31);
+#pragma unroll 4
+        for (int ks = 0; ks < WS / 2; ++ks) {
+            const float a = ap[ks * 2 * D];
+            if (HAS_H) {
+#pragma unroll
+                for (int b = 0; b < 8; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xp[ks * 2 * D + 32 * b], acc[b], 0, 0, 0);
+            }
+            if (HAS_E) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[(HAS_H ? 8 : 0) + b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ep[ks * 2 * 64 + 32 * b], acc[(HAS_H ? 8 : 0) + b], 0, 0, 0);
+            }
+        }
+        if (more) store_slab(smem + ((s + 1) & 1) * WG_BUF, slab0 + s + 1);
+        __syncthreads();
+    }
+    // flush: acc[b][reg] = dW[n = 32 wave + (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)][k = 32 b + (lane & 31)]
+    const int Kreal = (HAS_H ? D : 0) + (HAS_E ? W.E : 0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        int k = 32 * b + (lane & 31);
+        bool ok = true;
+        if (HAS_E && b >= (HAS_H ? 8 : 0)) {
+            const int e = 32 * (b - (HAS_H ? 8 : 0)) + (lane & 31);
+            ok = e < W.E;
+            k = (HAS_H ? D : 0) + e;
+        }
+        if (ok)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                atomicAdd(W.dW[l] + (int64_t)n * Kreal + k, acc[b][r]);
+            }
+    }
+    // bias gradient: the 8 waves hold partial sums of the same feature quads
+    float4* red = reinterpret_cast<float4*>(smem);
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < 64) {
+        float4 t = red[tid];
+        for (int w = 1; w < 8; ++w) { const float4 o = red[w * 64 + tid]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+        atomicAdd(W.db[l] + 4 * tid, t.x);
+        atomicAdd(W.db[l] + 4 * tid + 1, t.y);
+        atomicAdd(W.db[l] + 4 * tid + 2, t.z);
+        atomicAdd(W.db[l] + 4 * tid + 3, t.w);
+    }
+}
+
+__global__ void __launch_bounds__(NT, 2) k_h2_wgrad(WgradArgs W) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int l = blockIdx.y, tid = threadIdx.x;
+    if (l == W.n_layers) {
+        // output layer: dw_out[n] = sum_rows g_out[row] a_{L-1}[row][n]  (tangent rows included: their g_out is dL/d(df/dx_d))
+        const int64_t slab0 = (int64_t)blockIdx.x * W.slabs_per_strip, nslabs_total = W.Rpad / WS;
+        const float* X = W.A + (int64_t)(W.n_layers - 1) * W.Rpad * D;
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t s = slab0; s < min(slab0 + W.slabs_per_strip, nslabs_total); ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t row = s * WS + (tid >> 6) + 8 * i;
+                const float g = W.g_out[row];
+                const float4 x = *reinterpret_cast<const float4*>(X + row * D + 4 * (tid & 63));
+                s4.x += g * x.x; s4.y += g * x.y; s4.z += g * x.z; s4.w += g * x.w;
+            }
+        float4* red = reinterpret_cast<float4*>(smem_f);
+        red[tid] = s4;
+        __syncthreads();
+        if (tid < 64) {
+            float4 t = red[tid];
+            for (int w = 1; w < 8; ++w) { const float4 o = red[w * 64 + tid]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+            atomicAdd(W.dW[l] + 4 * tid, t.x);
+            atomicAdd(W.dW[l] + 4 * tid + 1, t.y);
+            atomicAdd(W.dW[l] + 4 * tid + 2, t.z);
+            atomicAdd(W.dW[l] + 4 * tid + 3, t.w);
+        }
+        return;
+    }
+    if (l == 0) wgrad_layer<2, false, true>(W, l, smem_f, tid);
+    else if (l == W.skip_layer) wgrad_layer<10, true, true>(W, l, smem_f, tid);
+    else wgrad_layer<8, true, false>(W, l, smem_f, tid);
+}
+
 constexpr size_t SMEM_BYTES = (size_t)(2 * TM * LDH + 2 * TM * LDEH) * sizeof(_Float16);
-static_assert(SMEM_BYTES <= 80 * 1024, "two workgroups per CU");
+constexpr size_t SMEM_BWD_BYTES = (size_t)(2 * TM * LDH) * sizeof(_Float16) + (size_t)(TM * LDG + TM) * sizeof(float);
+constexpr size_t SMEM_WGRAD_BYTES = (size_t)2 * WG_BUF * sizeof(float);
+static_assert(SMEM_BYTES <= 80 * 1024 && SMEM_BWD_BYTES <= 80 * 1024, "two workgroups per CU");
+static_assert(SMEM_WGRAD_BYTES <= 160 * 1024, "LDS");
 
 // ---- weight packing ------------------------------------------------------------------------------------------------
+// packed = [ forward fragments | transposed (dgrad) fragments | fp32 tail: biases [n_layers][256], w_out [256], b_out ]
+struct PackLayout {
+    int n_layers, skip_layer, E;
+    int64_t frag_off[MAX_LAYERS];     // h8 units, forward fragments of layer l: [k-step][8 blocks][2 pieces][64 lanes]
+    int64_t fragT_off[MAX_LAYERS];    // transposed fragments of layer l: [n-step 16][nblkT][2][64]
+    int nblkT[MAX_LAYERS];
+    int64_t total_frags;              // forward + transposed
+    int64_t tail_off_bytes;
+};
+
+int layer_steps(int l, int skip_layer) { return l == 0 ? EK / 16 : D / 16 + (l == skip_layer ? EK / 16 : 0); }
+
+PackLayout make_layout(int n_freq, int n_hidden, int skip_layer) {
+    PackLayout L{};
+    L.n_layers = n_hidden + 1; L.skip_layer = skip_layer; L.E = 3 * (2 * n_freq + 1);
+    int64_t off = 0;
+    for (int l = 0; l < L.n_layers; ++l) {
+        L.frag_off[l] = off;
+        off += (int64_t)layer_steps(l, skip_layer) * 1024;
+    }
+    for (int l = 0; l < L.n_layers; ++l) {
+        L.nblkT[l] = l == 0 ? 2 : (l == skip_layer ? 10 : 8);
+        L.fragT_off[l] = off;
+        off += (int64_t)(D / 16) * L.nblkT[l] * 128;
+    }
+    L.total_frags = off;
+    L.tail_off_bytes = off * 16;
+    return L;
+}
+
 struct PackArgs {
     const float* w[MAX_LAYERS + 1];   // torch Linear.weight [out, in] of every layer, output layer last
     const float* b[MAX_LAYERS + 1];
-    int n_layers, skip_layer, E;
-    int64_t frag_off[MAX_LAYERS];     // in h8 units
-    int nsteps[MAX_LAYERS];
-    int64_t total_frags;              // h8 entries
+    PackLayout L;
     h8* frags;
-    float* tail;                      // biases [n_layers][256], w_out [256], b_out
+    float* tail;
 };
 
 __global__ void __launch_bounds__(256) k_h2_pack(PackArgs P) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < P.total_frags) {
-        int l = 0;
-        while (l + 1 < P.n_layers && i >= P.frag_off[l + 1]) ++l;
-        int64_t j = i - P.frag_off[l];
-        const int lane = (int)(j & 63), piece = (int)((j >> 6) & 1), wave = (int)((j >> 7) & 7), step = (int)(j >> 10);
-        const int n = wave * 32 + (lane & 31);
-        const int k0 = step * 16 + 8 * (lane >> 5);
-        const int Kin = l == 0 ? P.E : (l == P.skip_layer ? D + P.E : D);      // torch row length
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const PackLayout& L = P.L;
+    if (i < L.total_frags) {
         h8 o;
+        if (i < L.fragT_off[0]) {      // forward: rows = output features n, K = input index k
+            int l = 0;
+            while (l + 1 < L.n_layers && i >= L.frag_off[l + 1]) ++l;
+            const int64_t j = i - L.frag_off[l];
+            const int lane = (int)(j & 63), piece = (int)((j >> 6) & 1), wave = (int)((j >> 7) & 7), step = (int)(j >> 10);
+            const int n = wave * 32 + (lane & 31);
+            const int k0 = step * 16 + 8 * (lane >> 5);
+            const int Kin = l == 0 ? L.E : (l == L.skip_layer ? D + L.E : D);      // torch row length
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            int k = k0 + q, src = -1;
-            if (l == 0) src = k < P.E ? k : -1;
-            else if (k < D) src = k;
-            else if (l == P.skip_layer && k - D < P.E) src = k;            // [h | emb] order of geometry/mlp.py:37
-            float v = src >= 0 ? P.w[l][(int64_t)n * Kin + src] : 0.f;
-            _Float16 hi, lo;
-            split_h2(v, hi, lo);
-            o[q] = piece ? lo : hi;
+            for (int q = 0; q < 8; ++q) {
+                int k = k0 + q, src = -1;
+                if (l == 0) src = k < L.E ? k : -1;
+                else if (k < D) src = k;
+                else if (l == L.skip_layer && k - D < L.E) src = k;            // [h | emb] order of geometry/mlp.py:37
+                float v = src >= 0 ? P.w[l][(int64_t)n * Kin + src] : 0.f;
+                _Float16 hi, lo;
+                split_h2(v, hi, lo);
+                o[q] = piece ? lo : hi;
+            }
+        } else {                       // transposed: rows = INPUT index of the layer (h feature, or encoding entry), K = output feature n
+            int l = 0;
+            while (l + 1 < L.n_layers && i >= L.fragT_off[l + 1]) ++l;
+            const int64_t j = i - L.fragT_off[l];
+            const int nb = L.nblkT[l];
+            const int lane = (int)(j & 63), piece = (int)((j >> 6) & 1);
+            const int blk = (int)((j >> 7) % nb), step = (int)((j >> 7) / nb);
+            const int Kin = l == 0 ? L.E : (l == L.skip_layer ? D + L.E : D);
+            int col;                  // torch column of this fragment row, -1 = padding
+            if (l == 0) { int e = blk * 32 + (lane & 31); col = e < L.E ? e : -1; }
+            else if (blk < 8) col = blk * 32 + (lane & 31);
+            else { int e = (blk - 8) * 32 + (lane & 31); col = e < L.E ? D + e : -1; }
+            const int n0 = step * 16 + 8 * (lane >> 5);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float v = col >= 0 ? P.w[l][(int64_t)(n0 + q) * Kin + col] : 0.f;
+                _Float16 hi, lo;
+                split_h2(v, hi, lo);
+                o[q] = piece ? lo : hi;
+            }
         }
         P.frags[i] = o;
     }
-    const int n_tail = P.n_layers * D + D + 1;
+    const int n_tail = L.n_layers * D + D + 1;
     if (i < n_tail) {
         float v;
-        if (i < (int64_t)P.n_layers * D) v = P.b[i / D][i % D];
-        else if (i < (int64_t)P.n_layers * D + D) v = P.w[P.n_layers][i - (int64_t)P.n_layers * D];
-        else v = P.b[P.n_layers][0];
+        if (i < (int64_t)L.n_layers * D) v = P.b[i / D][i % D];
+        else if (i < (int64_t)L.n_layers * D + D) v = P.w[L.n_layers][i - (int64_t)L.n_layers * D];
+        else v = P.b[L.n_layers][0];
         P.tail[i] = v;
     }
 }
 
-int layer_steps(int l, int skip_layer) { return l == 0 ? EK / 16 : D / 16 + (l == skip_layer ? EK / 16 : 0); }
-
-int check_shape(const char* who, int n_freq, int n_hidden, int skip_layer) {
+int check_shape(int n_freq, int n_hidden, int skip_layer) {
     int E = 3 * (2 * n_freq + 1);
     GS_REQUIRE(n_freq >= 0 && E <= EK, "sdf_mlp_h2: positional encoding wider than 48 is not supported");
     GS_REQUIRE(n_hidden >= 0 && n_hidden + 1 <= MAX_LAYERS, "sdf_mlp_h2: too many layers");
     GS_REQUIRE(skip_layer == -1 || (skip_layer >= 1 && skip_layer <= n_hidden), "sdf_mlp_h2: bad skip layer");
-    (void)who;
+    return 0;
+}
+
+void fill_fwd_args(H2Args& A, const void* packed, const PackLayout& L) {
+    A.n_layers = L.n_layers; A.skip_layer = L.skip_layer; A.E = L.E;
+    const float* tail = (const float*)((const char*)packed + L.tail_off_bytes);
+    for (int l = 0; l < L.n_layers; ++l) {
+        A.wfrag[l] = (const h8*)packed + L.frag_off[l];
+        A.bias[l] = tail + (int64_t)l * D;
+    }
+    A.w_out = tail + (int64_t)L.n_layers * D;
+}
+
+template <int MODE>
+int launch_fwd(const H2Args& A, int64_t tiles, hipStream_t stream) {
+    // per launch (cheap, and correct per device / per thread, unlike a process-wide "done" flag)
+    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_fwd<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES));
+    hipLaunchKernelGGL(k_h2_fwd<MODE>, dim3((unsigned)tiles), dim3(NT), SMEM_BYTES, stream, A);
+    GS_LAUNCH_CHECK();
     return 0;
 }
 
 }  // namespace
 
 extern "C" int64_t gs_sdf_mlp_h2_packed_bytes(int n_freq, int n_hidden, int skip_layer) {
-    (void)n_freq;
-    int64_t frags = 0;
-    for (int l = 0; l <= n_hidden; ++l) frags += (int64_t)layer_steps(l, skip_layer) * 1024;
-    return frags * 16 + ((int64_t)(n_hidden + 1) * D + D + 1) * 4;
+    PackLayout L = make_layout(n_freq, n_hidden, skip_layer);
+    return L.tail_off_bytes + ((int64_t)L.n_layers * D + D + 1) * 4;
 }
 
 // weights / biases: HOST arrays of n_hidden + 2 DEVICE pointers (torch layout, Linear.weight [out, in] row-major; the
@@ -282,24 +781,17 @@ extern "C" int gs_sdf_mlp_h2_pack(const float* const* weights, const float* cons
                                   gs_stream_t stream) {
     GS_REQUIRE(weights && biases && packed, "gs_sdf_mlp_h2_pack: null pointer");
     GS_REQUIRE(((uintptr_t)packed & 15) == 0, "gs_sdf_mlp_h2_pack: packed buffer must be 16-byte aligned");
-    if (int rc = check_shape("pack", n_freq, n_hidden, skip_layer)) return rc;
+    if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
     PackArgs P{};
-    P.n_layers = n_hidden + 1; P.skip_layer = skip_layer; P.E = 3 * (2 * n_freq + 1);
-    int64_t off = 0;
-    for (int l = 0; l < P.n_layers; ++l) {
-        P.frag_off[l] = off;
-        P.nsteps[l] = layer_steps(l, skip_layer);
-        off += (int64_t)P.nsteps[l] * 1024;
-    }
-    P.total_frags = off;
-    for (int l = 0; l <= P.n_layers; ++l) {
+    P.L = make_layout(n_freq, n_hidden, skip_layer);
+    for (int l = 0; l <= P.L.n_layers; ++l) {
         GS_REQUIRE(weights[l] && biases[l], "gs_sdf_mlp_h2_pack: null layer pointer");
         P.w[l] = weights[l];
         P.b[l] = biases[l];
     }
     P.frags = (h8*)packed;
-    P.tail = (float*)((char*)packed + off * 16);
-    hipLaunchKernelGGL(k_h2_pack, dim3((unsigned)gs::cdiv(off, 256)), dim3(256), 0, (hipStream_t)stream, P);
+    P.tail = (float*)((char*)packed + P.L.tail_off_bytes);
+    hipLaunchKernelGGL(k_h2_pack, dim3((unsigned)gs::cdiv(P.L.total_frags, 256)), dim3(256), 0, (hipStream_t)stream, P);
     GS_LAUNCH_CHECK();
     return 0;
 }
@@ -308,20 +800,86 @@ extern "C" int gs_sdf_mlp_fwd_h2(const float* x, int64_t N, const void* packed, 
                                  gs_stream_t stream) {
     if (N == 0) return 0;
     GS_REQUIRE(x && packed && out, "gs_sdf_mlp_fwd_h2: null pointer");
-    if (int rc = check_shape("fwd", n_freq, n_hidden, skip_layer)) return rc;
+    if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
     H2Args A{};
-    A.x = x; A.out = out; A.N = N; A.n_freq = n_freq; A.E = 3 * (2 * n_freq + 1); A.n_layers = n_hidden + 1; A.skip_layer = skip_layer;
-    int64_t off = 0;
-    for (int l = 0; l < A.n_layers; ++l) {
-        A.wfrag[l] = (const h8*)packed + off;
-        off += (int64_t)layer_steps(l, skip_layer) * 1024;
+    A.x = x; A.out = out; A.N = N; A.n_freq = n_freq;
+    fill_fwd_args(A, packed, make_layout(n_freq, n_hidden, skip_layer));
+    return launch_fwd<MODE_GRID>(A, gs::cdiv(N, TM), (hipStream_t)stream);
+}
+
+extern "C" int64_t gs_sdf_mlp_h2_rows_padded(int mode, int64_t n) {      // virtual rows of the saved planes (multiple of 64)
+    return mode == MODE_EIK ? gs::cdiv(n, 16) * TM : gs::cdiv(n, TM) * TM;
+}
+
+// mode 1 (ROWS): recompute rows `rows[0..n)` of x;  mode 2 (EIK): value + 3 tangent rows of the n sample points x [n,3].
+// A [n_hidden+1][Rpad][256], EMB [Rpad][48] WRITTEN (Rpad = gs_sdf_mlp_h2_rows_padded);  out [Rpad] WRITTEN in mode 2
+// (tile-major virtual rows: entry 64 t + 16 c + i belongs to sample 16 t + i; c = 0: f - b_out, c = 1..3: df/dx_{c-1}).
+extern "C" int gs_sdf_mlp_h2_save_fwd(int mode, const float* x, const int32_t* rows, int64_t n, const void* packed, int n_freq, int n_hidden,
+                                      int skip_layer, float* A_save, float* EMB_save, float* out, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_REQUIRE(mode == MODE_ROWS || mode == MODE_EIK, "gs_sdf_mlp_h2_save_fwd: mode must be 1 (rows) or 2 (eikonal)");
+    GS_REQUIRE(x && packed && A_save && EMB_save && (mode == MODE_EIK ? out != nullptr : rows != nullptr), "gs_sdf_mlp_h2_save_fwd: null pointer");
+    if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
+    H2Args A{};
+    A.x = x; A.rows = rows; A.out = out; A.N = n; A.n_freq = n_freq; A.A = A_save; A.EMB = EMB_save;
+    A.Rpad = gs_sdf_mlp_h2_rows_padded(mode, n);
+    fill_fwd_args(A, packed, make_layout(n_freq, n_hidden, skip_layer));
+    return mode == MODE_ROWS ? launch_fwd<MODE_ROWS>(A, A.Rpad / TM, (hipStream_t)stream) : launch_fwd<MODE_EIK>(A, A.Rpad / TM, (hipStream_t)stream);
+}
+
+// Backward chain over the saved planes: D [n_hidden+1][Rpad][256] WRITTEN (dL/d pre-activation of every layer, per virtual
+// row); mode 1 with g_x != NULL: g_x[rows[r]] (of [N,3]) WRITTEN for r < n (dL/dx through the encoding).  g_out [Rpad]:
+// upstream gradient per virtual row, 0 on padding rows.
+extern "C" int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* rows, int64_t n, const void* packed, int n_freq, int n_hidden,
+                                 int skip_layer, const float* A_save, const float* EMB_save, float* D_save, float* g_x, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_REQUIRE(mode == MODE_ROWS || mode == MODE_EIK, "gs_sdf_mlp_h2_bwd: mode must be 1 (rows) or 2 (eikonal)");
+    GS_REQUIRE(g_out && packed && A_save && EMB_save && D_save && (mode == MODE_EIK || rows != nullptr), "gs_sdf_mlp_h2_bwd: null pointer");
+    if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
+    PackLayout L = make_layout(n_freq, n_hidden, skip_layer);
+    BwdArgs B{};
+    B.g_out = g_out; B.A = A_save; B.EMB = EMB_save; B.Dsave = D_save; B.rows = rows; B.g_x = mode == MODE_ROWS ? g_x : nullptr;
+    B.R = n; B.Rpad = gs_sdf_mlp_h2_rows_padded(mode, n); B.E = L.E; B.n_layers = L.n_layers; B.skip_layer = L.skip_layer;
+    for (int l = 0; l < L.n_layers; ++l) {
+        B.wfragT[l] = (const h8*)packed + L.fragT_off[l];
+        B.nblkT[l] = L.nblkT[l];
     }
-    const float* tail = (const float*)((const char*)packed + off * 16);
-    for (int l = 0; l < A.n_layers; ++l) A.bias[l] = tail + (int64_t)l * D;
-    A.w_out = tail + (int64_t)A.n_layers * D;
-    // per launch (cheap, and correct per device / per thread, unlike a process-wide "done" flag)
-    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sdf_mlp_fwd_h2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES));
-    hipLaunchKernelGGL(k_sdf_mlp_fwd_h2, dim3((unsigned)gs::cdiv(N, TM)), dim3(NT), SMEM_BYTES, (hipStream_t)stream, A);
+    B.w_out = (const float*)((const char*)packed + L.tail_off_bytes) + (int64_t)L.n_layers * D;
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == MODE_ROWS) {
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_bwd<MODE_ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BWD_BYTES));
+        hipLaunchKernelGGL(k_h2_bwd<MODE_ROWS>, dim3((unsigned)(B.Rpad / TM)), dim3(NT), SMEM_BWD_BYTES, st, B);
+    } else {
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_bwd<MODE_EIK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BWD_BYTES));
+        hipLaunchKernelGGL(k_h2_bwd<MODE_EIK>, dim3((unsigned)(B.Rpad / TM)), dim3(NT), SMEM_BWD_BYTES, st, B);
+    }
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+// Weight / bias gradients from the saved planes, ACCUMULATED (float atomics) into torch-layout tensors:
+// dW, db = HOST arrays of n_hidden + 2 DEVICE pointers (Linear.weight.grad [out,in], Linear.bias.grad), output layer last;
+// db[n_hidden + 1] (the output bias, = sum of g_out over the value rows) is not touched.
+extern "C" int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, int n_freq, int n_hidden, int skip_layer, const float* A_save,
+                                   const float* EMB_save, const float* D_save, float* const* dW, float* const* db, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_REQUIRE(mode == MODE_ROWS || mode == MODE_EIK, "gs_sdf_mlp_h2_wgrad: mode must be 1 (rows) or 2 (eikonal)");
+    GS_REQUIRE(g_out && A_save && EMB_save && D_save && dW && db, "gs_sdf_mlp_h2_wgrad: null pointer");
+    if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
+    WgradArgs W{};
+    W.A = A_save; W.EMB = EMB_save; W.D = D_save; W.g_out = g_out; W.Rpad = gs_sdf_mlp_h2_rows_padded(mode, n);
+    W.E = 3 * (2 * n_freq + 1); W.n_layers = n_hidden + 1; W.skip_layer = skip_layer; W.mode = mode;
+    for (int l = 0; l <= W.n_layers; ++l) {
+        GS_REQUIRE(dW[l] && (l == W.n_layers || db[l]), "gs_sdf_mlp_h2_wgrad: null gradient pointer");
+        W.dW[l] = dW[l];
+        W.db[l] = db[l];
+    }
+    const int64_t nslabs = W.Rpad / WS;
+    int strips = (int)std::min<int64_t>(nslabs, 40);           // ~ (CUs / layers): every CU owns one (strip, layer) pair
+    W.slabs_per_strip = (int)gs::cdiv(nslabs, strips);
+    strips = (int)gs::cdiv(nslabs, W.slabs_per_strip);
+    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_WGRAD_BYTES));
+    hipLaunchKernelGGL(k_h2_wgrad, dim3((unsigned)strips, (unsigned)(W.n_layers + 1)), dim3(NT), SMEM_WGRAD_BYTES, (hipStream_t)stream, W);
     GS_LAUNCH_CHECK();
     return 0;
 }

@@ -9,7 +9,7 @@ from .. import _lib
 from .._lib import c_int64, check, ptr, stream
 from ..render import mesh, optixutils as ou, regularizer, render
 from .gshell_tets import GShell_Tets
-from .mlp import MLP, forward_row_sharded, forward_row_sparse_backward
+from .mlp import MLP, eikonal_sq_sum, forward_row_sharded, forward_row_sparse_backward
 
 
 class _SdfRegFn(torch.autograd.Function):
@@ -58,15 +58,6 @@ def sample_points(v_pos, faces, n, generator=None):
     r = torch.rand(n, 2, device=v_pos.device, generator=generator)
     u, v = r[:, 0:1].sqrt(), r[:, 1:2]
     return (1 - u) * v0[fid] + u * (1 - v) * v1[fid] + u * v * v2[fid], fid
-
-
-def eikonal_sq_sum(sdf_net, pts):
-    """sum_i (|d sdf / d x_i| - 1)^2 over the sample points (reference :318-324, before the mean), differentiable w.r.t.
-    the network parameters (torch double backward; the samples are detached as in the reference)."""
-    v = pts.detach().requires_grad_(True)
-    sdf_eik = sdf_net(v)
-    grad = torch.autograd.grad(sdf_eik.sum(), v, create_graph=True)[0]
-    return (grad.pow(2).sum(dim=-1).sqrt() - 1).pow(2).sum()
 
 
 class GShellTetsGeometry(torch.nn.Module):

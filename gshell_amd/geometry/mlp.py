@@ -274,9 +274,9 @@ class _RowSparseBackward(torch.autograd.Function):
         return (g_x, None) + tuple(g_params)
 
 
-def row_sparse_backward(net, x, g_y, need_x):
-    """(d loss / d x [N,3] or None, [d loss / d p for p in net.parameters()]) from the upstream gradient g_y [N,1],
-    touching only the rows where g_y != 0 (they are recomputed; the forward pass keeps no activations)."""
+def row_sparse_backward_torch(net, x, g_y, need_x):
+    """Plain-torch formulation (autograd over the recomputed active rows): CPU path of the gloo tests, and the oracle of the
+    HIP chain kernels in tests/."""
     params = [p for p in net.parameters()]
     rows = torch.nonzero(g_y.reshape(x.shape[0], -1).abs().sum(dim=1) != 0).reshape(-1)      # one host sync
     g_x = torch.zeros_like(x) if need_x else None
@@ -290,6 +290,111 @@ def row_sparse_backward(net, x, g_y, need_x):
         g_x[rows] = grads[0]
         grads = grads[1:]
     return g_x, [torch.zeros_like(p) if g is None else g for p, g in zip(params, grads)]
+
+
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class _SavedChain:
+    """Saved planes of one pass of the h2 chain kernels over n (virtual) rows: A [layers, Rpad, 256], EMB [Rpad, 48]."""
+
+    def __init__(self, net, mode, x, rows, n):
+        L = _lib.lib()
+        self.net, self.mode, self.n = net, mode, int(n)
+        self.lin, self.n_hidden, self.skip = _layer_structure(net)
+        self.nf = net.emb.N_freqs
+        self.packed, _, _ = pack_weights_h2(net)
+        dev = x.device
+        self.Rpad = int(L.gs_sdf_mlp_h2_rows_padded(c_int(mode), c_int64(self.n)))
+        nl = self.n_hidden + 1
+        self.A = torch.empty((nl, self.Rpad, 256), dtype=torch.float32, device=dev)
+        self.EMB = torch.empty((self.Rpad, 48), dtype=torch.float32, device=dev)
+        self.out = torch.empty((self.Rpad,), dtype=torch.float32, device=dev) if mode == 2 else None
+        self.rows = rows
+        with torch.cuda.device(dev):
+            check(L.gs_sdf_mlp_h2_save_fwd(c_int(mode), ptr(x, torch.float32, "x"), ptr(rows, torch.int32, "rows"), c_int64(self.n), ptr(self.packed),
+                                           c_int(self.nf), c_int(self.n_hidden), c_int(self.skip), ptr(self.A), ptr(self.EMB), ptr(self.out), stream()),
+                  "gs_sdf_mlp_h2_save_fwd")
+
+    def backward(self, g_out, g_x=None):
+        """g_out [Rpad] per virtual row -> ([d loss / d p for p in net.parameters()]); g_x [N,3] is filled in place (mode 1)."""
+        L = _lib.lib()
+        dev = g_out.device
+        D = torch.empty_like(self.A)
+        params = list(self.net.parameters())
+        grads = {id(p): torch.zeros_like(p) for p in params}
+        dW = [grads[id(m.weight)] for m in self.lin]
+        db = [grads[id(m.bias)] for m in self.lin]
+        with torch.cuda.device(dev):
+            check(L.gs_sdf_mlp_h2_bwd(c_int(self.mode), ptr(g_out, torch.float32, "g_out"), ptr(self.rows, torch.int32, "rows"), c_int64(self.n), ptr(self.packed),
+                                      c_int(self.nf), c_int(self.n_hidden), c_int(self.skip), ptr(self.A), ptr(self.EMB), ptr(D), ptr(g_x), stream()),
+                  "gs_sdf_mlp_h2_bwd")
+            check(L.gs_sdf_mlp_h2_wgrad(c_int(self.mode), ptr(g_out), c_int64(self.n), c_int(self.nf), c_int(self.n_hidden), c_int(self.skip), ptr(self.A),
+                                        ptr(self.EMB), ptr(D), _ptr_array(dW), _ptr_array(db), stream()), "gs_sdf_mlp_h2_wgrad")
+        if self.mode == 1:      # output bias: sum of the upstream gradient over the (value) rows
+            db[-1].copy_(g_out.sum().reshape(db[-1].shape))
+        return [grads[id(p)] for p in params]
+
+
+def row_sparse_backward(net, x, g_y, need_x):
+    """(d loss / d x [N,3] or None, [d loss / d p for p in net.parameters()]) from the upstream gradient g_y [N,1],
+    touching only the rows where g_y != 0: they are recomputed by the h2 chain kernels (csrc/mlp_h2.hip: forward with saved
+    planes -> backward chain -> weight gradients on the matrix cores); the full-grid forward pass keeps no activations."""
+    if not (_fusable(net, x) and g_y.is_cuda):
+        return row_sparse_backward_torch(net, x, g_y, need_x)
+    g = g_y.detach().reshape(-1).float()
+    rows = torch.nonzero(g != 0).reshape(-1).int()                  # one host sync (the count sizes the saved planes)
+    g_x = torch.zeros_like(x) if need_x else None
+    n = int(rows.numel())
+    if n == 0:
+        return g_x, [torch.zeros_like(p) for p in net.parameters()]
+    saved = _SavedChain(net, 1, x.detach().contiguous(), rows, n)
+    g_rows = torch.zeros((saved.Rpad,), dtype=torch.float32, device=x.device)
+    g_rows[:n] = g[rows.long()]
+    return g_x, saved.backward(g_rows, g_x)
+
+
+class _EikonalFn(torch.autograd.Function):
+    """sum_i (|grad_x f(x_i)| - 1)^2 with gradients w.r.t. the network parameters (reference geometry/gshell_tets_geometry.py:
+    302-324: autograd.grad(..., create_graph=True) + a second backward).  Here: forward-mode tangents through the chain kernel
+    (4 virtual rows per sample), then ONE reverse pass over those rows -- no double backward, no hipBLASLt."""
+
+    @staticmethod
+    def forward(ctx, pts, net, *params):
+        n = pts.shape[0]
+        saved = _SavedChain(net, 2, pts.detach().contiguous().float(), None, n)
+        tiles = saved.Rpad // 64
+        J = saved.out.view(tiles, 4, 16)[:, 1:4, :].permute(0, 2, 1).reshape(tiles * 16, 3)[:n]
+        nrm = J.pow(2).sum(dim=-1).sqrt()
+        ctx.saved, ctx.n = saved, n
+        ctx.save_for_backward(J, nrm)
+        return (nrm - 1).pow(2).sum()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        J, nrm = ctx.saved_tensors
+        saved, n = ctx.saved, ctx.n
+        tiles = saved.Rpad // 64
+        gJ = (g * 2.0 * (nrm - 1) / nrm.clamp_min(1e-20))[:, None] * J                  # [n,3]
+        gv = torch.zeros((tiles * 16, 4), dtype=torch.float32, device=J.device)
+        gv[:n, 1:4] = gJ
+        g_out = gv.view(tiles, 16, 4).permute(0, 2, 1).contiguous().reshape(-1)       # virtual-row order 64 t + 16 c + i
+        grads = saved.backward(g_out)
+        ctx.saved = None
+        return (None, None) + tuple(grads)
+
+
+def eikonal_sq_sum(net, pts):
+    """sum_i (|d net / d x (pts_i)| - 1)^2, differentiable w.r.t. the parameters of `net` (the points are constants, as in the
+    reference, which detaches them)."""
+    if _fusable(net, pts):
+        return _EikonalFn.apply(pts, net, *list(net.parameters()))
+    v = pts.detach().requires_grad_(True)
+    grad = torch.autograd.grad(net(v).sum(), v, create_graph=True)[0]
+    return (grad.pow(2).sum(dim=-1).sqrt() - 1).pow(2).sum()
 
 
 class _RowShardedForward(torch.autograd.Function):

@@ -434,6 +434,31 @@ int gs_sdf_mlp_fwd_h2(const float* x, int64_t N, const void* packed, int n_freq,
                       int skip_layer, float* out, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * SDF network, gradients   (replaces autograd through geometry/mlp.py:32-40 as used by
+ *   geometry/gshell_tets_geometry.py:194 [d loss / d sdf of the grid rows that carry gradient] and the eikonal term
+ *   :302-324 [autograd.grad(create_graph=True) + second backward])          -- csrc/mlp_h2.hip
+ *   Three launches over n (virtual) rows, all through HBM-resident fp32 planes owned by the caller:
+ *     save_fwd : recompute the rows through the h2 chain and save every layer's output  A [n_hidden+1][Rpad][256], EMB [Rpad][48]
+ *     bwd      : reverse chain -> D [n_hidden+1][Rpad][256] = d loss / d pre-activation; mode 1 also d loss / d x
+ *     wgrad    : dW_l += D_l^T [A_{l-1} | EMB], db_l += column sums of D_l   (fp32 MFMA, float atomics across row strips)
+ *   mode 1 (ROWS): rows[0..n) index x [N,3] (row-sparse backward).   mode 2 (EIK): x = n sample points; every sample is FOUR
+ *   virtual rows (value, d/dx, d/dy, d/dz): forward-mode tangents ride the same GEMMs, out[64 t + 16 c + i] = df/dx_{c-1}
+ *   of sample 16 t + i (c = 1..3), and ONE reverse pass over the virtual rows yields the parameter gradient of any loss of
+ *   grad_x f (g_out = d loss / d out on the tangent rows, 0 on the value rows).  Rpad = gs_sdf_mlp_h2_rows_padded(mode, n).
+ *   dW / db: HOST arrays of n_hidden + 2 DEVICE pointers (torch layout, output layer last), ACCUMULATED; db[last] untouched.
+ * ---------------------------------------------------------------------------------- */
+int64_t gs_sdf_mlp_h2_rows_padded(int mode, int64_t n);
+int gs_sdf_mlp_h2_save_fwd(int mode, const float* x, const int32_t* rows, int64_t n, const void* packed,
+                           int n_freq, int n_hidden, int skip_layer, float* A_save, float* EMB_save,
+                           float* out, gs_stream_t stream);
+int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* rows, int64_t n, const void* packed,
+                      int n_freq, int n_hidden, int skip_layer, const float* A_save,
+                      const float* EMB_save, float* D_save, float* g_x, gs_stream_t stream);
+int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, int n_freq, int n_hidden, int skip_layer,
+                        const float* A_save, const float* EMB_save, const float* D_save,
+                        float* const* dW, float* const* db, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * G-FlexiCubes topology   (replaces the index machinery of GShellFlexiCubes.__call__,
  *   geometry/gshell_flexicubes.py:136-230: _identify_surf_cubes :334, _get_case_id :266, _identify_surf_edges :309,
  *   the edge-group tables of _compute_vd :406-485 and the quad gathering / splitting of _triangulate :493-522)

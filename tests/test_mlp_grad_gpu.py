@@ -1,0 +1,100 @@
+"""Hand-written gradient path of the SDF network (csrc/mlp_h2.hip: save_fwd -> bwd chain -> wgrad) against torch autograd of
+the SAME network in float64 (reference formulation: geometry/mlp.py:32-40 under autograd, and the eikonal term's
+autograd.grad(create_graph=True) + second backward, geometry/gshell_tets_geometry.py:302-324).  Tolerance 1e-4 relative
+(north_star) -- the kernels sit two orders below it."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _net(n_hidden=6, skip_in=(3,), seed=0):
+    from gshell_amd.geometry.mlp import MLP
+    torch.manual_seed(seed)
+    net = MLP(skip_in=list(skip_in), n_freq=6, n_hidden=n_hidden, d_hidden=256)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.05)
+    return net.to(DEV)
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
+
+
+@pytest.mark.parametrize("n_hidden,skip_in,need_x", [(6, (3,), True), (6, (3,), False), (2, (), True)])
+def test_row_sparse_backward_matches_float64_autograd(n_hidden, skip_in, need_x):
+    from gshell_amd.geometry.mlp import row_sparse_backward, row_sparse_backward_torch
+    net = _net(n_hidden, skip_in)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    N = 5000 + 13
+    x = (torch.rand(N, 3, device=DEV, generator=g) * 1.4 - 0.7).contiguous()
+    gy = torch.zeros(N, 1, device=DEV)
+    idx = torch.arange(0, N, 3, device=DEV)
+    # upstream gradients spanning six decades (means over 10^6 pixels give 1e-8 .. 1e-2 in training)
+    gy[idx, 0] = torch.randn(idx.numel(), device=DEV, generator=g) * torch.pow(10.0, torch.rand(idx.numel(), device=DEV, generator=g) * 6 - 8)
+    g_x, grads = row_sparse_backward(net, x, gy, need_x)
+    net64 = copy.deepcopy(net).double()
+    x64 = x.double().requires_grad_(True)
+    ref = torch.autograd.grad(net64(x64), [x64] + list(net64.parameters()), gy.double())
+    if need_x:
+        assert _rel(g_x, ref[0]) < 1e-4
+        rows_without = torch.ones(N, dtype=torch.bool, device=DEV)
+        rows_without[idx] = False
+        assert float(g_x[rows_without].abs().max()) == 0.0
+    else:
+        assert g_x is None
+    for (name, _), a, b in zip(net.named_parameters(), grads, ref[1:]):
+        assert a.shape == b.shape
+        assert _rel(a, b) < 1e-4, (name, _rel(a, b))
+    # and the fp32 torch formulation it replaces is no closer to float64 than a factor of a few
+    _, grads_t = row_sparse_backward_torch(net, x, gy, False)
+    worst_hip = max(_rel(a, b) for a, b in zip(grads, ref[1:]))
+    worst_torch = max(_rel(a, b) for a, b in zip(grads_t, ref[1:]))
+    assert worst_hip < max(20 * worst_torch, 2e-6), (worst_hip, worst_torch)
+
+
+@pytest.mark.parametrize("n", [1000 + 7, 16])
+def test_eikonal_term_matches_float64_double_backward(n):
+    from gshell_amd.geometry.mlp import eikonal_sq_sum
+    net = _net()
+    g = torch.Generator(device=DEV).manual_seed(2)
+    pts = (torch.rand(n, 3, device=DEV, generator=g) * 1.2 - 0.6).contiguous()
+    loss = eikonal_sq_sum(net, pts) * 0.37
+    grads = torch.autograd.grad(loss, list(net.parameters()))
+    net64 = copy.deepcopy(net).double()
+    v = pts.double().requires_grad_(True)
+    gr = torch.autograd.grad(net64(v).sum(), v, create_graph=True)[0]
+    loss64 = (gr.pow(2).sum(dim=-1).sqrt() - 1).pow(2).sum() * 0.37
+    ref = torch.autograd.grad(loss64, list(net64.parameters()), allow_unused=True)
+    assert abs(float(loss) - float(loss64)) <= 1e-5 * abs(float(loss64))
+    for (name, p), a, b in zip(net.named_parameters(), grads, ref):
+        if b is None:                      # the output bias does not influence grad_x f
+            assert float(a.abs().max()) == 0.0, name
+            continue
+        assert _rel(a, b) < 1e-4, (name, _rel(a, b))
+
+
+def test_eikonal_gradient_of_network_output_equals_autograd():
+    """The tangent rows themselves: df/dx from the forward-mode pass vs autograd of the fp64 network."""
+    from gshell_amd.geometry.mlp import _SavedChain
+    net = _net()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    n = 333
+    pts = (torch.rand(n, 3, device=DEV, generator=g) - 0.5).contiguous()
+    saved = _SavedChain(net, 2, pts, None, n)
+    tiles = saved.Rpad // 64
+    ov = saved.out.view(tiles, 4, 16)
+    J = ov[:, 1:4, :].permute(0, 2, 1).reshape(tiles * 16, 3)[:n]
+    f = ov[:, 0, :].reshape(-1)[:n]
+    net64 = copy.deepcopy(net).double()
+    v = pts.double().requires_grad_(True)
+    y = net64(v)
+    gr = torch.autograd.grad(y.sum(), v)[0]
+    lin = [m for m in net64.net if isinstance(m, torch.nn.Linear)]
+    assert float((f.double() + lin[-1].bias - y[:, 0]).abs().max()) < 2e-6
+    assert float((J.double() - gr).abs().max()) < 1e-5 * float(gr.abs().max())
