@@ -474,6 +474,178 @@ __global__ void __launch_bounds__(256) k_texture_linear(const float* __restrict_
     }
 }
 
+// ---- shade() buffer assembly + background composite in one pass --------------------------------------------------
+// Replaces the torch tail of render.shade / render_mesh (reference render/render.py:74 ks_grad mask, :105-112 normal
+// regulariser, :160-186 kd * (1 - metalness), shaded = diffuse * kd + specular and the ~11 torch.cat((buffer, alpha)) of the
+// buffer dictionary, :352-359 + :417-433 composite of every buffer over its background, and the division col / weight that
+// follows the bilateral denoiser, optixutils/ops.py:145-147): ~60 forward and ~80 backward ATen launches over 4 x 512^2
+// frames.  One thread per pixel writes the 45 composited channels
+//   shaded(4) z_grad(4) normal(4) geometric_normal(4) kd(4) ks(4) kd_grad(4) ks_grad(4) normal_grad(4) diffuse_light(4)
+//   specular_light(4) [msdf_image(1)]
+// staged through LDS so that the [P,45] frame is written in full lines.  alpha is 1 (3-channel kd), so the lerp of the
+// composite selects foreground where a triangle covers the pixel and background elsewhere, exactly as torch.lerp with a in {0,1}.
+struct AssembleArgs {
+    const float *rast, *tex, *texj, *n_in, *n_jit, *mask_tap, *n_shade, *n_geo, *depth, *dcw, *scw, *msdf, *bg;
+    int64_t P, HW;
+    int bg_views;      // 1: one background image broadcast over the views
+    int cw_channels;   // 4: (sum w c, sum w) from the bilateral filter; 3: raw radiance (no denoiser)
+    int C;             // 44, or 45 with the mSDF image
+    float* out;
+    const float* g_out;
+    float *g_tex, *g_texj, *g_n_in, *g_n_jit, *g_n_shade, *g_n_geo, *g_dcw, *g_scw, *g_msdf;
+};
+
+constexpr int AS_MAXC = 45;
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_shade_assemble(AssembleArgs A) {
+    __shared__ float tile[256 * AS_MAXC];
+    const int t = threadIdx.x, C = A.C;
+    const int64_t p0 = (int64_t)blockIdx.x * 256, p = p0 + t;
+    const int64_t n_here = min((int64_t)256, A.P - p0);
+    if (BWD) {      // coalesced load of the upstream gradient tile
+        for (int64_t i = t; i < n_here * C; i += 256) tile[i] = A.g_out[p0 * C + i];
+        __syncthreads();
+    }
+    if (p < A.P) {
+        float* o = tile + t * C;
+        const bool cover = A.rast[4 * p + 3] > 0.0f;
+        if (!BWD) {
+#pragma unroll 5
+            for (int c = 0; c < C; ++c) o[c] = 0.0f;
+        }
+        if (!cover) {
+            if (!BWD) {
+                const float* b = A.bg + 3 * (A.bg_views == 1 ? p % A.HW : p);
+                o[0] = b[0]; o[1] = b[1]; o[2] = b[2];
+            } else {
+                for (int c = 0; c < 6; ++c) { A.g_tex[6 * p + c] = 0.f; A.g_texj[6 * p + c] = 0.f; }
+                for (int c = 0; c < 3; ++c) { A.g_n_in[3 * p + c] = 0.f; A.g_n_jit[3 * p + c] = 0.f; A.g_n_shade[3 * p + c] = 0.f; A.g_n_geo[3 * p + c] = 0.f; }
+                for (int c = 0; c < A.cw_channels; ++c) { A.g_dcw[A.cw_channels * p + c] = 0.f; A.g_scw[A.cw_channels * p + c] = 0.f; }
+                if (A.g_msdf) A.g_msdf[p] = 0.f;
+            }
+        } else {
+            float kd[3], ks[3], kdj[3], ksj[3], ni[3], nj[3], dif[3], spc[3];
+            for (int c = 0; c < 3; ++c) {
+                kd[c] = A.tex[6 * p + c]; ks[c] = A.tex[6 * p + 3 + c];
+                kdj[c] = A.texj[6 * p + c]; ksj[c] = A.texj[6 * p + 3 + c];
+                ni[c] = A.n_in[3 * p + c]; nj[c] = A.n_jit[3 * p + c];
+            }
+            const int cw = A.cw_channels;
+            const float dw = cw == 4 ? A.dcw[4 * p + 3] : 1.0f, sw = cw == 4 ? A.scw[4 * p + 3] : 1.0f;
+            for (int c = 0; c < 3; ++c) {
+                dif[c] = cw == 4 ? A.dcw[4 * p + c] / dw : A.dcw[3 * p + c];
+                spc[c] = cw == 4 ? A.scw[4 * p + c] / sw : A.scw[3 * p + c];
+            }
+            const float om = 1.0f - ks[2];                 // 1 - metalness
+            const float gw = A.mask_tap[p];                // mask (= 1 here) * jittered mask tap
+            const float ksm[3] = {0.0f, 1.0f, 1.0f};       // the o-component of ks is left out of its regulariser
+            if (!BWD) {
+                for (int c = 0; c < 3; ++c) {
+                    const float kdm = kd[c] * om;
+                    o[c] = dif[c] * kdm + spc[c];
+                    o[8 + c] = A.n_shade[3 * p + c];
+                    o[12 + c] = A.n_geo[3 * p + c];
+                    o[16 + c] = kdm;
+                    o[20 + c] = ks[c];
+                    o[24 + c] = fabsf(kdj[c] - kd[c]);
+                    o[28 + c] = fabsf(ksj[c] - ks[c]) * ksm[c];
+                    o[32 + c] = fabsf(nj[c] - ni[c]) * gw;
+                    o[36 + c] = dif[c];
+                    o[40 + c] = spc[c];
+                }
+                o[4] = A.depth[2 * p]; o[5] = A.depth[2 * p + 1]; o[6] = 0.0f;
+                for (int b = 0; b < 11; ++b) o[4 * b + 3] = 1.0f;
+                if (C > 44) o[44] = A.msdf[p];
+            } else {
+                const float* g = o;
+                float g_ks2 = 0.0f, g_dw = 0.0f, g_sw = 0.0f;
+                for (int c = 0; c < 3; ++c) {
+                    const float kdm = kd[c] * om;
+                    const float g_kdm = g[c] * dif[c] + g[16 + c];
+                    const float g_dif = g[c] * kdm + g[36 + c];
+                    const float g_spc = g[c] + g[40 + c];
+                    const float s_kd = sgnf(kdj[c] - kd[c]) * g[24 + c];
+                    const float s_ks = sgnf(ksj[c] - ks[c]) * ksm[c] * g[28 + c];
+                    const float s_n = sgnf(nj[c] - ni[c]) * gw * g[32 + c];
+                    A.g_tex[6 * p + c] = g_kdm * om - s_kd;
+                    g_ks2 -= g_kdm * kd[c];
+                    A.g_tex[6 * p + 3 + c] = g[20 + c] - s_ks;          // metalness term added below
+                    A.g_texj[6 * p + c] = s_kd;
+                    A.g_texj[6 * p + 3 + c] = s_ks;
+                    A.g_n_in[3 * p + c] = -s_n;
+                    A.g_n_jit[3 * p + c] = s_n;
+                    A.g_n_shade[3 * p + c] = g[8 + c];
+                    A.g_n_geo[3 * p + c] = g[12 + c];
+                    if (cw == 4) {
+                        A.g_dcw[4 * p + c] = g_dif / dw;
+                        A.g_scw[4 * p + c] = g_spc / sw;
+                        g_dw -= g_dif * dif[c] / dw;
+                        g_sw -= g_spc * spc[c] / sw;
+                    } else {
+                        A.g_dcw[3 * p + c] = g_dif;
+                        A.g_scw[3 * p + c] = g_spc;
+                    }
+                }
+                A.g_tex[6 * p + 5] += g_ks2;
+                if (cw == 4) { A.g_dcw[4 * p + 3] = g_dw; A.g_scw[4 * p + 3] = g_sw; }
+                if (A.g_msdf) A.g_msdf[p] = C > 44 ? g[44] : 0.0f;
+            }
+        }
+    }
+    if (!BWD) {
+        __syncthreads();
+        for (int64_t i = t; i < n_here * C; i += 256) A.out[p0 * C + i] = tile[i];
+    }
+}
+
+}  // namespace
+
+static int assemble_check(const AssembleArgs& A) {
+    GS_REQUIRE(A.rast && A.tex && A.texj && A.n_in && A.n_jit && A.mask_tap && A.n_shade && A.n_geo && A.depth && A.dcw && A.scw && A.bg,
+               "gs_shade_assemble: null pointer");
+    GS_REQUIRE((A.C == 44 && !A.msdf) || (A.C == 45 && A.msdf), "gs_shade_assemble: C must be 44, or 45 with an mSDF image");
+    GS_REQUIRE(A.cw_channels == 3 || A.cw_channels == 4, "gs_shade_assemble: radiance inputs have 3 (raw) or 4 (filtered sum, weight) channels");
+    return 0;
+}
+
+extern "C" int gs_shade_assemble_fwd(const float* rast, const float* tex, const float* tex_jitter, const float* n_interp, const float* n_jitter,
+                                     const float* mask_tap, const float* n_shade, const float* n_geo, const float* depth, const float* diffuse,
+                                     const float* specular, int cw_channels, const float* msdf_image, const float* background, int bg_views,
+                                     int64_t B, int64_t H, int64_t W, float* out, gs_stream_t stream) {
+    if (B * H * W == 0) return 0;
+    AssembleArgs A{};
+    A.rast = rast; A.tex = tex; A.texj = tex_jitter; A.n_in = n_interp; A.n_jit = n_jitter; A.mask_tap = mask_tap; A.n_shade = n_shade; A.n_geo = n_geo;
+    A.depth = depth; A.dcw = diffuse; A.scw = specular; A.msdf = msdf_image; A.bg = background; A.P = B * H * W; A.HW = H * W; A.bg_views = bg_views;
+    A.cw_channels = cw_channels; A.C = msdf_image ? 45 : 44; A.out = out;
+    if (int rc = assemble_check(A)) return rc;
+    GS_REQUIRE(out && (bg_views == 1 || bg_views == B), "gs_shade_assemble_fwd: null output / background views");
+    hipLaunchKernelGGL(k_shade_assemble<false>, dim3((unsigned)gs::cdiv(A.P, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_shade_assemble_bwd(const float* rast, const float* tex, const float* tex_jitter, const float* n_interp, const float* n_jitter,
+                                     const float* mask_tap, const float* n_shade, const float* n_geo, const float* depth, const float* diffuse,
+                                     const float* specular, int cw_channels, const float* msdf_image, int64_t B, int64_t H, int64_t W,
+                                     const float* g_out, float* g_tex, float* g_tex_jitter, float* g_n_interp, float* g_n_jitter, float* g_n_shade,
+                                     float* g_n_geo, float* g_diffuse, float* g_specular, float* g_msdf_image, gs_stream_t stream) {
+    if (B * H * W == 0) return 0;
+    AssembleArgs A{};
+    A.rast = rast; A.tex = tex; A.texj = tex_jitter; A.n_in = n_interp; A.n_jit = n_jitter; A.mask_tap = mask_tap; A.n_shade = n_shade; A.n_geo = n_geo;
+    A.depth = depth; A.dcw = diffuse; A.scw = specular; A.msdf = msdf_image; A.bg = rast /* unused */; A.P = B * H * W; A.HW = H * W; A.bg_views = 1;
+    A.cw_channels = cw_channels; A.C = msdf_image ? 45 : 44; A.g_out = g_out;
+    A.g_tex = g_tex; A.g_texj = g_tex_jitter; A.g_n_in = g_n_interp; A.g_n_jit = g_n_jitter; A.g_n_shade = g_n_shade; A.g_n_geo = g_n_geo;
+    A.g_dcw = g_diffuse; A.g_scw = g_specular; A.g_msdf = g_msdf_image;
+    if (int rc = assemble_check(A)) return rc;
+    GS_REQUIRE(g_out && g_tex && g_tex_jitter && g_n_interp && g_n_jitter && g_n_shade && g_n_geo && g_diffuse && g_specular && (!msdf_image || g_msdf_image),
+               "gs_shade_assemble_bwd: null pointer");
+    hipLaunchKernelGGL(k_shade_assemble<true>, dim3((unsigned)gs::cdiv(A.P, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+namespace {
 }  // namespace
 
 extern "C" int gs_shading_normal_fwd(const float* pos, const float* view_pos, int view_full, const float* perturbed_nrm, const float* smooth_nrm,

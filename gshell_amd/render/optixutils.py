@@ -189,6 +189,11 @@ class _bilateral_denoiser_func(torch.autograd.Function):
         return g_col, None, None, None
 
 
+def bilateral_denoiser_raw(col, nrm, zdz, sigma):
+    """[B,H,W,4] = (sum w c, max(sum w, 1e-4)): the kernel's own output (denoising.cu:66-70), before the reference's division."""
+    return _bilateral_denoiser_func.apply(col, nrm, zdz, sigma)
+
+
 def bilateral_denoiser(col, nrm, zdz, sigma):
     col_w = _bilateral_denoiser_func.apply(col, nrm, zdz, sigma)
     return col_w[..., 0:3] / col_w[..., 3:4]

@@ -99,11 +99,60 @@ def _sample_texture(tex, pos, mask):
         return tex.sample(pos)
 
 
+class _ShadeAssembleFn(torch.autograd.Function):
+    """The tail of shade() + the background composite of render_mesh as ONE kernel pair (gs_shade_assemble_fwd / bwd):
+    -> [B,H,W,44 | 45] = shaded z_grad normal geometric_normal kd ks kd_grad ks_grad normal_grad diffuse_light specular_light
+    [msdf_image], every buffer with its alpha channel, composited over the background (shaded) or zero."""
+
+    @staticmethod
+    def forward(ctx, rast, tex, texj, n_in, n_jit, mask_tap, n_shade, n_geo, depth, dif, spc, msdf_img, background):
+        from .. import _lib
+        from .._lib import c_int, c_int64, check, ptr, stream
+        B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
+        f = lambda t: None if t is None else t.detach().contiguous().float()
+        t = [f(x) for x in (rast, tex, texj, n_in, n_jit, mask_tap, n_shade, n_geo, depth, dif, spc, msdf_img, background)]
+        cw = int(t[9].shape[-1])
+        C = 45 if msdf_img is not None else 44
+        out = torch.empty((B, H, W, C), dtype=torch.float32, device=rast.device)
+        with torch.cuda.device(rast.device):
+            check(_lib.lib().gs_shade_assemble_fwd(*[ptr(x) for x in t[:11]], c_int(cw), ptr(t[11]), ptr(t[12]), c_int(int(t[12].shape[0])), c_int64(B), c_int64(H),
+                                                   c_int64(W), ptr(out), stream()), "gs_shade_assemble_fwd")
+        ctx.t, ctx.cw, ctx.dims = t, cw, (B, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        from .. import _lib
+        from .._lib import c_int, c_int64, check, ptr, stream
+        t, cw, (B, H, W) = ctx.t, ctx.cw, ctx.dims
+        dev = g_out.device
+        g = g_out.contiguous().float()
+        e = lambda c: torch.empty((B, H, W, c), dtype=torch.float32, device=dev)
+        g_tex, g_texj, g_nin, g_njit, g_nsh, g_ngeo, g_dif, g_spc = e(6), e(6), e(3), e(3), e(3), e(3), e(cw), e(cw)
+        g_msdf = e(1) if t[11] is not None else None
+        with torch.cuda.device(dev):
+            check(_lib.lib().gs_shade_assemble_bwd(*[ptr(x) for x in t[:11]], c_int(cw), ptr(t[11]), c_int64(B), c_int64(H), c_int64(W), ptr(g), ptr(g_tex),
+                                                   ptr(g_texj), ptr(g_nin), ptr(g_njit), ptr(g_nsh), ptr(g_ngeo), ptr(g_dif), ptr(g_spc), ptr(g_msdf), stream()),
+                  "gs_shade_assemble_bwd")
+        ctx.t = None
+        return None, g_tex, g_texj, g_nin, g_njit, None, g_nsh, g_ngeo, None, g_dif, g_spc, g_msdf, None
+
+
+class PendingFrame:
+    """What shade() hands to render_mesh on the fused path: the per-pixel inputs of gs_shade_assemble (the buffer dictionary
+    of the reference is materialised by the composite, as channel slices of one tensor)."""
+    KEYS = ['shaded', 'z_grad', 'normal', 'geometric_normal', 'kd', 'ks', 'kd_grad', 'ks_grad', 'normal_grad', 'diffuse_light', 'specular_light']
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+        self.msdf_image = None
+
+
 # ==============================================================================================
 #  pixel shader
 # ==============================================================================================
 def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_texc, gb_texc_deriv, view_pos, lgt, material, optix_ctx,
-          mesh, bsdf, denoiser, shadow_scale, use_uv=True, finetune_normal=True, xfm_lgt=None, shade_data=False):
+          mesh, bsdf, denoiser, shadow_scale, use_uv=True, finetune_normal=True, xfm_lgt=None, shade_data=False, _defer=False):
     dev = gb_pos.device
     B, H, W = gb_depth.shape[0], gb_depth.shape[1], gb_depth.shape[2]
     offset = _noise('jitter', lambda: torch.normal(mean=0, std=0.005, size=(B, H, W, 2), device=dev), FLAGS, 0.005, (B, H, W, 2), dev)
@@ -121,8 +170,11 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
         all_tex = _sample_texture(material['kd_ks'], gb_pos, mask)
         assert all_tex.shape[-1] == 6, "Combined kd_ks must be 6 channels"
         kd, ks = all_tex[..., 0:3], all_tex[..., 3:6]
-        kd_grad = torch.abs(all_tex_jitter[..., 0:3] - kd)
-        ks_grad = torch.abs(all_tex_jitter[..., 3:6] - ks) * _const_011(dev)      # omit the o-component (reference :74)
+        if not (_defer and getattr(FLAGS, "fused_assemble", True)):
+            kd_grad = torch.abs(all_tex_jitter[..., 0:3] - kd)
+            ks_grad = torch.abs(all_tex_jitter[..., 3:6] - ks) * _const_011(dev)      # omit the o-component (reference :74)
+        else:
+            kd_grad = ks_grad = None
     else:
         raise NotImplementedError("only the combined 'kd_ks' material of the G-Shell scripts is supported (uv-textured materials need "
                                   "mip-mapped texture sampling, which the G-Shell path never enters)")
@@ -134,7 +186,10 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
     if (not finetune_normal) or ('no_perturbed_nrm' in material and material['no_perturbed_nrm']):
         perturbed_nrm = None
     nrm_jitter = dr.texture(gb_normal.contiguous(), jitter, filter_mode='linear', boundary_mode='clamp')
-    nrm_grad = torch.abs(nrm_jitter - gb_normal) * grad_weight
+    gb_normal_interp = gb_normal
+    fused = (_defer and getattr(FLAGS, "fused_assemble", True) and (material['bsdf'] if bsdf is None else bsdf) == 'pbr'
+             and kd.shape[-1] == 3 and (denoiser is None or (FLAGS.denoiser_demodulate and hasattr(denoiser, "filter_raw"))))
+    nrm_grad = None if fused else torch.abs(nrm_jitter - gb_normal) * grad_weight
 
     gb_normal = ru.prepare_shading_normal(gb_pos, view_pos, perturbed_nrm, gb_normal, gb_tangent, gb_geometric_normal, two_sided_shading=True,
                                           opengl=True)
@@ -153,6 +208,16 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
                                                            rnd_seed=None if FLAGS.decorrelated else rnd_seed, shadow_scale=shadow_scale,
                                                            **_view_map(FLAGS))
         rnd_seed += 1
+        if fused:
+            # everything below (demodulated filtering weights, kd * (1 - metalness), the buffer dictionary with its alpha
+            # channels) happens inside gs_shade_assemble, called by render_mesh once the background is known
+            if denoiser is not None:
+                with torch.no_grad():
+                    nrm_unit = util.safe_normalize(gb_normal)       # the filter's guides carry no gradient (optixutils.py backward)
+                diffuse_accum = denoiser.filter_raw(diffuse_accum, nrm_unit, gb_depth)        # [B,H,W,4] = (sum w c, sum w)
+                specular_accum = denoiser.filter_raw(specular_accum, nrm_unit, gb_depth)
+            return PendingFrame(tex=all_tex, texj=all_tex_jitter, n_in=gb_normal_interp, n_jit=nrm_jitter, mask_tap=grad_weight, n_shade=gb_normal,
+                                n_geo=gb_geometric_normal, depth=gb_depth, dif=diffuse_accum, spc=specular_accum)
         if denoiser is not None and FLAGS.denoiser_demodulate:
             diffuse_accum = denoiser.forward(torch.cat((diffuse_accum, gb_normal, gb_depth), dim=-1))
             specular_accum = denoiser.forward(torch.cat((specular_accum, gb_normal, gb_depth), dim=-1))
@@ -174,6 +239,11 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
     else:
         assert False, "Invalid BSDF '%s'" % bsdf
 
+    if kd_grad is None:          # the fused path was requested but this configuration is not covered by the kernel
+        kd_grad = torch.abs(all_tex_jitter[..., 0:3] - all_tex[..., 0:3])
+        ks_grad = torch.abs(all_tex_jitter[..., 3:6] - ks) * _const_011(dev)
+    if nrm_grad is None:
+        nrm_grad = torch.abs(nrm_jitter - gb_normal_interp) * grad_weight
     buffers = {
         'shaded': torch.cat((shaded_col, alpha), dim=-1),
         'z_grad': torch.cat((gb_depth, torch.zeros_like(alpha), alpha), dim=-1),
@@ -196,7 +266,7 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
 #  one depth layer
 # ==============================================================================================
 def render_layer(FLAGS, v_pos_clip, rast, rast_deriv, mesh, view_pos, lgt, resolution, spp, msaa, optix_ctx, bsdf, denoiser, shadow_scale,
-                 use_uv=True, finetune_normal=True, extra_dict=None, xfm_lgt=None, shade_data=False):
+                 use_uv=True, finetune_normal=True, extra_dict=None, xfm_lgt=None, shade_data=False, _defer=False):
     full_res = [resolution[0] * spp, resolution[1] * spp]
     if spp > 1 and msaa:
         rast_out_s = util.scale_img_nhwc(rast, resolution, mag='nearest', min='nearest')
@@ -239,7 +309,10 @@ def render_layer(FLAGS, v_pos_clip, rast, rast_deriv, mesh, view_pos, lgt, resol
 
     buffers = shade(FLAGS, rast_out_s, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_texc, gb_texc_deriv, view_pos, lgt,
                     mesh.material, optix_ctx, mesh, bsdf, denoiser, shadow_scale, use_uv=use_uv, finetune_normal=finetune_normal, xfm_lgt=xfm_lgt,
-                    shade_data=shade_data)
+                    shade_data=shade_data, _defer=_defer and spp == 1)
+    if isinstance(buffers, PendingFrame):
+        buffers.msdf_image = gb[..., 6:7] if msdf is not None else None
+        return buffers
     if msdf is not None:
         buffers['msdf_image'] = gb[..., 6:7]
     if spp > 1 and msaa:
@@ -298,7 +371,7 @@ def render_mesh(FLAGS, ctx, mesh, mtx_in, view_pos, lgt, resolution, spp=1, num_
     visible_triangles = torch.nonzero(vis).reshape(-1)          # sorted ids == rast[...,-1].long().unique() - 1
 
     buffers = render_layer(FLAGS, v_pos_clip, rast, db, mesh, view_pos, lgt, resolution, spp, msaa, optix_ctx, bsdf, denoiser, shadow_scale,
-                           use_uv=use_uv, finetune_normal=finetune_normal, extra_dict=extra_dict, xfm_lgt=xfm_lgt, shade_data=shade_data)
+                           use_uv=use_uv, finetune_normal=finetune_normal, extra_dict=extra_dict, xfm_lgt=xfm_lgt, shade_data=shade_data, _defer=True)
 
     if background is not None:
         if spp > 1:
@@ -311,8 +384,20 @@ def render_mesh(FLAGS, ctx, mesh, mtx_in, view_pos, lgt, resolution, spp=1, num_
     # over the ~12 buffers (render.py:417-433: alpha, cat, lerp, antialias each); here the buffers are stacked once along
     # the channel axis and composited with a handful of whole-stack ops: out = lerp(bg, [rgb.., 1], cover * alpha_of_group).
     cover = (rast[..., -1:] > 0).float()
-    keys = [k for k, b in buffers.items() if b is not None]
-    if keys:
+    if isinstance(buffers, PendingFrame):
+        pf = buffers
+        keys = list(PendingFrame.KEYS) + (['msdf_image'] if pf.msdf_image is not None else [])
+        sizes = [4] * 11 + ([1] if pf.msdf_image is not None else [])
+        comp = _ShadeAssembleFn.apply(rast, pf.tex, pf.texj, pf.n_in, pf.n_jit, pf.mask_tap, pf.n_shade, pf.n_geo, pf.depth, pf.dif, pf.spc,
+                                      pf.msdf_image, background[..., 0:3])
+        aa = dr.antialias_stacked([comp], rast, v_pos_clip, tri)[0]
+        out_list = list(torch.split(aa, sizes, dim=-1))
+        buffers = None
+    else:
+        keys = [k for k, b in buffers.items() if b is not None]
+    if buffers is None:
+        pass
+    elif keys:
         sizes = [buffers[k].shape[-1] for k in keys]
         layout = _composite_layout(tuple(sizes), dev)
         stacked = torch.cat([buffers[k] for k in keys], dim=-1)                       # [B,H,W,sum C]

@@ -404,6 +404,28 @@ int gs_face_normal_bwd(const float* v_pos, int64_t V, const int32_t* tri, int64_
                        gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * shade() buffer assembly + background composite   (replaces the torch tail of render/render.py:74, :105-112, :160-186,
+ *   the composite :352-359 / :417-433 and the division after ou.bilateral_denoiser, optixutils/ops.py:145-147)
+ *   Inputs per pixel: rast [P,4] (coverage = rast.w > 0), tex / tex_jitter [P,6] (kd, ks and their jittered taps),
+ *   n_interp / n_jitter [P,3] (smooth normal, its jittered tap), mask_tap [P] (mask * jittered mask), n_shade / n_geo [P,3],
+ *   depth [P,2], diffuse / specular [P,cw] (cw = 4: (sum w c, sum w) of the bilateral filter; cw = 3: raw radiance),
+ *   msdf_image [P] or NULL, background [bg_views (1 or B),H,W,3].
+ *   out [P, 44 | 45] = shaded z_grad normal geometric_normal kd ks kd_grad ks_grad normal_grad diffuse_light specular_light
+ *   [msdf_image], each 4-channel buffer with alpha = 1, composited over (background, 0) / zero.  bwd: all g_* WRITTEN.
+ * ---------------------------------------------------------------------------------- */
+int gs_shade_assemble_fwd(const float* rast, const float* tex, const float* tex_jitter, const float* n_interp,
+                          const float* n_jitter, const float* mask_tap, const float* n_shade, const float* n_geo,
+                          const float* depth, const float* diffuse, const float* specular, int cw_channels,
+                          const float* msdf_image, const float* background, int bg_views, int64_t B, int64_t H,
+                          int64_t W, float* out, gs_stream_t stream);
+int gs_shade_assemble_bwd(const float* rast, const float* tex, const float* tex_jitter, const float* n_interp,
+                          const float* n_jitter, const float* mask_tap, const float* n_shade, const float* n_geo,
+                          const float* depth, const float* diffuse, const float* specular, int cw_channels,
+                          const float* msdf_image, int64_t B, int64_t H, int64_t W, const float* g_out, float* g_tex,
+                          float* g_tex_jitter, float* g_n_interp, float* g_n_jitter, float* g_n_shade, float* g_n_geo,
+                          float* g_diffuse, float* g_specular, float* g_msdf_image, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * SDF network, fused forward   (replaces MLP.forward + Embedding.forward, geometry/mlp.py:32-40,
  *   geometry/embedding.py:22-39, as called on the whole grid at geometry/gshell_tets_geometry.py:194)
  *   x [N,3] -> out [N];  d_hidden = 256, d_out = 1, Softplus(beta=100).

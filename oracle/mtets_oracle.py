@@ -39,8 +39,8 @@ CUT_QUAD = (
     (0, 1, 5, 0, 5, 6, 0, 6, 3), (0, 1, 2, 0, 2, 6, 0, 6, 7), (0, 1, 2, 0, 2, 3))
 
 
-def _pad(table, width):
-    return torch.tensor([list(r) + [0] * (width - len(r)) for r in table], dtype=torch.long)
+def _pad(table, width, device=None):
+    return torch.tensor([list(r) + [0] * (width - len(r)) for r in table], dtype=torch.long, device=device)
 
 
 def build_topology(tets: torch.Tensor):
@@ -52,7 +52,7 @@ def build_topology(tets: torch.Tensor):
     equivalent and needs no per-call sort.
     """
     t = tets.long()
-    ec = torch.tensor(EDGE_CORNERS)
+    ec = torch.tensor(EDGE_CORNERS, device=t.device)
     a, b = t[:, ec[:, 0]], t[:, ec[:, 1]]
     key = torch.minimum(a, b) * (int(t.max()) + 1) + torch.maximum(a, b)      # [F,6]
     ukey, inv = torch.unique(key.reshape(-1), return_inverse=True)
@@ -75,13 +75,14 @@ def extract(pos, sdf, msdf, tets, topo=None, with_tangents=True):
     if topo is None:
         topo = build_topology(tets)
     edges, tet_edge = topo["edges"], topo["tet_edge"]
+    dev = pos.device       # the restatement is plain torch: it also runs on the GPU box at the full BASELINE grid sizes
     sdf = sdf.float().reshape(-1)
     msdf = msdf.reshape(-1)
     F = tets.shape[0]
     occ = sdf > 0                                                   # ref :250 (strict)
     occ4 = occ[tets.reshape(-1)].reshape(F, 4).long()
     code = occ4[:, 0] + 2 * occ4[:, 1] + 4 * occ4[:, 2] + 8 * occ4[:, 3]     # ref :296-297
-    ntri = torch.tensor([len(r) // 3 for r in TRI_TABLE])[code]
+    ntri = torch.tensor([len(r) // 3 for r in TRI_TABLE], device=dev)[code]
 
     ea, eb = edges[:, 0], edges[:, 1]
     cross = occ[ea] != occ[eb]
@@ -97,7 +98,7 @@ def extract(pos, sdf, msdf, tets, topo=None, with_tangents=True):
     tet1 = torch.nonzero(ntri == 1).reshape(-1)                     # tet order preserved
     tet2 = torch.nonzero(ntri == 2).reshape(-1)
     M1, M2 = int(tet1.shape[0]), int(tet2.shape[0])
-    tri_t, poly_t = _pad(TRI_TABLE, 6), _pad(POLY_TABLE, 4)
+    tri_t, poly_t = _pad(TRI_TABLE, 6, dev), _pad(POLY_TABLE, 4, dev)
     vid1 = vid_of_edge[tet_edge[tet1]]                              # [M1,6]
     vid2 = vid_of_edge[tet_edge[tet2]]
     faces_wt = torch.cat([
@@ -134,11 +135,11 @@ def extract(pos, sdf, msdf, tets, topo=None, with_tangents=True):
     mocc2 = (mv[poly2] > 0).long()
     ci1 = mocc1[:, 0] * 4 + mocc1[:, 1] * 2 + mocc1[:, 2]           # ref :396-399 (flipped powers)
     ci2 = mocc2[:, 0] * 8 + mocc2[:, 1] * 4 + mocc2[:, 2] * 2 + mocc2[:, 3]
-    loc1 = torch.cat([poly1, V + torch.arange(3 * M1).reshape(-1, 3)], 1)             # ref :402
-    loc2 = torch.cat([poly2, V + 3 * M1 + torch.arange(4 * M2).reshape(-1, 4)], 1)    # ref :403
-    cut1, cut2 = _pad(CUT_TRI, 6), _pad(CUT_QUAD, 12)
-    n1 = torch.tensor([len(r) // 3 for r in CUT_TRI])[ci1]
-    n2 = torch.tensor([len(r) // 3 for r in CUT_QUAD])[ci2]
+    loc1 = torch.cat([poly1, V + torch.arange(3 * M1, device=dev).reshape(-1, 3)], 1)             # ref :402
+    loc2 = torch.cat([poly2, V + 3 * M1 + torch.arange(4 * M2, device=dev).reshape(-1, 4)], 1)    # ref :403
+    cut1, cut2 = _pad(CUT_TRI, 6, dev), _pad(CUT_QUAD, 12, dev)
+    n1 = torch.tensor([len(r) // 3 for r in CUT_TRI], device=dev)[ci1]
+    n2 = torch.tensor([len(r) // 3 for r in CUT_QUAD], device=dev)[ci2]
     groups = []
     for k in (1, 2):                                                # ref :409-416 group order
         sel = n1 == k
@@ -148,7 +149,7 @@ def extract(pos, sdf, msdf, tets, topo=None, with_tangents=True):
         groups.append(torch.gather(loc2[sel], 1, cut2[ci2[sel]][:, :3 * k]).reshape(-1, 3))
     faces_aug = torch.cat(groups, 0)
 
-    used = torch.zeros(verts_aug.shape[0], dtype=torch.bool)        # ref :419-423
+    used = torch.zeros(verts_aug.shape[0], dtype=torch.bool, device=dev)        # ref :419-423
     used[faces_aug.reshape(-1)] = True
     verts_aug = torch.where(used[:, None], verts_aug, torch.zeros_like(verts_aug))
 
@@ -218,13 +219,14 @@ def extract_from_auggrid(pos, sdf, tets, verts_disc, coeff_grid, msdf_grid, occg
     if topo is None:
         topo = build_topology(tets)
     edges, tet_edge = topo["edges"], topo["tet_edge"]
+    dev = pos.device       # the restatement is plain torch: it also runs on the GPU box at the full BASELINE grid sizes
     sdf = sdf.float().reshape(-1)
     vd = verts_disc.float()
     F = tets.shape[0]
     occ = sdf > 0                                                   # ref :454
     occ4 = occ[tets.reshape(-1)].reshape(F, 4).long()
     code = occ4[:, 0] + 2 * occ4[:, 1] + 4 * occ4[:, 2] + 8 * occ4[:, 3]     # ref :459-460
-    ntri = torch.tensor([len(r) // 3 for r in TRI_TABLE])[code]
+    ntri = torch.tensor([len(r) // 3 for r in TRI_TABLE], device=dev)[code]
     ea, eb = edges[:, 0], edges[:, 1]
     cross = occ[ea] != occ[eb]                                      # ref :470
     vid_of_edge = torch.cumsum(cross.long(), 0) - 1
@@ -240,7 +242,7 @@ def extract_from_auggrid(pos, sdf, tets, verts_disc, coeff_grid, msdf_grid, occg
     tet1 = torch.nonzero(ntri == 1).reshape(-1)
     tet2 = torch.nonzero(ntri == 2).reshape(-1)
     M1, M2 = int(tet1.shape[0]), int(tet2.shape[0])
-    tri_t, poly_t = _pad(TRI_TABLE, 6), _pad(POLY_TABLE, 4)
+    tri_t, poly_t = _pad(TRI_TABLE, 6, dev), _pad(POLY_TABLE, 4, dev)
     vid1 = vid_of_edge[tet_edge[tet1]]
     vid2 = vid_of_edge[tet_edge[tet2]]
     faces_wt = torch.cat([
@@ -273,11 +275,11 @@ def extract_from_auggrid(pos, sdf, tets, verts_disc, coeff_grid, msdf_grid, occg
     mocc2 = (mv[poly2] > 0).long()
     ci1 = mocc1[:, 0] * 4 + mocc1[:, 1] * 2 + mocc1[:, 2]           # ref :602-606
     ci2 = mocc2[:, 0] * 8 + mocc2[:, 1] * 4 + mocc2[:, 2] * 2 + mocc2[:, 3]
-    loc1 = torch.cat([poly1, V + torch.arange(3 * M1).reshape(-1, 3)], 1)             # ref :608
-    loc2 = torch.cat([poly2, V + 3 * M1 + torch.arange(4 * M2).reshape(-1, 4)], 1)    # ref :609
-    cut1, cut2 = _pad(CUT_TRI, 6), _pad(CUT_QUAD, 12)
-    n1 = torch.tensor([len(r) // 3 for r in CUT_TRI])[ci1]
-    n2 = torch.tensor([len(r) // 3 for r in CUT_QUAD])[ci2]
+    loc1 = torch.cat([poly1, V + torch.arange(3 * M1, device=dev).reshape(-1, 3)], 1)             # ref :608
+    loc2 = torch.cat([poly2, V + 3 * M1 + torch.arange(4 * M2, device=dev).reshape(-1, 4)], 1)    # ref :609
+    cut1, cut2 = _pad(CUT_TRI, 6, dev), _pad(CUT_QUAD, 12, dev)
+    n1 = torch.tensor([len(r) // 3 for r in CUT_TRI], device=dev)[ci1]
+    n2 = torch.tensor([len(r) // 3 for r in CUT_QUAD], device=dev)[ci2]
     groups = []
     for k in (1, 2):                                                # ref :614-621
         sel = n1 == k

@@ -1,0 +1,36 @@
+"""gs_shade_assemble (one kernel for shade()'s buffer dictionary + the background composite) against the op-by-op torch
+formulation it replaces (reference render/render.py:74, :105-112, :160-186, :352-359, :417-433): same frame, same gradients."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("denoise", [True, False])
+def test_fused_assembly_equals_the_torch_formulation(denoise):
+    from gshell_amd import workload
+    from gshell_amd.render import render
+    tr = workload.build(res=16, n_samples=2, batch=2, train_res=(48, 56), fit_steps=40, denoiser='bilateral' if denoise else 'none')
+    target = workload.make_targets(tr, [0, 5], (48, 56))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    results = []
+    for fused in (True, False):
+        tr.FLAGS.fused_assemble = fused
+        render.rnd_seed = 11
+        tr.FLAGS.noise_stream.set_iteration(3)
+        for p in tr.all_params():
+            p.grad = None
+        d = tr.geometry.render(tr.glctx, target, tr.lgt, tr.mat, denoiser=tr.denoiser, shadow_scale=0.7)
+        st, keys, sizes = d['buffers'].stacked
+        if not results:
+            w = torch.rand(st.shape, device="cuda", generator=g)
+        (st * w).sum().backward()
+        results.append((st.detach().clone(), keys, sizes, [None if p.grad is None else p.grad.clone() for p in tr.all_params()]))
+    (a, ka, sa, ga), (b, kb, sb, gb) = results
+    assert ka == kb and sa == sb and a.shape[-1] == 45
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert float((a[..., 3] > 0).float().mean()) > 0.02          # something is covered
+    for x, y in zip(ga, gb):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert float((x - y).norm()) <= 1e-4 * float(y.norm()) + 1e-12

@@ -33,6 +33,8 @@ for name in ("shading_loss", "material_smoothness_grad", "chroma_loss"):
     wrap(regularizer, name)
 wrap(G, "compute_sdf_reg_loss")
 wrap(G, "sample_points")
+wrap(G, "eikonal_sq_sum")
+wrap(M, "row_sparse_backward")
 wrap(G.GShellTetsGeometry, "getMesh")
 wrap(G.GShellTetsGeometry, "render", "geometry.render")
 wrap(G.GShellTetsGeometry, "tick")
@@ -54,6 +56,7 @@ if GEOM == "flexicubes":
     wrap(FC.GShellFlexiCubes, "__call__", "GShellFlexiCubes.__call__")
 tr = workload.build(res=RES, n_samples=8, batch=4, train_res=(512, 512), fit_steps=200, geometry=GEOM)
 tg = workload.make_targets(tr, [0, 1, 2, 3], (512, 512))
+tr.it = 1000          # steady-state schedule (sigma 2, shadow_scale 1), as bench.py
 for _ in range(3):
     tr.step(tg)
 torch.cuda.synchronize()
