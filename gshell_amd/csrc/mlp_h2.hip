@@ -63,6 +63,7 @@ enum { MODE_GRID = 0, MODE_ROWS = 1, MODE_EIK = 2 };
 struct H2Args {
     const float* x;       // [N,3] points
     const int32_t* rows;  // MODE_ROWS: [R]
+    uint64_t* occ;        // MODE_GRID: optional sign bits, word t = ballot(sdf[64 t + i] > 0)
     float* out;           // MODE_GRID: [N] sdf;  MODE_EIK: [tiles*64] per virtual row (value rows: f - b_out; tangent rows: df/dx_d)
     float* A;             // saved activations [n_layers][Rpad][256] fp32 (value rows a_l, tangent rows a'_l)   (ROWS / EIK)
     float* EMB;           // saved encoding [Rpad][EK] fp32 (tangent rows: d enc / dx_d)                            (ROWS / EIK)
@@ -308,7 +309,11 @@ __global__ void __launch_bounds__(NT, 4) k_h2_fwd(H2Args A) {
         for (int w = 0; w < 8; ++w) s += red[w * TM + tid];
         int64_t r = r0 + tid;
         if (MODE == MODE_GRID) {
-            if (r < A.N) A.out[r] = s + A.w_out[D];
+            s += A.w_out[D];
+            if (r < A.N) A.out[r] = s;
+            // fused geometry front end: the tile is one 64-bit word of the extraction's occupancy bits (strict > 0, ref gshell_tets.py:250)
+            const uint64_t m = __ballot(r < A.N && s > 0.0f);
+            if (A.occ && tid == 0) A.occ[tile] = m;
         } else {
             A.out[r] = s;                                    // virtual rows: value rows lack b_out (unused), tangent rows = df/dx_d
         }
@@ -797,12 +802,12 @@ extern "C" int gs_sdf_mlp_h2_pack(const float* const* weights, const float* cons
 }
 
 extern "C" int gs_sdf_mlp_fwd_h2(const float* x, int64_t N, const void* packed, int n_freq, int n_hidden, int skip_layer, float* out,
-                                 gs_stream_t stream) {
+                                 uint64_t* occ_bits, gs_stream_t stream) {
     if (N == 0) return 0;
     GS_REQUIRE(x && packed && out, "gs_sdf_mlp_fwd_h2: null pointer");
     if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
     H2Args A{};
-    A.x = x; A.out = out; A.N = N; A.n_freq = n_freq;
+    A.x = x; A.out = out; A.occ = occ_bits; A.N = N; A.n_freq = n_freq;
     fill_fwd_args(A, packed, make_layout(n_freq, n_hidden, skip_layer));
     return launch_fwd<MODE_GRID>(A, gs::cdiv(N, TM), (hipStream_t)stream);
 }

@@ -706,13 +706,17 @@ __global__ void k_tng_boundary(int64_t V, int64_t M1, int64_t M2, const float* _
 // C ABI
 // ====================================================================================
 template <bool AUG>
-static int count_impl(gs_mtets_topo* t, const float* sdf, const float* msdf, const AugIn& G, hipStream_t stream, int64_t* counts_host) {
+static int count_impl(gs_mtets_topo* t, const float* sdf, const float* msdf, const AugIn& G, hipStream_t stream, int64_t* counts_host,
+                      bool presigned = false) {
     if (t->F == 0 || t->N == 0) {
         for (int k = 0; k < GS_MTETS_NCOUNTS; ++k) counts_host[k] = t->last_counts[k] = 0;
         return 0;
     }
     unsigned long long* cnt = (unsigned long long*)t->counts_dev;
-    k_occ_bits<<<gs::cdiv(t->N, 256), 256, 0, stream>>>(sdf, t->N, t->occ_bits, cnt);
+    if (presigned)      // the sign bits were written into t->occ_bits by the SDF-network kernel's epilogue (gs_sdf_mlp_fwd_h2)
+        GS_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * GS_MTETS_NCOUNTS, stream));
+    else
+        k_occ_bits<<<gs::cdiv(t->N, 256), 256, 0, stream>>>(sdf, t->N, t->occ_bits, cnt);
     k_edge_cross<<<t->nb_e, 256, 0, stream>>>((const int2*)t->edges, t->E, t->nchunks, t->occ_bits, t->edge_mask, t->edge_blk, cnt);
     k_classify<AUG><<<t->nb_t, 256, 0, stream>>>((const int4*)t->tet, t->F, t->occ_bits, sdf, msdf, t->tet_code, t->tet_blk, cnt, G);
     GS_LAUNCH_CHECK();
@@ -732,6 +736,18 @@ extern "C" int gs_mtets_count(gs_mtets_topo* t, const float* pos, const float* s
     GS_REQUIRE(t && sdf && msdf && counts_host, "gs_mtets_count: null argument");
     (void)pos;
     return count_impl<false>(t, sdf, msdf, AugIn{}, (hipStream_t)stream_, counts_host);
+}
+
+extern "C" int gs_mtets_occ_bits(gs_mtets_topo* t, uint64_t** bits_dev, int64_t* n_words) {
+    GS_REQUIRE(t && bits_dev && n_words, "gs_mtets_occ_bits: null argument");
+    *bits_dev = t->occ_bits;
+    *n_words = gs::cdiv(std::max<int64_t>(t->N, 1), 64);
+    return 0;
+}
+
+extern "C" int gs_mtets_count_presigned(gs_mtets_topo* t, const float* sdf, const float* msdf, gs_stream_t stream_, int64_t* counts_host) {
+    GS_REQUIRE(t && sdf && msdf && counts_host, "gs_mtets_count_presigned: null argument");
+    return count_impl<false>(t, sdf, msdf, AugIn{}, (hipStream_t)stream_, counts_host, true);
 }
 
 extern "C" int gs_mtets_aug_count(gs_mtets_topo* t, const float* sdf, const int32_t* vdisc, const float* msdf_sign_grid, int64_t G,

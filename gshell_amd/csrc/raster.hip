@@ -109,17 +109,72 @@ struct TriJob {
     int x0, x1, y0, y1;  // inclusive pixel bbox (clamped); empty if x0 > x1
 };
 
-__device__ __forceinline__ bool tri_setup(const float4* __restrict__ pos, const int32_t* __restrict__ tri, int64_t t, int64_t V, int H,
-                                          int W, TriJob& j) {
+enum { TRI_REJECT = 0, TRI_FIXED = 1, TRI_NEAR_CLIPPED = 2 };
+
+// A triangle with a vertex at w <= eps (behind or at the eye) cannot be projected vertex by vertex.  nvdiffrast clips it
+// against the view volume; here the part in front of the near plane (z >= -w) is rasterised by evaluating the 2-D
+// homogeneous edge functions per pixel (no clipped geometry is ever built): this routine only bounds the pixels to visit
+// -- the screen-space box of the polygon "triangle  intersected with  z + w >= 0" (its corners all have w > 0 for a
+// perspective projection with a positive near distance; any corner that does not falls back to the whole screen).
+__device__ __forceinline__ int near_clip_bbox(const float4 (&p)[3], int H, int W, TriJob& j) {
+    float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
+    bool any = false, whole = false;
+    auto add = [&](float x, float y, float w) {
+        any = true;
+        if (!(w > W_EPS)) { whole = true; return; }
+        const float sx = (x / w * 0.5f + 0.5f) * (float)W, sy = (y / w * 0.5f + 0.5f) * (float)H;
+        xmin = fminf(xmin, sx); xmax = fmaxf(xmax, sx); ymin = fminf(ymin, sy); ymax = fmaxf(ymax, sy);
+    };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float4 a = p[i], b = p[(i + 1) % 3];
+        const float da = a.z + a.w, db = b.z + b.w;        // signed distance to the near plane in clip space
+        if (da >= 0.0f) add(a.x, a.y, a.w);
+        if ((da >= 0.0f) != (db >= 0.0f)) {
+            const float t = da / (da - db);
+            add(a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.w + t * (b.w - a.w));
+        }
+    }
+    if (!any) return TRI_REJECT;                             // entirely behind the near plane
+    if (whole || !(xmin == xmin) || !(ymin == ymin)) { xmin = 0.f; ymin = 0.f; xmax = (float)W; ymax = (float)H; }
+    j.x0 = max(0, (int)floorf(fminf(fmaxf(xmin, -1.0f), (float)W + 1.0f)) - 1);
+    j.x1 = min(W - 1, (int)ceilf(fminf(fmaxf(xmax, -1.0f), (float)W + 1.0f)) + 1);
+    j.y0 = max(0, (int)floorf(fminf(fmaxf(ymin, -1.0f), (float)H + 1.0f)) - 1);
+    j.y1 = min(H - 1, (int)ceilf(fminf(fmaxf(ymax, -1.0f), (float)H + 1.0f)) + 1);
+    return (j.x0 <= j.x1 && j.y0 <= j.y1) ? TRI_NEAR_CLIPPED : TRI_REJECT;
+}
+
+// coverage of a near-clipped triangle at one pixel centre: inside the triangle's plane polygon (all homogeneous barycentrics
+// >= 0), in front of the eye, and inside the depth range (raster_sample's test)
+__device__ __forceinline__ void raster_sample_homogeneous(uint64_t* __restrict__ zrow, int px, int py, int H, int W, const float4 p0,
+                                                          const float4 p1, const float4 p2, uint32_t tri_id) {
+    Bary r = bary_eval(p0, p1, p2, pix_ndc(px, W), pix_ndc(py, H));
+    if (!(r.s != 0.0f)) return;
+    const float b2 = 1.0f - r.b0 - r.b1;
+    if (!(r.b0 >= 0.0f && r.b1 >= 0.0f && b2 >= 0.0f)) return;
+    const float w = p0.w * r.b0 + p1.w * r.b1 + p2.w * b2;    // clip-space w of the point hit by the pixel's ray
+    if (!(w > 0.0f) || !(r.zw >= -1.0f && r.zw <= 1.0f)) return;
+    uint64_t key = ((uint64_t)depth_key(r.zw) << 32) | tri_id;
+    atomicMin((unsigned long long*)&zrow[px], (unsigned long long)key);
+}
+
+__device__ __forceinline__ int tri_setup(const float4* __restrict__ pos, const int32_t* __restrict__ tri, int64_t t, int64_t V, int H,
+                                         int W, TriJob& j) {
     int32_t i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-    if ((uint32_t)i0 >= (uint32_t)V || (uint32_t)i1 >= (uint32_t)V || (uint32_t)i2 >= (uint32_t)V) return false;
+    if ((uint32_t)i0 >= (uint32_t)V || (uint32_t)i1 >= (uint32_t)V || (uint32_t)i2 >= (uint32_t)V) return TRI_REJECT;
     j.p0 = pos[i0];
     j.p1 = pos[i1];
     j.p2 = pos[i2];
+    const int n_front = (j.p0.w > W_EPS) + (j.p1.w > W_EPS) + (j.p2.w > W_EPS);
+    if (n_front == 0) return TRI_REJECT;
+    if (n_front < 3) {
+        const float4 p[3] = {j.p0, j.p1, j.p2};
+        return near_clip_bbox(p, H, W, j);
+    }
     int32_t x[3], y[3];
-    if (!project_fix(j.p0, H, W, x[0], y[0]) || !project_fix(j.p1, H, W, x[1], y[1]) || !project_fix(j.p2, H, W, x[2], y[2])) return false;
+    if (!project_fix(j.p0, H, W, x[0], y[0]) || !project_fix(j.p1, H, W, x[1], y[1]) || !project_fix(j.p2, H, W, x[2], y[2])) return TRI_REJECT;
     int64_t area2 = (int64_t)(x[1] - x[0]) * (y[2] - y[0]) - (int64_t)(y[1] - y[0]) * (x[2] - x[0]);
-    if (area2 == 0) return false;
+    if (area2 == 0) return TRI_REJECT;
     int sgn = area2 > 0 ? 1 : -1;
     j.e0 = edge_setup(x[1], y[1], x[2], y[2], sgn);
     j.e1 = edge_setup(x[2], y[2], x[0], y[0], sgn);
@@ -131,7 +186,7 @@ __device__ __forceinline__ bool tri_setup(const float4* __restrict__ pos, const 
     j.x1 = min(W - 1, (mxx - SUBPIX / 2) >> SUBPIX_BITS);
     j.y0 = max(0, (mny - SUBPIX / 2 + SUBPIX - 1) >> SUBPIX_BITS);
     j.y1 = min(H - 1, (mxy - SUBPIX / 2) >> SUBPIX_BITS);
-    return j.x0 <= j.x1 && j.y0 <= j.y1;
+    return (j.x0 <= j.x1 && j.y0 <= j.y1) ? TRI_FIXED : TRI_REJECT;
 }
 
 __global__ void __launch_bounds__(256) k_rast_clear(uint64_t* __restrict__ zbuf, int64_t n, int32_t* __restrict__ qcount) {
@@ -147,9 +202,10 @@ __global__ void __launch_bounds__(256) k_rast_small(const float4* __restrict__ p
     if (idx >= B * T) return;
     int64_t b = idx / T, t = idx - b * T;
     TriJob j;
-    if (!tri_setup(pos + b * V, tri, t, V, H, W, j)) return;
+    const int kind = tri_setup(pos + b * V, tri, t, V, H, W, j);
+    if (kind == TRI_REJECT) return;
     int64_t area = (int64_t)(j.x1 - j.x0 + 1) * (j.y1 - j.y0 + 1);
-    if (area > LARGE_BBOX) {
+    if (area > LARGE_BBOX || kind == TRI_NEAR_CLIPPED) {      // near-clipped triangles always take the workgroup path
         int32_t slot = atomicAdd(qcount, 1);
         queue[slot] = idx;
         return;
@@ -179,9 +235,17 @@ __global__ void __launch_bounds__(256) k_rast_large(const float4* __restrict__ p
         int64_t idx = queue[q];
         int64_t b = idx / T, t = idx - b * T;
         TriJob j;
-        if (!tri_setup(pos + b * V, tri, t, V, H, W, j)) continue;  // uniform across the block
+        const int kind = tri_setup(pos + b * V, tri, t, V, H, W, j);  // uniform across the block
+        if (kind == TRI_REJECT) continue;
         uint64_t* zview = zbuf + b * (int64_t)H * W;
         int bw = j.x1 - j.x0 + 1, bh = j.y1 - j.y0 + 1;
+        if (kind == TRI_NEAR_CLIPPED) {
+            for (int i = threadIdx.x; i < bw * bh; i += blockDim.x) {
+                int py = j.y0 + i / bw, px = j.x0 + i % bw;
+                raster_sample_homogeneous(zview + (int64_t)py * W, px, py, H, W, j.p0, j.p1, j.p2, (uint32_t)t);
+            }
+            continue;
+        }
         for (int i = threadIdx.x; i < bw * bh; i += blockDim.x) {
             int py = j.y0 + i / bw, px = j.x0 + i % bw;
             int64_t cx = (int64_t)px * SUBPIX + SUBPIX / 2, cy = (int64_t)py * SUBPIX + SUBPIX / 2;

@@ -40,6 +40,7 @@ class TetTopology:
                                             ctypes.byref(self._edges_ptr), ctypes.byref(self._tet_ptr)))
         self.E = int(e.value)
         self._edges = None
+        self.sign_epoch = 0          # bumped by every writer of the occupancy bits
         nuv = int(math.ceil(math.sqrt((2 * self.F + 1) // 2))) if self.F > 0 else 1
         self.Nuv = nuv
         # torch.linspace(0, 1 - 1/N, N): the uv atlas axis of the reference's map_uv (gshell_tets.py:211-216)
@@ -48,6 +49,12 @@ class TetTopology:
     @property
     def handle(self):
         return self._h
+
+    def occ_bits_ptr(self) -> int:
+        """Device address of the [ceil(N/64)] uint64 occupancy bits (written by k_occ_bits, or by the SDF network's epilogue)."""
+        bits, words = c_void_p(), c_int64()
+        check(_lib.lib().gs_mtets_occ_bits(self._h, ctypes.byref(bits), ctypes.byref(words)))
+        return int(bits.value)
 
     def edges(self) -> torch.Tensor:
         """[E,2] int32, lexicographically sorted unique (min,max) grid edges (a copy)."""
@@ -69,7 +76,7 @@ class TetTopology:
 
 class _MarchingTetsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pos, sdf, msdf, topo: TetTopology, want_tangents: bool):
+    def forward(ctx, pos, sdf, msdf, topo: TetTopology, want_tangents: bool, presigned: bool = False):
         L = _lib.lib()
         dev = pos.device
         pos_c, sdf_c, msdf_c = pos.detach().contiguous().float(), sdf.detach().contiguous().float(), msdf.detach().contiguous().float()
@@ -77,8 +84,12 @@ class _MarchingTetsFn(torch.autograd.Function):
             raise _lib.GShellHipError(f"field sizes {tuple(pos_c.shape)}, {sdf_c.numel()}, {msdf_c.numel()} do not match the grid (N={topo.N})")
         counts = (c_int64 * 16)()
         with torch.cuda.device(dev):
-            check(L.gs_mtets_count(topo.handle, ptr(pos_c, torch.float32, "pos"), ptr(sdf_c, torch.float32, "sdf"),
-                                   ptr(msdf_c, torch.float32, "msdf"), stream(), counts), "gs_mtets_count")
+            if presigned:      # sign bits already in the topology's array (fused geometry front end)
+                check(L.gs_mtets_count_presigned(topo.handle, ptr(sdf_c, torch.float32, "sdf"), ptr(msdf_c, torch.float32, "msdf"), stream(), counts),
+                      "gs_mtets_count_presigned")
+            else:
+                check(L.gs_mtets_count(topo.handle, ptr(pos_c, torch.float32, "pos"), ptr(sdf_c, torch.float32, "sdf"),
+                                       ptr(msdf_c, torch.float32, "msdf"), stream(), counts), "gs_mtets_count")
             V, M1, M2, T, V_aug = counts[0], counts[1], counts[2], counts[9], counts[10]
             f32 = dict(dtype=torch.float32, device=dev)
             verts_aug = torch.empty((V_aug, 3), **f32)
@@ -128,7 +139,7 @@ class _MarchingTetsFn(torch.autograd.Function):
                                               ptr(ga), ptr(gm), ptr(gw), ptr(scratch), ptr(g_pos), ptr(g_sdf), ptr(g_msdf),
                                               stream()), "gs_mtets_bwd")
         ps, ss, ms = ctx.in_shapes
-        return g_pos.reshape(ps), g_sdf.reshape(ss), g_msdf.reshape(ms), None, None
+        return g_pos.reshape(ps), g_sdf.reshape(ss), g_msdf.reshape(ms), None, None, None
 
 
 class GShell_Tets:
@@ -151,8 +162,14 @@ class GShell_Tets:
             raise NotImplementedError("output_watertight_template=False (mSDF pre-filter, gshell_tets.py:263) is never used "
                                       "by the reference's call sites and is not implemented")
         topo = self.topology(tet_fx4, pos_nx3.shape[0])
+        # fused geometry front end: an sdf tensor that comes straight out of the SDF-network kernel carries the tag of the
+        # occupancy bits its epilogue wrote into THIS topology; any later writer of those bits invalidates the tag (epoch)
+        tag = getattr(sdf_n, '_gs_presigned', None)
+        presigned = tag is not None and tag[0] is topo and tag[1] == topo.sign_epoch and tag[2] == sdf_n._version
+        if not presigned:
+            topo.sign_epoch += 1
         verts_aug, msdf_aug, verts_wt, faces_aug, faces_wt, faces_i32, v_tng_aug, tet_id = _MarchingTetsFn.apply(
-            pos_nx3, sdf_n, msdf_n, topo, self.compute_tangents)
+            pos_nx3, sdf_n, msdf_n, topo, self.compute_tangents, presigned)
         V = verts_wt.shape[0]
         extra = {
             'n_verts_watertight': V,
@@ -209,6 +226,7 @@ class GShell_Tets:
             topo._vdisc_checked = (verts_discretized.data_ptr(), G, G2)
         counts = (c_int64 * 16)()
         with torch.cuda.device(dev):
+            topo.sign_epoch += 1       # this pass rewrites the occupancy bits too
             check(L.gs_mtets_aug_count(topo.handle, ptr(sdf_c, torch.float32, "sdf"), ptr(vdisc, torch.int32, "verts_discretized"),
                                        ptr(mgrid), c_int64(G), stream(), counts), "gs_mtets_aug_count")
             V, M1, M2, T, V_aug = counts[0], counts[1], counts[2], counts[9], counts[10]

@@ -163,7 +163,9 @@ class GShellTetsGeometry(torch.nn.Module):
         shard = getattr(self.FLAGS, "view_shard", None)
         if shard is not None and shard.world > 1 and getattr(self.FLAGS, "shard_mlp_rows", False):
             return forward_row_sharded(self.sdf_net, v_deformed, shard)
-        return forward_row_sparse_backward(self.sdf_net, v_deformed)
+        # single GPU: the kernel's epilogue also writes the extraction's occupancy bits (fused geometry front end)
+        sink = self.gshell_tets.topology(self.indices, self.verts.shape[0]) if hasattr(self, 'gshell_tets') else None
+        return forward_row_sparse_backward(self.sdf_net, v_deformed, sign_sink=sink)
 
     def getMesh(self, material):
         v_deformed = self.verts + self.max_displacement * self.deform

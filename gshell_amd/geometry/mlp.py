@@ -227,8 +227,9 @@ def pack_weights_h2(net):
     return packed, n_hidden, skip
 
 
-def fused_forward(net, x, precision=None):
-    """sdf = net(x) through the fused MFMA kernel (no autograd)."""
+def fused_forward(net, x, precision=None, occ_bits_ptr=None):
+    """sdf = net(x) through the fused MFMA kernel (no autograd).  `occ_bits_ptr`: device address of a [ceil(N/64)] uint64
+    array that receives the sign bits (h2 only; the extraction's occupancy bits)."""
     precision = precision or SDF_MLP_PRECISION
     L = _lib.lib()
     xc = x.detach().contiguous()
@@ -237,7 +238,7 @@ def fused_forward(net, x, precision=None):
         packed, n_hidden, skip = pack_weights_h2(net)
         with torch.cuda.device(xc.device):
             check(L.gs_sdf_mlp_fwd_h2(ptr(xc, torch.float32, "x"), c_int64(xc.shape[0]), ptr(packed), c_int(net.emb.N_freqs), c_int(n_hidden), c_int(skip),
-                                      ptr(out), stream()), "gs_sdf_mlp_fwd_h2")
+                                      ptr(out), _lib.c_void_p(occ_bits_ptr or 0), stream()), "gs_sdf_mlp_fwd_h2")
         return out[:, None]
     if precision != "fp32":
         raise ValueError(f"unknown SDF-MLP precision {precision!r} (h2 | fp32)")
@@ -260,10 +261,12 @@ class _RowSparseBackward(torch.autograd.Function):
     recomputed in the backward pass."""
 
     @staticmethod
-    def forward(ctx, x, net, *params):
+    def forward(ctx, x, net, sign_sink, *params):
         with torch.no_grad():
-            y = fused_forward(net, x) if _fusable(net, x) else net(x)
+            presign = sign_sink is not None and SDF_MLP_PRECISION == "h2" and _fusable(net, x) and sign_sink.N == x.shape[0]
+            y = (fused_forward(net, x, occ_bits_ptr=sign_sink.occ_bits_ptr() if presign else None) if _fusable(net, x) else net(x))
         ctx.net = net
+        ctx.presigned = presign
         ctx.save_for_backward(x)
         return y
 
@@ -271,7 +274,7 @@ class _RowSparseBackward(torch.autograd.Function):
     def backward(ctx, g_y):
         (x,) = ctx.saved_tensors
         g_x, g_params = row_sparse_backward(ctx.net, x, g_y, ctx.needs_input_grad[0])
-        return (g_x, None) + tuple(g_params)
+        return (g_x, None, None) + tuple(g_params)
 
 
 def row_sparse_backward_torch(net, x, g_y, need_x):
@@ -442,6 +445,12 @@ def forward_row_sharded(net, x, shard):
     return _RowShardedForward.apply(x, net, shard, *list(net.parameters()))
 
 
-def forward_row_sparse_backward(net, x):
-    """net(x) with the row-sparse backward described above (first-order gradients only)."""
-    return _RowSparseBackward.apply(x, net, *list(net.parameters()))
+def forward_row_sparse_backward(net, x, sign_sink=None):
+    """net(x) with the row-sparse backward described above (first-order gradients only).  `sign_sink` (a TetTopology): the
+    kernel's epilogue also writes the sign bits of the result straight into the extractor's occupancy array; the returned
+    tensor is tagged (`_gs_presigned`) so that GShell_Tets skips its own sign pass."""
+    y = _RowSparseBackward.apply(x, net, sign_sink, *list(net.parameters()))
+    if sign_sink is not None and SDF_MLP_PRECISION == "h2" and _fusable(net, x) and sign_sink.N == x.shape[0]:
+        sign_sink.sign_epoch += 1
+        y._gs_presigned = (sign_sink, sign_sink.sign_epoch, y._version)
+    return y

@@ -59,6 +59,13 @@ int gs_mtets_topo_info(const gs_mtets_topo* topo, int64_t* N, int64_t* F, int64_
 #define GS_MTETS_NCOUNTS 16
 int gs_mtets_count(gs_mtets_topo* topo, const float* pos_nx3, const float* sdf_n,
                    const float* msdf_n, gs_stream_t stream, int64_t* counts_host);
+/* Fused geometry front end: the topology's own sign-bit array (1 bit per grid vertex, bit i of word i/64
+ * = sdf[i] > 0) can be WRITTEN by the SDF-network kernel's epilogue (gs_sdf_mlp_fwd_h2, occ_bits argument), in which case
+ * gs_mtets_count_presigned skips the sign pass over sdf (sdf itself is still read by the classification for the
+ * interpolation weights).  The caller guarantees that the bits belong to this sdf. */
+int gs_mtets_occ_bits(gs_mtets_topo* topo, uint64_t** bits_dev, int64_t* n_words);
+int gs_mtets_count_presigned(gs_mtets_topo* topo, const float* sdf_n, const float* msdf_n,
+                             gs_stream_t stream, int64_t* counts_host);
 
 /* Fill phase; must follow gs_mtets_count on the same topo/stream with the same inputs.
  *   verts_aug [V_aug,3] f32, msdf_aug [V_aug] f32 (stop-gradient mSDF, ref :386-390),
@@ -453,7 +460,8 @@ int64_t gs_sdf_mlp_h2_packed_bytes(int n_freq, int n_hidden, int skip_layer);
 int gs_sdf_mlp_h2_pack(const float* const* weights, const float* const* biases, int n_freq, int n_hidden,
                        int skip_layer, void* packed, gs_stream_t stream);
 int gs_sdf_mlp_fwd_h2(const float* x, int64_t N, const void* packed, int n_freq, int n_hidden,
-                      int skip_layer, float* out, gs_stream_t stream);
+                      int skip_layer, float* out, uint64_t* occ_bits /* [ceil(N/64)] sign bits WRITTEN, or NULL */,
+                      gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * SDF network, gradients   (replaces autograd through geometry/mlp.py:32-40 as used by

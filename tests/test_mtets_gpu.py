@@ -11,6 +11,7 @@ from oracle import fields, mtets_oracle
 from tests.helpers import golden_inputs
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda"
 FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mtets_*.npz")))
 
 
@@ -149,3 +150,33 @@ def test_full_size_res256_properties():
     assert torch.equal(f, f2) and torch.equal(v, v2)
     # the open mesh keeps only the msdf>0 side
     assert float(extra["msdf"][f.reshape(-1)].min()) > -1e-6
+
+
+def test_presigned_extraction_equals_plain_extraction():
+    """Fused geometry front end: the SDF-network kernel writes the sign bits of its result into the extractor's
+    occupancy array and the extraction skips its own sign pass -- same mesh, bit for bit; a stale tag must not be trusted."""
+    from gshell_amd import grid
+    from gshell_amd.geometry.gshell_tets import GShell_Tets
+    from gshell_amd.geometry.mlp import MLP, forward_row_sparse_backward
+    torch.manual_seed(0)
+    verts, tets = grid.bcc_grid(12)
+    verts, tets = (verts * 1.4).to(DEV), tets.to(DEV)
+    net = MLP(n_freq=6, d_hidden=256, n_hidden=6, skip_in=[3]).to(DEV)
+    with torch.no_grad():      # a surface inside the grid: shift the output bias to the median
+        lin = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+        lin[-1].bias -= net(verts).median()
+    msdf = torch.rand(verts.shape[0], device=DEV) - 0.1
+    ext = GShell_Tets(compute_tangents=False)
+    topo = ext.topology(tets, verts.shape[0])
+    sdf_tagged = forward_row_sparse_backward(net, verts, sign_sink=topo)
+    assert getattr(sdf_tagged, "_gs_presigned", None) is not None
+    v1, f1, _, _, _, e1 = ext(verts, sdf_tagged, msdf, tets)
+    sdf_plain = sdf_tagged.detach().clone()
+    v2, f2, _, _, _, e2 = ext(verts, sdf_plain, msdf, tets)
+    assert f1.shape[0] > 100
+    assert torch.equal(f1, f2) and torch.equal(v1, v2) and torch.equal(e1["msdf"], e2["msdf"])
+    # the plain call rewrote the bits: the old tag is stale now and must be ignored (other field, same topology)
+    other = -sdf_plain
+    ext(verts, other, msdf, tets)
+    v3, f3, _, _, _, _ = ext(verts, sdf_tagged, msdf, tets)
+    assert torch.equal(f3, f1) and torch.equal(v3, v1)
