@@ -19,21 +19,20 @@ def write_obj(folder, mesh, save_material=True, name="mesh"):
     obj_file = os.path.join(folder, name + ".obj")
     v_pos, v_nrm, v_tex = _np(mesh.v_pos), _np(mesh.v_nrm), _np(mesh.v_tex)
     t_pos, t_nrm, t_tex = _np(mesh.t_pos_idx), _np(mesh.t_nrm_idx), _np(mesh.t_tex_idx)
+    # numpy scalars are formatted exactly as the reference formats them ('{}'.format(np.float32) = shortest float32 repr;
+    # `1.0 - v` follows numpy's own promotion), so the file is byte-identical to the reference writer's for the same mesh
     lines = [f"mtllib {name}.mtl", "g default"]
-    lines += ["v {} {} {} ".format(*v) for v in v_pos.tolist()]
+    lines += ["v {} {} {} ".format(v[0], v[1], v[2]) for v in v_pos]
     if v_tex is not None:
         assert len(t_pos) == len(t_tex)
-        lines += ["vt {} {} ".format(u, 1.0 - v) for u, v in v_tex.tolist()]
+        lines += ["vt {} {} ".format(v[0], 1.0 - v[1]) for v in v_tex]
     if v_nrm is not None:
         assert len(t_pos) == len(t_nrm)
-        lines += ["vn {} {} {}".format(*v) for v in v_nrm.tolist()]
+        lines += ["vn {} {} {}".format(v[0], v[1], v[2]) for v in v_nrm]
     lines += ["s 1 ", "g pMesh1", "usemtl defaultMat"]
-    p = (t_pos + 1).astype(np.int64)
-    tt = (t_tex + 1).astype(np.int64) if v_tex is not None else None
-    nn = (t_nrm + 1).astype(np.int64) if v_nrm is not None else None
-    for i in range(len(p)):
-        lines.append("f " + "".join(" %d/%s/%s" % (p[i, j], "" if tt is None else str(tt[i, j]), "" if nn is None else str(nn[i, j]))
-                                    for j in range(3)))
+    for i in range(len(t_pos)):
+        lines.append("f " + "".join(" %s/%s/%s" % (str(t_pos[i][j] + 1), "" if v_tex is None else str(t_tex[i][j] + 1),
+                                                   "" if v_nrm is None else str(t_nrm[i][j] + 1)) for j in range(3)))
     with open(obj_file, "w") as f:
         f.write("\n".join(lines) + "\n")
     if save_material:

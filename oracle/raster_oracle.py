@@ -74,6 +74,32 @@ def _depth_key(zw):
     return np.where(neg, (~u) & np.uint64(0xFFFFFFFF), u | np.uint64(0x80000000))
 
 
+def _near_clipped(zb, p0, p1, p2, t, H, W):
+    """A triangle with a vertex at w <= eps (behind the eye): nvdiffrast clips it against the view volume; equivalently every
+    pixel whose ray hits the triangle's plane polygon (homogeneous barycentrics >= 0) IN FRONT of the eye (w > 0) and inside
+    the depth range is covered.  Every pixel is tested here (the kernel bounds the search with the clipped polygon's box)."""
+    if not ((p0[2] + p0[3] >= 0) or (p1[2] + p1[3] >= 0) or (p2[2] + p2[3] >= 0)):
+        return
+    py, px = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    fx, fy = _pix_ndc(px, W), _pix_ndc(py, H)
+    p0x, p0y = p0[0] - fx * p0[3], p0[1] - fy * p0[3]
+    p1x, p1y = p1[0] - fx * p1[3], p1[1] - fy * p1[3]
+    p2x, p2y = p2[0] - fx * p2[3], p2[1] - fy * p2[3]
+    a0 = p1x * p2y - p1y * p2x
+    a1 = p2x * p0y - p2y * p0x
+    a2 = p0x * p1y - p0y * p1x
+    s = a0 + a1 + a2
+    with np.errstate(all="ignore"):
+        iw = f32(1.0) / s
+        b0, b1 = a0 * iw, a1 * iw
+        b2 = f32(1.0) - b0 - b1
+        zw = (p0[2] * a0 + p1[2] * a1 + p2[2] * a2) / (p0[3] * a0 + p1[3] * a1 + p2[3] * a2)
+        w = p0[3] * b0 + p1[3] * b1 + p2[3] * b2
+        good = (s != 0) & (b0 >= 0) & (b1 >= 0) & (b2 >= 0) & (w > 0) & (zw >= f32(-1.0)) & (zw <= f32(1.0))
+    key = (_depth_key(zw) << np.uint64(32)) | np.uint64(t)
+    zb[good] = np.minimum(zb[good], key[good])
+
+
 def rasterize_ids(pos, tri, H, W):
     """pos [B,V,4] float32 clip space, tri [T,3] int -> ids [B,H,W] int64 (triangle id, -1 = empty)."""
     pos = np.ascontiguousarray(pos, dtype=f32)
@@ -84,6 +110,10 @@ def rasterize_ids(pos, tri, H, W):
         ix, iy, ok = _project_fix(pos[b], H, W)
         for t in range(tri.shape[0]):
             i = tri[t]
+            front = pos[b, i, 3] > f32(1e-6)
+            if front.any() and not front.all():
+                _near_clipped(zbuf[b], pos[b, i[0]], pos[b, i[1]], pos[b, i[2]], t, H, W)
+                continue
             if not ok[i].all():
                 continue
             x, y = ix[i], iy[i]

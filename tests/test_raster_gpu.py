@@ -178,3 +178,52 @@ def test_face_normals():
     (out * w.to(DEV)).sum().backward()
     assert torch.allclose(out.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
     assert (v.grad.cpu() - v_ref.grad).abs().max() <= 1e-4 * v_ref.grad.abs().max()
+
+
+def test_rasterize_near_plane_clipping_matches_oracle():
+    """Triangles with a vertex behind the eye (camera inside / next to the surface): ids equal to the oracle's restatement of
+    the view-volume clip, coverage non-empty, and the antialias cache must not serve a stale analysis for new tensors at
+    recycled addresses."""
+    from gshell_amd.render import rast as dr
+    n, f = 0.1, 100.0
+    proj = np.array([[1.5, 0, 0, 0], [0, 1.5, 0, 0], [0, 0, -(f + n) / (f - n), -2 * f * n / (f - n)], [0, 0, -1, 0]], dtype=np.float32)
+    rng = np.random.default_rng(5)
+    # a floor and a wall that both pass the eye, plus small triangles scattered around (and behind) it
+    quad = np.array([[-1, -0.5, -4.0], [1, -0.5, -4.0], [1, -0.5, 3.0], [-1, -0.5, 3.0], [0.7, -1, -5.0], [0.7, 1, -5.0], [0.7, 1, 2.0], [0.7, -1, 2.0]],
+                    dtype=np.float32)
+    centres = rng.uniform(-1, 1, (20, 1, 3)).astype(np.float32) * np.array([0.6, 0.3, 2.0], np.float32) + np.array([0, 0.2, -1.5], np.float32)
+    small = (centres + rng.uniform(-0.12, 0.12, (20, 3, 3)).astype(np.float32)).reshape(60, 3)      # some straddle the eye plane too
+    verts = np.concatenate([quad, small])
+    tri = np.concatenate([np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7]]), 8 + np.arange(60).reshape(20, 3)]).astype(np.int32)
+    pos = (np.concatenate([verts, np.ones((len(verts), 1), np.float32)], 1) @ proj.T)[None].astype(np.float32)
+    assert (pos[0, :, 3] <= 0).sum() >= 4
+    H, W = 72, 96
+    ids_ref = ro.rasterize_ids(pos, tri, H, W)
+    rast, _ = dr.rasterize(None, torch.tensor(pos, device=DEV), torch.tensor(tri, device=DEV), (H, W))
+    ids = rast[..., 3].long().cpu().numpy() - 1
+    assert (ids_ref[0] == 0).sum() + (ids_ref[0] == 1).sum() > 300          # the near-clipped floor is visible
+    assert np.array_equal(ids, ids_ref)
+
+
+def test_antialias_cache_is_keyed_on_tensor_identity():
+    """dr.antialias cached its analysis on (data_ptr, _version); kernel-written tensors keep _version 0 and the
+    caching allocator recycles addresses, so the next iteration could be served the previous alpha.  The cache now holds the
+    tensors themselves: new tensors at the same addresses are analysed afresh."""
+    from gshell_amd.render import rast as dr
+    verts, tri = _scene("sheet", 2)
+    tri_d = torch.tensor(tri, device=DEV)
+    outs = []
+    for first in (0, 3):
+        dr.antialias_cache_clear() if first == 0 else None
+        pos, _, _ = _clip(verts, 1, first=first)
+        pos_d = pos.to(DEV)
+        rast, _ = dr.rasterize(None, pos_d, tri_d, (64, 64))
+        col = (rast[..., 3:4] > 0).float().expand(-1, -1, -1, 3).contiguous()
+        a = dr.antialias(col, rast, pos_d, tri_d)
+        dr.antialias_cache_clear()
+        b = dr.antialias(col, rast, pos_d, tri_d)
+        assert torch.equal(a, b)
+        ptrs = (rast.data_ptr(), pos_d.data_ptr())
+        outs.append((a, ptrs))
+        del rast, pos_d, col          # free the blocks so that the second pass may receive the same addresses
+    assert not torch.equal(outs[0][0], outs[1][0])

@@ -132,3 +132,27 @@ def test_antialias_ignores_interior_edges_and_has_gradients():
     out = ro.aa_apply(color, alpha)
     out.square().sum().backward()
     assert pos.grad.abs().sum() > 0 and torch.isfinite(pos.grad).all() and torch.isfinite(color.grad).all()
+
+
+def test_near_plane_clipping_known_answer():
+    """A ground quad that runs from in front of the camera to BEHIND it: the triangles with a vertex behind the eye must cover
+    exactly what the explicitly clipped geometry (cut at a plane in front of the eye, all w > 0) covers."""
+    import numpy as np
+    from oracle import raster_oracle as ro
+    n, f = 0.1, 100.0
+    proj = np.array([[1.5, 0, 0, 0], [0, 1.5, 0, 0], [0, 0, -(f + n) / (f - n), -2 * f * n / (f - n)], [0, 0, -1, 0]], dtype=np.float32)
+
+    def clip(v):
+        return (np.concatenate([v, np.ones((len(v), 1), np.float32)], 1) @ proj.T)[None].astype(np.float32)
+    y = -0.5
+    quad = np.array([[-1, y, -4.0], [1, y, -4.0], [1, y, 3.0], [-1, y, 3.0]], dtype=np.float32)        # z = +3 is behind the eye
+    tri = np.array([[0, 1, 2], [0, 2, 3]])
+    ids = ro.rasterize_ids(clip(quad), tri, 48, 64)
+    zc = -0.05                                                                                        # cut in front of the eye, before the near plane
+    cut = np.array([[-1, y, -4.0], [1, y, -4.0], [1, y, zc], [-1, y, zc]], dtype=np.float32)
+    ids_cut = ro.rasterize_ids(clip(cut), tri, 48, 64)
+    cov, cov_cut = ids >= 0, ids_cut >= 0
+    assert cov_cut.sum() > 200
+    # the near plane (z_eye = -0.1) hides everything between the cut and the eye in both renderings -> identical coverage
+    assert (cov != cov_cut).sum() <= 2, int((cov != cov_cut).sum())
+    assert cov[:24].sum() == 0 or cov[24:].sum() == 0            # the floor occupies one half of the image only
