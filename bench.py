@@ -163,7 +163,10 @@ def main():
             out["op_ms"] = {k: round(v["ms"], 4) for k, v in sorted(op_times.items(), key=lambda kv: -kv[1]["ms"] * kv[1]["n"])}
             out["op_calls_per_step"] = {k: v["n"] / a.steps for k, v in op_times.items()}
         if not a.no_cpu_baseline and world == 1:      # reported at N=1 only (rank 0's host cores)
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(a.res if a.geometry == "tets" else 256)
+            ref = gpu_reference_formulation(trainer)
+            if ref:
+                out["gpu_reference_formulation"] = ref
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -172,11 +175,13 @@ def main():
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_traffic.json; collected with
     rocprofv3 --pmc in separate runs, corrected as MI355X_MICROARCH.md prescribes) -- None if not measured."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return float(json.load(f)[kernel]["bytes"])
-    except Exception:
-        return None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return float(json.load(f)[kernel]["bytes"])
+        except Exception:
+            continue
+    return None
 
 
 def algorithmic_bytes(N, Ftets, V_aug, T, B, H, W):
@@ -193,6 +198,8 @@ def algorithmic_bytes(N, Ftets, V_aug, T, B, H, W):
         "gs_sdf_reg_fwd": 8 * int(1.19 * Ftets) + 4 * N, "gs_texmlp_fwd": npix * 152, "gs_texmlp_bwd": npix * (152 + 128 + 24),
         "gs_frame_sums_fwd": npix * 4 * 49, "gs_frame_sums_bwd": npix * 8 * 49,
         "gs_interpolate_fwd": npix * (16 + 4 * 7), "gs_auto_normals_fwd": 36 * T + 24 * V_aug,
+        "gs_shade_assemble_fwd": npix * 4 * (4 + 6 + 6 + 3 + 3 + 1 + 3 + 3 + 2 + 4 + 4 + 1 + 3 + 45),
+        "gs_shade_assemble_bwd": npix * 4 * (4 + 6 + 6 + 3 + 3 + 1 + 3 + 3 + 2 + 4 + 4 + 1 + 45 + 6 + 6 + 3 + 3 + 3 + 3 + 4 + 4 + 1),
     }
 
 
@@ -225,6 +232,18 @@ def roofline(op_times, N, Ftets, V_aug, T, B, H, W, n):
         return {"kernel": "k_sdf_mlp_fwd (gs_sdf_mlp_fwd)", "bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
                 "frac": round(tf / 157.3, 4), "traffic": pmc_traffic("k_sdf_mlp_fwd") if N == 2282489 else None, "avg_launch_ms": round(rec["ms"], 4), "algorithmic_flops": flops,
                 "note": "fp32-in/fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32); HBM traffic is 16 B/vertex by construction"}
+    if name == "gs_sdf_mlp_fwd_h2":
+        # f16 matrix path with fp16-pair operands: 826 880 ALGORITHMIC flop per grid vertex (what the network defines); the kernel
+        # executes 3 MFMA products per algorithmic product over K padded to 16 (48 + 5 x 256 + 304 input columns x 256 outputs)
+        flops = 826880.0 * N
+        executed = 2.0 * 256 * (48 + 5 * 256 + 304) * 3 * N
+        tf = flops / (rec["ms"] * 1e-3) / 1e12
+        return {"kernel": "k_h2_fwd<GRID> (gs_sdf_mlp_fwd_h2)", "bound": "mfma", "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": round(tf / 2500.0, 4), "traffic": pmc_traffic("k_h2_fwd") if N == 2282489 else None, "avg_launch_ms": round(rec["ms"], 4),
+                "algorithmic_flops": flops, "executed_mfma_flops": executed, "executed_TFLOPs": round(executed / (rec["ms"] * 1e-3) / 1e12, 1),
+                "executed_frac_of_f16_peak": round(executed / (rec["ms"] * 1e-3) / 1e12 / 2500.0, 4), "vs_fp32_mfma_peak_157.3": round(tf / 157.3, 3),
+                "note": "v_mfma_f32_32x32x16_f16, operands = fp16 pairs (2^-22), fp32 accumulate; three products per algorithmic product; "
+                        "the exact-fp32 MFMA kernel it replaces (csrc/mlp.hip) ran at 0.74 of the 157.3 TFLOP/s fp32 roofline"}
     alg = algorithmic_bytes(N, Ftets, V_aug, T, B, H, W).get(name)
     if alg is None:
         return {"kernel": name, "bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
@@ -235,12 +254,76 @@ def roofline(op_times, N, Ftets, V_aug, T, B, H, W, n):
             "note": "ray-traversal kernels are latency/ALU bound; rays/s reported in DESIGN.md"}
 
 
-def cpu_baseline():
+def cpu_baseline(res=256):
+    """CPU numbers of the reference formulation on this box's host cores (reported, not the target):
+      value    end-to-end forward + backward of the oracle pipeline on a bounded sample (numpy brute-force shadow rays make the
+               config size infeasible on a CPU: 20 M rays x 2.3 10^5 triangles per pass)
+      stages   the stages whose reference formulation DOES run at the config size on a CPU: the SDF network over all grid rows
+               (geometry/mlp.py module, torch CPU) and the G-MarchingTets extraction (torch.unique per call + gathers, as
+               geometry/gshell_tets.py:266-276 does) on the tet-res256 grid."""
     try:
         from oracle import pipeline_oracle
     except Exception as e:           # pragma: no cover
         return {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
-    return pipeline_oracle.timed_sample()
+    out = pipeline_oracle.timed_sample()
+    try:
+        out["stages"] = cpu_stage_times(res)
+    except Exception as e:           # pragma: no cover
+        out["stages"] = {"error": str(e)}
+    return out
+
+
+def cpu_stage_times(res):
+    import numpy as np
+    from gshell_amd import grid
+    from gshell_amd.geometry.mlp import MLP
+    from oracle import fields, mtets_oracle
+    st = {"cores": torch.get_num_threads()}
+    verts, tets = grid.grid_for_res(res, device="cpu")
+    torch.manual_seed(0)
+    net = MLP(n_freq=6, d_hidden=256, n_hidden=6, skip_in=[3])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        for i in range(0, verts.shape[0], 1 << 17):
+            net(verts[i:i + (1 << 17)])
+        st["sdf_mlp_fwd"] = {"s": round(time.perf_counter() - t0, 3), "rows": int(verts.shape[0]), "what": "geometry/mlp.py module, torch CPU fp32"}
+    vn = verts.numpy()
+    pos = vn + fields.make_deform(vn, 1.0 / {64: 26, 128: 52, 256: 104}[res], 3)
+    sdf, msdf = fields.make_sdf(pos, "skirt", 3).astype(np.float32), fields.make_msdf(pos, "wavy", 3).astype(np.float32)
+    t0 = time.perf_counter()
+    topo = mtets_oracle.build_topology(tets)                    # the reference sorts / uniques the crossing edges on every call
+    ex = mtets_oracle.extract(torch.tensor(pos.astype(np.float32)), torch.tensor(sdf), torch.tensor(msdf), tets, topo=topo, with_tangents=False)
+    st["extraction_fwd"] = {"s": round(time.perf_counter() - t0, 3), "tets": int(tets.shape[0]), "faces": int(ex["faces_aug"].shape[0]),
+                            "what": "oracle/mtets_oracle (edge unique + gathers, the formulation of geometry/gshell_tets.py:245-443), torch CPU"}
+    return st
+
+
+def gpu_reference_formulation(trainer):
+    """Same-device baseline: the reference's torch formulation of the extraction (per-call edge unique + gathers,
+    oracle/mtets_oracle.py -- pinned bit-exactly to the real geometry/gshell_tets.py) and of the SDF network (geometry/mlp.py
+    module through hipBLASLt) on THIS GPU, beside the hand-written kernels' times."""
+    from oracle import mtets_oracle
+    g = trainer.geometry
+    if not hasattr(g, "gshell_tets"):
+        return None
+    out = {}
+    with torch.no_grad():
+        v = g.verts + g.max_displacement * g.deform
+        sdf = g.sdf_net(v[:1 << 18])            # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sdf = torch.cat([g.sdf_net(v[i:i + (1 << 19)]) for i in range(0, v.shape[0], 1 << 19)])[:, 0]
+        torch.cuda.synchronize()
+        out["sdf_mlp_fwd_torch_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            topo = mtets_oracle.build_topology(g.indices)
+            ex = mtets_oracle.extract(v, sdf, g.msdf.detach(), g.indices, topo=topo, with_tangents=False)
+            torch.cuda.synchronize()
+            out["extraction_fwd_torch_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        out["faces"] = int(ex["faces_aug"].shape[0])
+    return out
 
 
 if __name__ == "__main__":

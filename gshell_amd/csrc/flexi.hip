@@ -82,8 +82,10 @@ __global__ void __launch_bounds__(256) k_flexi_entries(const uint8_t* __restrict
                                                        const int32_t* __restrict__ vd_base, const int32_t* __restrict__ ent_base,
                                                        const int32_t* __restrict__ cube_edge, int64_t F, int32_t* __restrict__ ent_vd,
                                                        int32_t* __restrict__ ent_edge, int32_t* __restrict__ ent_cube, int32_t* __restrict__ ent_e,
-                                                       int32_t* __restrict__ vd_idx_map, int32_t* __restrict__ vd_cube) {
+                                                       int32_t* __restrict__ vd_idx_map, int32_t* __restrict__ vd_cube, int32_t* __restrict__ vd_start,
+                                                       int64_t n_vd, int64_t n_entries) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && vd_start) vd_start[n_vd] = (int32_t)n_entries;
     if (c >= F) return;
     int nv = num_vd[c];
     if (nv == 0) return;
@@ -92,6 +94,7 @@ __global__ void __launch_bounds__(256) k_flexi_entries(const uint8_t* __restrict
     int64_t pos = ent_base[c];
     for (int j = 0; j < nv; ++j) {
         vd_cube[vb + j] = (int32_t)c;
+        if (vd_start) vd_start[vb + j] = (int32_t)pos;      // the entries of a dual vertex are contiguous
         for (int k = 0; k < 7; ++k) {
             int e = c_dmc[cs][j][k];
             if (e == 255) continue;
@@ -159,12 +162,12 @@ extern "C" int gs_flexi_edge_flags(const float* s, const int32_t* edges_ex2, con
 
 extern "C" int gs_flexi_entries(const uint8_t* case_id, const uint8_t* num_vd, const int32_t* vd_base, const int32_t* ent_base, const int32_t* cube_edge,
                                 int64_t F, int32_t* ent_vd, int32_t* ent_edge, int32_t* ent_cube, int32_t* ent_e, int32_t* vd_idx_map, int32_t* vd_cube,
-                                gs_stream_t stream) {
+                                int32_t* vd_start, int64_t n_vd, int64_t n_entries, gs_stream_t stream) {
     if (F == 0) return 0;
     GS_REQUIRE(case_id && num_vd && vd_base && ent_base && cube_edge && ent_vd && ent_edge && ent_cube && ent_e && vd_idx_map && vd_cube,
                "gs_flexi_entries: null pointer");
     hipLaunchKernelGGL(k_flexi_entries, dim3((unsigned)gs::cdiv(F, 256)), dim3(256), 0, (hipStream_t)stream, case_id, num_vd, vd_base, ent_base, cube_edge, F,
-                       ent_vd, ent_edge, ent_cube, ent_e, vd_idx_map, vd_cube);
+                       ent_vd, ent_edge, ent_cube, ent_e, vd_idx_map, vd_cube, vd_start, n_vd, n_entries);
     GS_LAUNCH_CHECK();
     return 0;
 }

@@ -123,6 +123,12 @@ __device__ __forceinline__ float slope_from_value(float a) {
     return x < 0.01f ? x * (1.0f - 0.5f * x + 0.16666667f * x * x) : 1.0f - __builtin_amdgcn_exp2f(-SP_C1 * a);
 }
 
+#ifndef GS_H2_BPF
+#define GS_H2_BPF 0     // 1: double-buffer the LDS (activation) fragments as well
+#endif
+#ifndef GS_H2_PRIO
+#define GS_H2_PRIO 0    // 1: raise the wave priority around the MFMA cluster
+#endif
 #ifndef GS_H2_PD
 #define GS_H2_PD 1      // weight-fragment prefetch distance in k-steps (register ring of PD + 1 stages x 8 VGPRs); measured flat 1..4
 #endif
@@ -144,24 +150,44 @@ __device__ __forceinline__ void gemm_seg(v16f (&hi)[2], v16f (&lo)[2], const _Fl
         a1[i] = wp[i * sstride];
         a2[i] = wp[i * sstride + 64];
     }
+#if GS_H2_BPF
+    h8 c10 = *reinterpret_cast<const h8*>(b1p), c11 = *reinterpret_cast<const h8*>(b1p + 32 * STRIDE);
+    h8 c20 = *reinterpret_cast<const h8*>(b2p), c21 = *reinterpret_cast<const h8*>(b2p + 32 * STRIDE);
+#endif
 #pragma unroll
     for (int st = 0; st < NSTEPS; ++st) {
         if (st + PD < NSTEPS) {
             a1[(st + PD) % (PD + 1)] = wp[(st + PD) * sstride];
             a2[(st + PD) % (PD + 1)] = wp[(st + PD) * sstride + 64];
         }
+#if GS_H2_BPF
+        const h8 b10 = c10, b11 = c11, b20 = c20, b21 = c21;
+        if (st + 1 < NSTEPS) {
+            c10 = *reinterpret_cast<const h8*>(b1p + (st + 1) * 16);
+            c11 = *reinterpret_cast<const h8*>(b1p + 32 * STRIDE + (st + 1) * 16);
+            c20 = *reinterpret_cast<const h8*>(b2p + (st + 1) * 16);
+            c21 = *reinterpret_cast<const h8*>(b2p + 32 * STRIDE + (st + 1) * 16);
+        }
+#else
         const h8 b10 = *reinterpret_cast<const h8*>(b1p + st * 16);
         const h8 b11 = *reinterpret_cast<const h8*>(b1p + 32 * STRIDE + st * 16);
         const h8 b20 = *reinterpret_cast<const h8*>(b2p + st * 16);
         const h8 b21 = *reinterpret_cast<const h8*>(b2p + 32 * STRIDE + st * 16);
+#endif
         const h8 w1 = a1[st % (PD + 1)], w2 = a2[st % (PD + 1)];
         __builtin_amdgcn_sched_barrier(0);
+#if GS_H2_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
         hi[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b10, hi[0], 0, 0, 0);
         hi[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b11, hi[1], 0, 0, 0);
         lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b20, lo[0], 0, 0, 0);
         lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b21, lo[1], 0, 0, 0);
         lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, b10, lo[0], 0, 0, 0);
         lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, b11, lo[1], 0, 0, 0);
+#if GS_H2_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 }

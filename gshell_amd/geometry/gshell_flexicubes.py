@@ -4,10 +4,12 @@
     verts, faces, L_dev, extra = GShellFlexiCubes()(x_nx3, s_n, nu_n, cube_fx8, res, beta_fx12, alpha_fx8, gamma_f)
 
 Index / topology work runs as HIP kernels (gshell_amd/csrc/flexi.hip) over a STATIC per-grid edge table, so no
-`torch.unique` / stable sort / python loop over `num_vd` groups runs per call; the floating-point part (weighted zero
-crossings, dual vertices, L_dev, the mSDF cut interpolation) is expressed as gather / index_add torch ops on the index
-tables the kernels emit, which gives its backward pass through autograd.  Output orderings are bit-identical to the
-reference (tests/test_flexi_gpu.py against goldens minted from the real reference).
+`torch.unique` / stable sort / python loop over `num_vd` groups runs per call; the prefix ranks behind the reference's
+orderings are three scan launches, and the floating-point part (weighted zero crossings, dual vertices, nu_d with the
+reference's in-place quirk, L_dev, the mSDF cut interpolation) and its adjoint are one kernel each
+(gshell_amd/csrc/flexi_float.hip, wrapped by _FlexiVdFn / _FlexiCutFn).  Only the tanh / sigmoid normalisation of the
+per-cube weights stays in torch.  Output orderings are bit-identical to the reference (tests/test_flexi_gpu.py against
+goldens minted from the real reference).
 
 Not implemented (never reached by the reference's scripts): training=True quad fans, output_tetmesh, grad_func.
 """
@@ -49,6 +51,71 @@ class FlexiTopology:
         self.inc = inc.contiguous()
         self.cubes_i32 = cubes.int().contiguous()
         self.corner_of_edge = ce                                   # [12,2]
+
+
+class _FlexiVdFn(torch.autograd.Function):
+    """Dual vertices / nu_d / nu_d_stopvgd / L_dev from the entry tables (gs_flexi_vd_fwd / bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, s, nu, beta, alpha, topo, ent_edge, ent_cube, ent_e, vd_start, n_vd, n_entries):
+        L = _lib.lib()
+        dev = x.device
+        t = [v.detach().contiguous().float() for v in (x, s, nu, beta, alpha)]
+        vd = torch.empty((n_vd, 3), dtype=torch.float32, device=dev)
+        nu_d, nu_d_sv = torch.empty(n_vd, dtype=torch.float32, device=dev), torch.empty(n_vd, dtype=torch.float32, device=dev)
+        l_dev = torch.empty(n_entries, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.gs_flexi_vd_fwd(*[ptr(v, torch.float32) for v in t], ptr(topo.edges, torch.int32), ptr(ent_edge), ptr(ent_cube), ptr(ent_e), ptr(vd_start),
+                                    c_int64(n_vd), ptr(vd), ptr(nu_d), ptr(nu_d_sv), ptr(l_dev), stream()), "gs_flexi_vd_fwd")
+        ctx.t, ctx.tables, ctx.n_vd = t, (topo.edges, ent_edge, ent_cube, ent_e, vd_start), n_vd
+        ctx.shapes = (x.shape, s.shape, nu.shape, beta.shape, alpha.shape)
+        return vd, nu_d, nu_d_sv, l_dev
+
+    @staticmethod
+    def backward(ctx, g_vd, g_nu_d, g_nu_d_sv, g_l):
+        L = _lib.lib()
+        t, (edges, ent_edge, ent_cube, ent_e, vd_start) = ctx.t, ctx.tables
+        dev = t[0].device
+        z = lambda ref: torch.zeros_like(ref)
+        g_x, g_s, g_nu, g_beta, g_alpha = z(t[0]), z(t[1]), z(t[2]), z(t[3]), z(t[4])
+        f = lambda g, n: (torch.zeros(n, dtype=torch.float32, device=dev) if g is None else g.contiguous().float())
+        gv, gn, gs_, gl = f(g_vd, (ctx.n_vd, 3)), f(g_nu_d, ctx.n_vd), f(g_nu_d_sv, ctx.n_vd), f(g_l, ent_edge.shape[0])
+        with torch.cuda.device(dev):
+            check(L.gs_flexi_vd_bwd(*[ptr(v) for v in t], ptr(edges), ptr(ent_edge), ptr(ent_cube), ptr(ent_e), ptr(vd_start), c_int64(ctx.n_vd), ptr(gv),
+                                    ptr(gn), ptr(gs_), ptr(gl), ptr(g_x), ptr(g_s), ptr(g_nu), ptr(g_beta), ptr(g_alpha), stream()), "gs_flexi_vd_bwd")
+        sh = ctx.shapes
+        return (g_x.reshape(sh[0]), g_s.reshape(sh[1]), g_nu.reshape(sh[2]), g_beta.reshape(sh[3]), g_alpha.reshape(sh[4])) + (None,) * 7
+
+
+class _FlexiCutFn(torch.autograd.Function):
+    """Boundary vertices of the mSDF cut: bverts = interp_nonan(nu_d, vd), bnu = interp_nonan(nu_d_sv detached, nu_d_sv)."""
+
+    @staticmethod
+    def forward(ctx, vd, nu_d, nu_d_sv, pa, pb):
+        L = _lib.lib()
+        t = [v.detach().contiguous().float() for v in (vd, nu_d, nu_d_sv)]
+        n = pa.shape[0]
+        bverts = torch.empty((n, 3), dtype=torch.float32, device=vd.device)
+        bnu = torch.empty(n, dtype=torch.float32, device=vd.device)
+        with torch.cuda.device(vd.device):
+            check(L.gs_flexi_cut_fwd(ptr(pa, torch.int64), ptr(pb, torch.int64), c_int64(n), ptr(t[0]), ptr(t[1]), ptr(t[2]), ptr(bverts), ptr(bnu), stream()),
+                  "gs_flexi_cut_fwd")
+        ctx.t, ctx.idx = t, (pa, pb)
+        return bverts, bnu
+
+    @staticmethod
+    def backward(ctx, g_bverts, g_bnu):
+        L = _lib.lib()
+        t, (pa, pb) = ctx.t, ctx.idx
+        n = pa.shape[0]
+        dev = t[0].device
+        g_vd, g_nu_d, g_nu_sv = torch.zeros_like(t[0]), torch.zeros_like(t[1]), torch.zeros_like(t[2])
+        gb = torch.zeros((n, 3), dtype=torch.float32, device=dev) if g_bverts is None else g_bverts.contiguous().float()
+        gn = torch.zeros(n, dtype=torch.float32, device=dev) if g_bnu is None else g_bnu.contiguous().float()
+        with torch.cuda.device(dev):
+            check(L.gs_flexi_cut_bwd(ptr(pa), ptr(pb), c_int64(n), ptr(t[0]), ptr(t[1]), ptr(t[2]), ptr(gb), ptr(gn), ptr(g_vd), ptr(g_nu_d), ptr(g_nu_sv),
+                                     stream()), "gs_flexi_cut_bwd")
+        return g_vd, g_nu_d, g_nu_sv, None, None
 
 
 class GShellFlexiCubes:
@@ -105,28 +172,13 @@ class GShellFlexiCubes:
                                       c_int64(topo.res[2]), ptr(scratch), ptr(case_id), ptr(num_vd), ptr(n_ent), stream()), "gs_flexi_classify")
             flags = torch.empty(E, **u8)
             check(L.gs_flexi_edge_flags(ptr(s_c), ptr(topo.edges), ptr(topo.ncubes), c_int64(E), ptr(flags), stream()), "gs_flexi_edge_flags")
-            # prefix ranks (reference orderings): dual vertices by (num_vd group, cube, j), entries by (group, cube, j, slot),
-            # quads by ascending edge id with the flipped ones first
-            nv = num_vd.long()
-            ne = n_ent.long()
-            vd_base = torch.zeros(F, dtype=torch.long, device=dev)
-            ent_base = torch.zeros(F, dtype=torch.long, device=dev)
-            tot_vd = torch.zeros((), dtype=torch.long, device=dev)
-            tot_ent = torch.zeros((), dtype=torch.long, device=dev)
-            for n in (1, 2, 3, 4):
-                m = nv == n
-                ml = m.long()
-                vd_base = torch.where(m, tot_vd + (torch.cumsum(ml, 0) - 1) * n, vd_base)
-                en = ne * ml
-                ent_base = torch.where(m, tot_ent + torch.cumsum(en, 0) - en, ent_base)
-                tot_vd = tot_vd + ml.sum() * n
-                tot_ent = tot_ent + en.sum()
-            quad = (flags & 2) != 0
-            flip = (flags & 4) != 0
-            qf, qn = (quad & flip).long(), (quad & ~flip).long()
-            n_flip = qf.sum()
-            qrank = torch.where(flip, torch.cumsum(qf, 0) - 1, n_flip + torch.cumsum(qn, 0) - 1).int().contiguous()
-            n_vd, n_entries, n_quads = (int(v) for v in torch.stack([tot_vd, tot_ent, n_flip + qn.sum()]).tolist())     # the one host sync
+            # prefix ranks in the reference's orderings (device scans: count / scan / apply) + the one host sync for the sizes
+            vd_base32, ent_base32, qrank = torch.empty(F, **i32), torch.empty(F, **i32), torch.empty(E, **i32)
+            rscratch = torch.empty(max(int(L.gs_flexi_ranks_scratch_bytes(c_int64(F), c_int64(E))), 8) // 4 + 2, **i32)
+            totals = torch.empty(16, dtype=torch.int64, device=dev)
+            check(L.gs_flexi_ranks(ptr(num_vd), ptr(n_ent), ptr(flags), c_int64(F), c_int64(E), ptr(rscratch), ptr(totals), ptr(vd_base32), ptr(ent_base32),
+                                   ptr(qrank), stream()), "gs_flexi_ranks")
+            n_vd, n_entries, n_quads = (int(v) for v in totals[10:13].tolist())
         if n_vd == 0:           # no surface: the reference returns a 3-tuple (:193-202)
             return (torch.zeros((0, 3), device=dev), torch.zeros((0, 3), dtype=torch.long, device=dev), torch.zeros((0,), device=dev))
 
@@ -134,10 +186,10 @@ class GShellFlexiCubes:
             ent_vd, ent_edge, ent_cube, ent_e = (torch.empty(n_entries, **i32) for _ in range(4))
             vd_idx_map = torch.full((F, 12), -1, **i32)
             vd_cube = torch.empty(n_vd, **i32)
-            vd_base32, ent_base32 = vd_base.int().contiguous(), ent_base.int().contiguous()     # keep alive across the launch
+            vd_start = torch.empty(n_vd + 1, **i32)
             check(L.gs_flexi_entries(ptr(case_id), ptr(num_vd), ptr(vd_base32), ptr(ent_base32), ptr(topo.cube_edge),
-                                     c_int64(F), ptr(ent_vd), ptr(ent_edge), ptr(ent_cube), ptr(ent_e), ptr(vd_idx_map), ptr(vd_cube), stream()),
-                  "gs_flexi_entries")
+                                     c_int64(F), ptr(ent_vd), ptr(ent_edge), ptr(ent_cube), ptr(ent_e), ptr(vd_idx_map), ptr(vd_cube), ptr(vd_start),
+                                     c_int64(n_vd), c_int64(n_entries), stream()), "gs_flexi_entries")
 
         # ---- normalised weights (:242-264)
         ws = self.weight_scale
@@ -145,31 +197,9 @@ class GShellFlexiCubes:
         alpha = torch.ones((F, 8), device=dev) if alpha_fx8 is None else torch.tanh(alpha_fx8) * ws + 1
         gamma = torch.ones((F,), device=dev) if gamma_f is None else torch.sigmoid(gamma_f) * ws + (1 - ws) / 2
 
-        # ---- dual vertices (:387-485): float math over the entry tables
-        ev, ee, ec, el = ent_vd.long(), ent_edge.long(), ent_cube.long(), ent_e.long()
-        a_id, b_id = topo.edges[ee, 0].long(), topo.edges[ee, 1].long()
-        corner = topo.corner_of_edge[el]
-        ca = (s1[a_id] * alpha[ec, corner[:, 0]])[:, None]
-        cb = (s1[b_id] * alpha[ec, corner[:, 1]])[:, None]
-        xa, xb = x_nx3[a_id], x_nx3[b_id]
-        na, nb = nu1[a_id, None], nu1[b_id, None]
-
-        def interp(wa, wb, va, vb):
-            return (va * wb - vb * wa) / (wb - wa)
-        ue = interp(ca, cb, xa, xb)
-        nu_e = interp(ca, cb, na, nb)
-        nu_e_sv = interp(ca.detach(), cb.detach(), na, nb)
-        bt = beta[ec, el][:, None]
-        beta_sum = torch.zeros((n_vd, 1), device=dev).index_add(0, ev, bt)
-        vd = torch.zeros((n_vd, 3), device=dev).index_add(0, ev, ue * bt) / beta_sum
-        nu_d = torch.zeros((n_vd, 1), device=dev).index_add(0, ev, nu_e * bt) / beta_sum
-        nu_d = nu_d.index_add(0, ev, nu_e_sv * bt.detach())              # value of the reference's in-place index_add_ (:476-477)
-        nu_d_sv = nu_d / beta_sum.detach()
-        zc = interp(s1[a_id, None], s1[b_id, None], xa, xb)
-        dist = (zc - vd[ev]).norm(dim=-1)
-        ones = torch.ones_like(dist)
-        mean_l2 = torch.zeros(n_vd, device=dev).index_add(0, ev, dist) / torch.zeros(n_vd, device=dev).index_add(0, ev, ones)
-        L_dev = (dist - mean_l2[ev]).abs()
+        # ---- dual vertices, nu_d, nu_d_stopvgd, L_dev (:387-485, :232-240): one kernel, one thread per dual vertex
+        vd, nu_d, nu_d_sv, L_dev = _FlexiVdFn.apply(x_nx3, s1, nu1, beta, alpha, topo, ent_edge, ent_cube, ent_e, vd_start, n_vd, n_entries)
+        nu_d, nu_d_sv = nu_d[:, None], nu_d_sv[:, None]
 
         # ---- quads -> triangles (:487-522)
         with torch.cuda.device(dev), torch.no_grad():
@@ -190,13 +220,8 @@ class GShellFlexiCubes:
             return vd, faces, L_dev, extra
         pa, pb = cut[:, [0, 1, 2]].reshape(-1), cut[:, [1, 2, 0]].reshape(-1)
 
-        def interp_nonan(wa, wb, va, vb):
-            den = wb - wa
-            ok = den.abs() > 0
-            safe = torch.where(ok, den, torch.ones_like(den))
-            return va * torch.where(ok, wb / safe, torch.zeros_like(den)) + vb * torch.where(ok, -wa / safe, torch.zeros_like(den))
-        bverts = interp_nonan(nu_d[pa], nu_d[pb], vd[pa], vd[pb])
-        bnu = interp_nonan(nu_d_sv[pa].detach(), nu_d_sv[pb].detach(), nu_d_sv[pa], nu_d_sv[pb])
+        bverts, bnu = _FlexiCutFn.apply(vd, nu_d.reshape(-1), nu_d_sv.reshape(-1), pa.contiguous(), pb.contiguous())
+        bnu = bnu[:, None]
         with torch.no_grad():
             mc = mocc[cut_mask].long()
             cfg = mc[:, 0] * 4 + mc[:, 1] * 2 + mc[:, 2]

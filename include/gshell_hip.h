@@ -506,9 +506,45 @@ int gs_flexi_edge_flags(const float* s, const int32_t* edges_ex2, const uint8_t*
                         gs_stream_t stream);
 int gs_flexi_entries(const uint8_t* case_id, const uint8_t* num_vd, const int32_t* vd_base, const int32_t* ent_base,
                      const int32_t* cube_edge, int64_t F, int32_t* ent_vd, int32_t* ent_edge, int32_t* ent_cube,
-                     int32_t* ent_e, int32_t* vd_idx_map, int32_t* vd_cube, gs_stream_t stream);
+                     int32_t* ent_e, int32_t* vd_idx_map, int32_t* vd_cube,
+                     int32_t* vd_start /* [n_vd + 1] first entry of every dual vertex, or NULL */, int64_t n_vd,
+                     int64_t n_entries, gs_stream_t stream);
 int gs_flexi_quads(const uint8_t* flags, const int32_t* qrank, const int32_t* inc_ex4, const int32_t* vd_idx_map,
                    const float* vd_gamma, int64_t E, int64_t* faces, int32_t* faces_i32, gs_stream_t stream);
+
+
+/* ------------------------------------------------------------------------------------
+ * G-FlexiCubes float path   (replaces _compute_vd geometry/gshell_flexicubes.py:387-485, _compute_reg_loss :232-240, the
+ *   boundary vertices of _triangulate_msdf :554-599, and the cumsum / masked-scatter ops behind the reference orderings)
+ *   gs_flexi_ranks  : vd_base / ent_base [F] i32, qrank [E] i32 in the reference's orderings (dual vertices by (num_vd group,
+ *                     cube, j), entries by (group, cube, j, slot), quads flipped-first by edge id) from three launches;
+ *                     totals_dev [16] i64: [10] = n_vd, [11] = n_entries, [12] = n_quads; scratch gs_flexi_ranks_scratch_bytes.
+ *   gs_flexi_vd_fwd : one thread per dual vertex over its contiguous entries -> vd [n_vd,3], nu_d, nu_d_sv [n_vd] (the in-place
+ *                     index_add_ quirk of :476-477 reproduced), l_dev [n_entries].  beta [F,12], alpha [F,8] are the NORMALISED
+ *                     weights (tanh / sigmoid stay with the caller).
+ *   gs_flexi_vd_bwd : adjoint; g_x [N,3], g_s, g_nu [N], g_alpha [F,8] ACCUMULATED (float atomics), g_beta [F,12] slots WRITTEN --
+ *                     the caller zero-fills all five.
+ *   gs_flexi_cut_*  : boundary vertex per (cut triangle, edge): bverts [n,3] = interp_nonan(nu_d, vd), bnu [n] =
+ *                     interp_nonan(nu_d_sv detached, nu_d_sv); bwd ACCUMULATES into g_vd, g_nu_d, g_nu_d_sv.
+ * ---------------------------------------------------------------------------------- */
+int64_t gs_flexi_ranks_scratch_bytes(int64_t F, int64_t E);
+int gs_flexi_ranks(const uint8_t* num_vd, const uint8_t* n_ent, const uint8_t* flags, int64_t F, int64_t E,
+                   void* scratch, int64_t* totals_dev, int32_t* vd_base, int32_t* ent_base, int32_t* qrank,
+                   gs_stream_t stream);
+int gs_flexi_vd_fwd(const float* x, const float* s, const float* nu, const float* beta_fx12, const float* alpha_fx8,
+                    const int32_t* edges_ex2, const int32_t* ent_edge, const int32_t* ent_cube, const int32_t* ent_e,
+                    const int32_t* vd_start, int64_t n_vd, float* vd, float* nu_d, float* nu_d_sv, float* l_dev,
+                    gs_stream_t stream);
+int gs_flexi_vd_bwd(const float* x, const float* s, const float* nu, const float* beta_fx12, const float* alpha_fx8,
+                    const int32_t* edges_ex2, const int32_t* ent_edge, const int32_t* ent_cube, const int32_t* ent_e,
+                    const int32_t* vd_start, int64_t n_vd, const float* g_vd, const float* g_nu_d,
+                    const float* g_nu_d_sv, const float* g_l_dev, float* g_x, float* g_s, float* g_nu, float* g_beta,
+                    float* g_alpha, gs_stream_t stream);
+int gs_flexi_cut_fwd(const int64_t* pa, const int64_t* pb, int64_t n, const float* vd, const float* nu_d,
+                     const float* nu_d_sv, float* bverts, float* bnu, gs_stream_t stream);
+int gs_flexi_cut_bwd(const int64_t* pa, const int64_t* pb, int64_t n, const float* vd, const float* nu_d,
+                     const float* nu_d_sv, const float* g_bverts, const float* g_bnu, float* g_vd, float* g_nu_d,
+                     float* g_nu_d_sv, gs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,8 @@ def test_flexi_matches_reference_goldens(path):
     loss.backward()
     for name, t in (("g_x", X), ("g_s", S), ("g_nu", NU), ("g_w", Wt)):
         got = t.grad.cpu().numpy() if t.grad is not None else np.zeros_like(g[name])
+        rel = float(np.linalg.norm(got - g[name]) / max(np.linalg.norm(g[name]), 1e-30))
+        assert rel < 1e-4, (name, rel)                       # 1e-4 relative (north_star), in aggregate: float atomics reorder the sums
         np.testing.assert_allclose(got, g[name], rtol=1e-3, atol=1e-4 * max(1.0, np.abs(g[name]).max()), err_msg=name)
 
 
@@ -62,7 +64,13 @@ def test_flexi_matches_oracle_res24_and_voxel_grid():
     np.testing.assert_array_equal(f.cpu().numpy(), ref[1].numpy())
     np.testing.assert_array_equal(ex["faces_watertight"].cpu().numpy(), ref[3]["faces_watertight"].numpy())
     assert torch.allclose(v.detach().cpu(), ref[0], rtol=1e-4, atol=2e-6) and torch.allclose(L.detach().cpu(), ref[2], rtol=1e-4, atol=2e-6)
-    assert torch.allclose(ex["msdf"].detach().cpu(), ref[3]["msdf"], rtol=1e-4, atol=2e-6)
+    nw = ex["n_verts_watertight"]
+    assert torch.allclose(ex["msdf"].detach().cpu()[:nw], ref[3]["msdf"][:nw], rtol=1e-4, atol=2e-6)
+    # the mSDF of a boundary vertex is analytically ZERO (it is the zero crossing of the cut): both sides return only the round-off
+    # noise of  u_a u_b / (u_b - u_a) - u_b u_a / (u_b - u_a),  which is amplified by 1 / (u_b - u_a) and depends on the last bit
+    # of nu_d -- compare it as noise (absolute), not as a value
+    assert float((ex["msdf"].detach().cpu()[nw:] - ref[3]["msdf"][nw:]).abs().max()) < 5e-5
+    assert float(ex["msdf_boundary"].detach().abs().max()) < 5e-5
     # second call on the same grid reuses the static topology: identical topology (floats go through index_add atomics, like
     # the reference's index_add_, so they agree to round-off only)
     out2 = fc(X, S, NU, cubes, res, Wt[:, :12], Wt[:, 12:20], Wt[:, 20])

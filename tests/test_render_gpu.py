@@ -78,7 +78,8 @@ def test_render_mesh_matches_pipeline_oracle(denoise):
         if key == 'visible_triangles':
             continue
         frac = _close_frac(out[key].detach().cpu(), ref[key].detach(), 1e-4)
-        floor = 0.97 if key in ('shaded', 'diffuse_light', 'specular_light') else 0.995     # MC sample-placement flips, see test_shade_gpu
+        floor = 0.999       # measured on MI355X (r02): 1.0000 for every buffer of every case (MC sample-placement flips: see test_shade_gpu)
+        print(f"  buffer {key}: pixels within 1e-4: {frac:.4f}")
         assert frac >= floor, (key, frac)
 
     gen2 = torch.Generator().manual_seed(9)
@@ -97,4 +98,6 @@ def test_render_mesh_matches_pipeline_oracle(denoise):
         assert b.abs().max() > 0, name
         # float atomics + a few MC placement flips: compare in aggregate (relative L2) and element-wise coverage
         rel = float((a - b).norm() / b.norm())
-        assert rel < (5e-2 if name in ("light",) else 2e-2), (name, rel)
+        print(f"  end-to-end gradient {name}: relative L2 error {rel:.2e}")
+        # measured (r02): v_pos 1.4e-4 .. 1.7e-4 (float atomics through the silhouette antialiasing), everything else <= 8e-5
+        assert rel < (5e-4 if name == "v_pos" else 2e-4), (name, rel)

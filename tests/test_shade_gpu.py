@@ -63,11 +63,13 @@ def _gbuffer(B, H, W, seed):
 def test_env_shade_matches_oracle(bsdf, n, shadow):
     from gshell_amd.render import optixutils as ou
     B, H, W = 2, 20, 20
-    if n == 8:
-        B, H, W = 1, 12, 12
+    probe = (16, 32)
+    if n == 8:          # the benchmarked sample count (128 shadow rays per pixel and pass) on a 64 x 64 frame, finer probe
+        B, H, W = 1, 64, 64
+        probe = (64, 128)
     verts, tri, mask, gb_pos, gb_nrm, view, kd, ks = _gbuffer(B, H, W, 3)
     gen = torch.Generator().manual_seed(9)
-    light = torch.rand(16, 32, 3, generator=gen) * 2 + 0.05
+    light = torch.rand(probe[0], probe[1], 3, generator=gen) * 2 + 0.05
     pdf, rows, cols = po.update_pdf(light)
     perms = torch.argsort(torch.rand(ou.PERM_ROWS, n * n, generator=gen), dim=-1).int()
     wd, ws = torch.rand(B, H, W, 3, generator=gen), torch.rand(B, H, W, 3, generator=gen)
@@ -91,9 +93,16 @@ def test_env_shade_matches_oracle(bsdf, n, shadow):
         scale = b.abs().max().clamp(min=1e-12)
         return float(((a - b).abs() <= rtol * b.abs() + rtol * scale).float().mean())
     # sample placement uses sin/cos/acos/atan2: a GPU/CPU ulp can move a sample across a texel or lobe boundary, which changes
-    # ONE of the 2 n^2 samples of that pixel.  Demand >= 97 % of pixels within 1e-4 (north_star tolerance) and no drift overall.
-    assert close_frac(d.cpu(), d_ref.detach()) > 0.97, close_frac(d.cpu(), d_ref.detach())
-    assert close_frac(s.cpu(), s_ref.detach()) > 0.97, close_frac(s.cpu(), s_ref.detach())
+    # ONE of the 2 n^2 samples of that pixel.  Measured on MI355X (r02): every pixel of every case within 1e-4, position /
+    # normal gradients 0.9998 of the pixels at n = 8 on 64 x 64.  Demand 99.9 % / 99.5 % and bound the outliers.
+    print(f"n={n} {H}x{W}: pixels within 1e-4: diffuse {close_frac(d.cpu(), d_ref.detach()):.4f} specular {close_frac(s.cpu(), s_ref.detach()):.4f}; "
+          + " ".join(f"{nm} {close_frac(a.grad.cpu(), b.grad, rtol=2e-4):.4f}" for nm, a, b in zip(("g_pos", "g_nrm", "g_kd", "g_ks", "g_light"), dl, leaves)
+                     if a.grad is not None and b.grad is not None))
+    assert close_frac(d.cpu(), d_ref.detach()) >= 0.999, close_frac(d.cpu(), d_ref.detach())
+    assert close_frac(s.cpu(), s_ref.detach()) >= 0.999, close_frac(s.cpu(), s_ref.detach())
+    # a flipped sample is ONE of the 2 n^2 samples of its pixel: no pixel may be off by more than a few samples' worth
+    worst = float(((d.cpu() - d_ref.detach()).abs().amax(dim=-1) / d_ref.detach().abs().amax().clamp_min(1e-12)).max())
+    assert worst <= 8.0 / (2 * n * n) + 1e-4, worst
     assert abs(float(d.sum()) - float(d_ref.sum())) <= 2e-3 * float(d_ref.sum())
     assert (d.cpu()[mask == 0] == 0).all() and (s.cpu()[mask == 0] == 0).all()
     names = ("gb_pos", "gb_normal", "kd", "ks", "light")
@@ -103,7 +112,7 @@ def test_env_shade_matches_oracle(bsdf, n, shadow):
             continue
         assert b.grad.abs().max() > 0, name
         frac = close_frac(a.grad.cpu(), b.grad, rtol=2e-4)
-        assert frac > (0.90 if name == "light" else 0.96), (name, frac)
+        assert frac >= (0.99 if name == "light" else 0.995), (name, frac)
         assert abs(float(a.grad.sum()) - float(b.grad.sum())) <= 5e-3 * float(b.grad.abs().sum()), name
 
 
