@@ -35,9 +35,11 @@ def test_hashgrid_matches_oracle(cfg):
     assert ok.float().mean() > 0.999
     print(f"  hash grid: out within 1e-4: {float(ok.float().mean()):.5f}; param-grad max err / max {float((pd.grad.cpu() - p_ref.grad).abs().max() / p_ref.grad.abs().max()):.2e}; "
           f"param-grad rel L2 {float((pd.grad.cpu() - p_ref.grad).norm() / p_ref.grad.norm()):.2e}; x-grad rel L2 {float((xd.grad.cpu() - x_ref.grad).norm() / x_ref.grad.norm()):.2e}")
-    assert (pd.grad.cpu() - p_ref.grad).abs().max() <= 1e-3 * p_ref.grad.abs().max()
-    okx = ((xd.grad.cpu() - x_ref.grad).abs() <= 1e-3 * x_ref.grad.abs() + 1e-3 * x_ref.grad.abs().max())
-    assert okx.float().mean() > 0.995
+    # measured on MI355X (r02): max error / max 1e-7 .. 5e-7, relative L2 <= 2.4e-7 (float-atomic order)
+    assert (pd.grad.cpu() - p_ref.grad).abs().max() <= 1e-5 * p_ref.grad.abs().max()
+    okx = ((xd.grad.cpu() - x_ref.grad).abs() <= 1e-4 * x_ref.grad.abs() + 1e-5 * x_ref.grad.abs().max())
+    assert okx.float().mean() > 0.999
+    assert float((xd.grad.cpu() - x_ref.grad).norm() / x_ref.grad.norm()) < 1e-5
     # masked rows produce zeros and no gradient
     mask = (torch.arange(N) % 3 != 0).float().to(DEV)
     xm, pm = x.to(DEV).requires_grad_(True), params.to(DEV).requires_grad_(True)
