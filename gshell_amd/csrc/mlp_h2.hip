@@ -528,6 +528,7 @@ struct WgradArgs {
     int64_t Rpad;
     int E, n_layers, skip_layer, mode;
     int slabs_per_strip;  // 32-row slabs per workgroup
+    int only_output;      // 1: k_h2_wgrad handles the output layer only (the hidden layers run in k_h2_wgrad16)
     float* dW[MAX_LAYERS + 1];     // torch layout [256][K_l]; [n_layers] = output layer [1][256]
     float* db[MAX_LAYERS + 1];     // [256]; the output layer's bias gradient is the caller's
 };
@@ -636,9 +637,151 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs& W, int l, float* sm
     }
 }
 
+// ---- weight gradients on the bf16 matrix path (default) -----------------------------------------------------------------
+// Same job as wgrad_layer above at 3/16 of its matrix-core time: D and X are split into bf16 pairs v = hi + lo (bf16 keeps the
+// fp32 exponent range, so the gradient planes need no scaling; 16 significant bits per operand, products hi hi + hi lo + lo hi
+// = relative 2^-16 per term, unbiased, over >= 10^5 rows) and multiplied with v_mfma_f32_32x32x16_bf16 into ONE fp32
+// accumulator.  The MFMA reduces over ROWS here, so both fragments need 8 consecutive rows per lane: the fp32 slabs are
+// transposed on the way into LDS -- lane = feature, 4 consecutive rows per thread -> one ds_write_b64 per (feature, piece) into
+// a [feature][32 rows + 8 pad] image whose 80-byte row stride keeps the ds_read_b128 fragment reads conflict-free.
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+constexpr int WB_RS = WS + 8;                               // image row stride (bf16 elements): 80 B = 5 sixteen-byte slots
+constexpr int WB_FEATS = D + D + 64;                        // D_l | X_h | X_e (64 = encoding padded)
+constexpr int WB_PLANE = WB_FEATS * WB_RS;                  // one piece
+constexpr size_t SMEM_WGRAD16_BYTES = (size_t)2 * WB_PLANE * sizeof(__bf16);
+
+__device__ __forceinline__ void split_bf16_4(const float (&v)[4], bf4& hi, bf4& lo) {
+    const f2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    const bf2 ha = __builtin_convertvector(a, bf2), hb = __builtin_convertvector(b, bf2);
+    const bf2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f2), bf2);
+    const bf2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f2), bf2);
+    hi = bf4{ha.x, ha.y, hb.x, hb.y};
+    lo = bf4{la.x, la.y, lb.x, lb.y};
+}
+
+template <int NB, bool HAS_H, bool HAS_E>
+__device__ __forceinline__ void wgrad16_layer(const WgradArgs& W, int l, __bf16* img, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t slab0 = (int64_t)blockIdx.x * W.slabs_per_strip;
+    const int64_t nslab = min((int64_t)W.slabs_per_strip, W.Rpad / WS - slab0);
+    if (nslab <= 0) return;
+    const float* Dl = W.D + (int64_t)l * W.Rpad * D;
+    const float* Xh = HAS_H ? W.A + (int64_t)(l - 1) * W.Rpad * D : nullptr;
+    __bf16* hi_img = img;
+    __bf16* lo_img = img + WB_PLANE;
+    v16f acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    // staging: this thread owns rows 4 wave .. 4 wave + 3 of the slab and features lane + 64 c (c = 0..3) of D and of X_h,
+    // feature `lane` of the encoding (lane < EK)
+    float dreg[4][4], xreg[4][4], ereg[4];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    auto load_slab = [&](int64_t slab) {
+        const int64_t r0 = slab * WS + 4 * wave;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dreg[c][i] = Dl[(r0 + i) * D + lane + 64 * c];
+                if (HAS_H) xreg[c][i] = Xh[(r0 + i) * D + lane + 64 * c];
+            }
+        if (HAS_E)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ereg[i] = lane < EK ? W.EMB[(r0 + i) * EK + lane] : 0.0f;
+    };
+    auto store_slab = [&](int64_t slab) {
+        const int roff = 4 * wave;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf4 h, lw;
+            split_bf16_4(dreg[c], h, lw);
+            *reinterpret_cast<bf4*>(hi_img + (lane + 64 * c) * WB_RS + roff) = h;
+            *reinterpret_cast<bf4*>(lo_img + (lane + 64 * c) * WB_RS + roff) = lw;
+            if (HAS_H) {
+                split_bf16_4(xreg[c], h, lw);
+                *reinterpret_cast<bf4*>(hi_img + (D + lane + 64 * c) * WB_RS + roff) = h;
+                *reinterpret_cast<bf4*>(lo_img + (D + lane + 64 * c) * WB_RS + roff) = lw;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool value_row = W.mode != MODE_EIK || (((slab * WS + roff + i) & 63) < 16);
+                if (value_row) bsum[c] += dreg[c][i];
+            }
+        }
+        if (HAS_E) {
+            bf4 h, lw;
+            split_bf16_4(ereg, h, lw);
+            *reinterpret_cast<bf4*>(hi_img + (2 * D + lane) * WB_RS + roff) = h;
+            *reinterpret_cast<bf4*>(lo_img + (2 * D + lane) * WB_RS + roff) = lw;
+        }
+    };
+    load_slab(slab0);
+    for (int64_t s = 0; s < nslab; ++s) {
+        store_slab(slab0 + s);
+        __syncthreads();
+        if (s + 1 < nslab) load_slab(slab0 + s + 1);        // in flight during the MFMAs below
+        const int roff = 8 * (lane >> 5);
+        const __bf16* ah = hi_img + (wave * 32 + (lane & 31)) * WB_RS + roff;
+        const __bf16* al = lo_img + (wave * 32 + (lane & 31)) * WB_RS + roff;
+#pragma unroll
+        for (int ks = 0; ks < WS / 16; ++ks) {
+            const bf8 dh = *reinterpret_cast<const bf8*>(ah + 16 * ks), dl = *reinterpret_cast<const bf8*>(al + 16 * ks);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int feat = (HAS_H ? (b < 8 ? D + 32 * b : 2 * D + 32 * (b - 8)) : 2 * D + 32 * b) + (lane & 31);
+                const bf8 xh = *reinterpret_cast<const bf8*>(hi_img + feat * WB_RS + roff + 16 * ks);
+                const bf8 xl = *reinterpret_cast<const bf8*>(lo_img + feat * WB_RS + roff + 16 * ks);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, xh, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, xl, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl, xh, acc[b], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const int Kreal = (HAS_H ? D : 0) + (HAS_E ? W.E : 0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        int k = 32 * b + (lane & 31);
+        bool ok = true;
+        if (HAS_E && b >= (HAS_H ? 8 : 0)) {
+            const int e = 32 * (b - (HAS_H ? 8 : 0)) + (lane & 31);
+            ok = e < W.E;
+            k = (HAS_H ? D : 0) + e;
+        }
+        if (ok)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                atomicAdd(W.dW[l] + (int64_t)n * Kreal + k, acc[b][r]);
+            }
+    }
+    // bias gradient: thread (wave, lane) holds the partial column sums of features lane + 64 c over its rows
+    float* red = reinterpret_cast<float*>(img);       // [8 waves][256]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wave * D + lane + 64 * c] = bsum[c];
+    __syncthreads();
+    if (tid < D) {
+        float t = 0.f;
+        for (int w = 0; w < 8; ++w) t += red[w * D + tid];
+        atomicAdd(W.db[l] + tid, t);
+    }
+}
+
+__global__ void __launch_bounds__(NT, 2) k_h2_wgrad16(WgradArgs W) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem_b[];
+    const int l = blockIdx.y, tid = threadIdx.x;
+    if (l == 0) wgrad16_layer<2, false, true>(W, l, smem_b, tid);
+    else if (l == W.skip_layer) wgrad16_layer<10, true, true>(W, l, smem_b, tid);
+    else wgrad16_layer<8, true, false>(W, l, smem_b, tid);
+}
+
 __global__ void __launch_bounds__(NT, 2) k_h2_wgrad(WgradArgs W) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    const int l = blockIdx.y, tid = threadIdx.x;
+    const int l = W.only_output ? W.n_layers : blockIdx.y, tid = threadIdx.x;
     if (l == W.n_layers) {
         // output layer: dw_out[n] = sum_rows g_out[row] a_{L-1}[row][n]  (tangent rows included: their g_out is dL/d(df/dx_d))
         const int64_t slab0 = (int64_t)blockIdx.x * W.slabs_per_strip, nslabs_total = W.Rpad / WS;
@@ -674,7 +817,7 @@ constexpr size_t SMEM_BYTES = (size_t)(2 * TM * LDH + 2 * TM * LDEH) * sizeof(_F
 constexpr size_t SMEM_BWD_BYTES = (size_t)(2 * TM * LDH) * sizeof(_Float16) + (size_t)(TM * LDG + TM) * sizeof(float);
 constexpr size_t SMEM_WGRAD_BYTES = (size_t)2 * WG_BUF * sizeof(float);
 static_assert(SMEM_BYTES <= 80 * 1024 && SMEM_BWD_BYTES <= 80 * 1024, "two workgroups per CU");
-static_assert(SMEM_WGRAD_BYTES <= 160 * 1024, "LDS");
+static_assert(SMEM_WGRAD_BYTES <= 160 * 1024 && SMEM_WGRAD16_BYTES <= 160 * 1024, "LDS");
 
 // ---- weight packing ------------------------------------------------------------------------------------------------
 // packed = [ forward fragments | transposed (dgrad) fragments | fp32 tail: biases [n_layers][256], w_out [256], b_out ]
@@ -892,7 +1035,7 @@ extern "C" int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* ro
 // dW, db = HOST arrays of n_hidden + 2 DEVICE pointers (Linear.weight.grad [out,in], Linear.bias.grad), output layer last;
 // db[n_hidden + 1] (the output bias, = sum of g_out over the value rows) is not touched.
 extern "C" int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, int n_freq, int n_hidden, int skip_layer, const float* A_save,
-                                   const float* EMB_save, const float* D_save, float* const* dW, float* const* db, gs_stream_t stream) {
+                                   const float* EMB_save, const float* D_save, float* const* dW, float* const* db, int exact_fp32, gs_stream_t stream) {
     if (n == 0) return 0;
     GS_REQUIRE(mode == MODE_ROWS || mode == MODE_EIK, "gs_sdf_mlp_h2_wgrad: mode must be 1 (rows) or 2 (eikonal)");
     GS_REQUIRE(g_out && A_save && EMB_save && D_save && dW && db, "gs_sdf_mlp_h2_wgrad: null pointer");
@@ -910,7 +1053,14 @@ extern "C" int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, int 
     W.slabs_per_strip = (int)gs::cdiv(nslabs, strips);
     strips = (int)gs::cdiv(nslabs, W.slabs_per_strip);
     GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_WGRAD_BYTES));
-    hipLaunchKernelGGL(k_h2_wgrad, dim3((unsigned)strips, (unsigned)(W.n_layers + 1)), dim3(NT), SMEM_WGRAD_BYTES, (hipStream_t)stream, W);
+    if (exact_fp32) {
+        hipLaunchKernelGGL(k_h2_wgrad, dim3((unsigned)strips, (unsigned)(W.n_layers + 1)), dim3(NT), SMEM_WGRAD_BYTES, (hipStream_t)stream, W);
+    } else {
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_wgrad16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_WGRAD16_BYTES));
+        hipLaunchKernelGGL(k_h2_wgrad16, dim3((unsigned)strips, (unsigned)W.n_layers), dim3(NT), SMEM_WGRAD16_BYTES, (hipStream_t)stream, W);
+        W.only_output = 1;
+        hipLaunchKernelGGL(k_h2_wgrad, dim3((unsigned)strips, 1), dim3(NT), SMEM_WGRAD_BYTES, (hipStream_t)stream, W);
+    }
     GS_LAUNCH_CHECK();
     return 0;
 }

@@ -196,6 +196,9 @@ def pack_weights(net):
 #          operands represented to 2^-22, measured max |err| vs float64 within 2x of the fp32 kernel's own
 #   "fp32" csrc/mlp.hip -- v_mfma_f32_32x32x2_f32, bitwise a k-ordered fmaf chain, 4x slower; kept as the oracle of "h2"
 SDF_MLP_PRECISION = "h2"
+# weight gradients: False = bf16-pair operands on the bf16 matrix path (2^-16 per product, unbiased, summed over >= 10^5 rows);
+# True = the exact-fp32 MFMA version (5x slower), kept as its oracle
+SDF_MLP_WGRAD_FP32 = False
 
 
 def _layer_structure(net):
@@ -335,7 +338,8 @@ class _SavedChain:
                                       c_int(self.nf), c_int(self.n_hidden), c_int(self.skip), ptr(self.A), ptr(self.EMB), ptr(D), ptr(g_x), stream()),
                   "gs_sdf_mlp_h2_bwd")
             check(L.gs_sdf_mlp_h2_wgrad(c_int(self.mode), ptr(g_out), c_int64(self.n), c_int(self.nf), c_int(self.n_hidden), c_int(self.skip), ptr(self.A),
-                                        ptr(self.EMB), ptr(D), _ptr_array(dW), _ptr_array(db), stream()), "gs_sdf_mlp_h2_wgrad")
+                                        ptr(self.EMB), ptr(D), _ptr_array(dW), _ptr_array(db), c_int(1 if SDF_MLP_WGRAD_FP32 else 0), stream()),
+                  "gs_sdf_mlp_h2_wgrad")
         if self.mode == 1:      # output bias: sum of the upstream gradient over the (value) rows
             db[-1].copy_(g_out.sum().reshape(db[-1].shape))
         return [grads[id(p)] for p in params]

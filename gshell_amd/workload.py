@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import grid as gridlib
+from .geometry.mlp import forward_row_sparse_backward
 from .render import util
 
 
@@ -60,7 +61,8 @@ def fit_sdf_net(geometry, steps=400, batch=65536, seed=0):
     for _ in range(steps):
         idx = torch.randint(0, N, (min(batch, N),), device=geometry.verts.device, generator=g)
         x = geometry.verts[idx]
-        loss = (geometry.sdf_net(x)[:, 0] - skirt_sdf(x)).pow(2).mean()
+        # through the library's own kernels (h2 forward + chain backward + MFMA weight gradients), like the training iteration
+        loss = (forward_row_sparse_backward(geometry.sdf_net, x)[:, 0] - skirt_sdf(x)).pow(2).mean()
         opt.zero_grad()
         loss.backward()
         opt.step()

@@ -486,7 +486,9 @@ int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* rows, int64_t
                       const float* EMB_save, float* D_save, float* g_x, gs_stream_t stream);
 int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, int n_freq, int n_hidden, int skip_layer,
                         const float* A_save, const float* EMB_save, const float* D_save,
-                        float* const* dW, float* const* db, gs_stream_t stream);
+                        float* const* dW, float* const* db,
+                        int exact_fp32 /* 0: bf16-pair operands on the bf16 matrix path (default); 1: fp32 MFMA */,
+                        gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * G-FlexiCubes topology   (replaces the index machinery of GShellFlexiCubes.__call__,

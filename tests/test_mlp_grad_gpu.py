@@ -26,9 +26,11 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
 
 
-@pytest.mark.parametrize("n_hidden,skip_in,need_x", [(6, (3,), True), (6, (3,), False), (2, (), True)])
-def test_row_sparse_backward_matches_float64_autograd(n_hidden, skip_in, need_x):
+@pytest.mark.parametrize("n_hidden,skip_in,need_x,wgrad_fp32", [(6, (3,), True, False), (6, (3,), False, True), (2, (), True, False)])
+def test_row_sparse_backward_matches_float64_autograd(n_hidden, skip_in, need_x, wgrad_fp32, monkeypatch):
+    from gshell_amd.geometry import mlp as mlp_mod
     from gshell_amd.geometry.mlp import row_sparse_backward, row_sparse_backward_torch
+    monkeypatch.setattr(mlp_mod, "SDF_MLP_WGRAD_FP32", wgrad_fp32)       # bf16-pair weight gradients (default) / the exact-fp32 MFMA version
     net = _net(n_hidden, skip_in)
     g = torch.Generator(device=DEV).manual_seed(1)
     N = 5000 + 13
@@ -48,6 +50,8 @@ def test_row_sparse_backward_matches_float64_autograd(n_hidden, skip_in, need_x)
         assert float(g_x[rows_without].abs().max()) == 0.0
     else:
         assert g_x is None
+    print("  row-sparse backward, relative L2 error vs float64 per parameter (wgrad fp32 = %s): " % wgrad_fp32
+          + " ".join("%.1e" % _rel(a, b) for a, b in zip(grads, ref[1:])))
     for (name, _), a, b in zip(net.named_parameters(), grads, ref[1:]):
         assert a.shape == b.shape
         assert _rel(a, b) < 1e-4, (name, _rel(a, b))
@@ -55,7 +59,7 @@ def test_row_sparse_backward_matches_float64_autograd(n_hidden, skip_in, need_x)
     _, grads_t = row_sparse_backward_torch(net, x, gy, False)
     worst_hip = max(_rel(a, b) for a, b in zip(grads, ref[1:]))
     worst_torch = max(_rel(a, b) for a, b in zip(grads_t, ref[1:]))
-    assert worst_hip < max(20 * worst_torch, 2e-6), (worst_hip, worst_torch)
+    assert worst_hip < max(20 * worst_torch, 2e-6 if wgrad_fp32 else 3e-5), (worst_hip, worst_torch)
 
 
 @pytest.mark.parametrize("n", [1000 + 7, 16])
@@ -72,6 +76,7 @@ def test_eikonal_term_matches_float64_double_backward(n):
     loss64 = (gr.pow(2).sum(dim=-1).sqrt() - 1).pow(2).sum() * 0.37
     ref = torch.autograd.grad(loss64, list(net64.parameters()), allow_unused=True)
     assert abs(float(loss) - float(loss64)) <= 1e-5 * abs(float(loss64))
+    print("  eikonal term, relative L2 error vs float64 double backward per parameter: " + " ".join("%.1e" % _rel(a, b) for a, b in zip(grads, ref) if b is not None))
     for (name, p), a, b in zip(net.named_parameters(), grads, ref):
         if b is None:                      # the output bias does not influence grad_x f
             assert float(a.abs().max()) == 0.0, name
