@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--fit-steps", type=int, default=400)
     ap.add_argument("--geometry", choices=["tets", "flexicubes"], default="tets", help="flexicubes + --res 80 = BASELINE.json configs[4]")
     ap.add_argument("--set", action="append", default=[], metavar="FLAG=VALUE", help="override a training flag (python literal), e.g. --set eikonal_side_stream=False")
+    ap.add_argument("--state-file", default=None, help="save the fitted set-up state here / load it if the file exists (profiling runs skip the set-up kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--op-times", action="store_true", help="also print per-op HIP-event times (adds sync points)")
     return ap.parse_args()
@@ -100,7 +101,7 @@ def main():
     import ast
     overrides = {kv.split('=', 1)[0]: ast.literal_eval(kv.split('=', 1)[1]) for kv in a.set}
     trainer = workload.build(res=a.res, n_samples=a.n_samples, batch=B_global, train_res=(H, W), shard=shard, fit_steps=a.fit_steps, geometry=a.geometry,
-                             **overrides)
+                             state_file=a.state_file, **overrides)
     # this rank's views of every global batch: ids [it*B + r, it*B + r + world, ...]
     n_iters = a.warmup + a.steps
     targets = [workload.make_targets(trainer, [(it * B_global + v) % 72 for v in shard.local_views(B_global)], (H, W)) for it in range(min(n_iters, 4))]
