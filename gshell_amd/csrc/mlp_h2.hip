@@ -217,15 +217,7 @@ __device__ __forceinline__ bool tile_point(const H2Args& A, int64_t tile, int ro
     return true;
 }
 
-// (x, sin(2^k x), cos(2^k x))_k  /  its derivative w.r.t. x_d   (geometry/embedding.py:22-39)
-__device__ __forceinline__ float encoding_entry(const float (&p)[3], int f, int c) {
-    if (f < 3) return c == 0 ? p[f] : (f == c - 1 ? 1.0f : 0.0f);
-    const int g = f - 3, k = g / 6, sc = (g % 6) / 3, cc = g % 3;
-    const float fr = (float)(1 << k), arg = fr * p[cc];
-    if (c == 0) return sc ? cosf(arg) : sinf(arg);
-    if (cc != c - 1) return 0.0f;
-    return sc ? -fr * sinf(arg) : fr * cosf(arg);
-}
+static_assert(EK == 48, "the encoding stage lays out 39 + 9 columns");
 
 template <int MODE>
 __global__ void __launch_bounds__(NT, 4) k_h2_fwd(H2Args A) {
@@ -237,18 +229,39 @@ __global__ void __launch_bounds__(NT, 4) k_h2_fwd(H2Args A) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t tile = blockIdx.x, r0 = tile * TM;
 
-    // encoding of the tile, zero padded to EK columns, zero rows past the end
-    for (int idx = tid; idx < TM * EK; idx += NT) {
-        int row = idx / EK, f = idx - row * EK;
-        float p[3];
-        int c;
-        float v = 0.f;
-        if (f < A.E && tile_point<MODE>(A, tile, row, p, c)) v = encoding_entry(p, f, c);
+    // encoding of the tile, zero padded to EK columns, zero rows past the end.  24 work items per row: 18 (frequency, axis)
+    // pairs -- ONE sincosf serves the sin and the cos column (and, on tangent rows, both derivatives) --, the 3 coordinates,
+    // and 3 x 3 padding columns
+    auto put = [&](int row, int f, float v) {
         _Float16 hi, lo;
         split_h2(v, hi, lo);
         E1[row * LDEH + f] = hi;
         E2[row * LDEH + f] = lo;
         if (MODE != MODE_GRID) A.EMB[(r0 + row) * EK + f] = v;
+    };
+    for (int idx = tid; idx < TM * 24; idx += NT) {
+        const int row = idx / 24, slot = idx - row * 24;
+        float p[3] = {0.f, 0.f, 0.f};
+        int c = 0;
+        const bool valid = tile_point<MODE>(A, tile, row, p, c);
+        if (slot < 18) {
+            const int k = slot / 3, ax = slot - 3 * k;
+            float vs = 0.f, vc = 0.f;
+            if (valid && k < A.n_freq) {
+                const float fr = (float)(1 << k);
+                float sn, cs;
+                sincosf(fr * p[ax], &sn, &cs);
+                if (c == 0) { vs = sn; vc = cs; }
+                else if (ax == c - 1) { vs = fr * cs; vc = -fr * sn; }      // d/dx_ax of (sin, cos)(2^k x_ax)
+            }
+            put(row, 3 + 6 * k + ax, vs);
+            put(row, 3 + 6 * k + 3 + ax, vc);
+        } else if (slot < 21) {
+            const int f = slot - 18;
+            put(row, f, valid ? (c == 0 ? p[f] : (f == c - 1 ? 1.0f : 0.0f)) : 0.0f);
+        } else {
+            for (int j = 0; j < 3; ++j) put(row, 39 + 3 * (slot - 21) + j, 0.0f);
+        }
     }
     __syncthreads();
 

@@ -7,7 +7,7 @@ import sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "pmc_mlp")
 c = {}
-for tag in ("sq1", "sq2", "sq3", "tcp", "hbm"):
+for tag in ("sq1", "sq2", "sq3", "tcp", "hbm_fetch", "hbm_write"):
     p = os.path.join(src, tag + ".stdout")
     if os.path.isfile(p):
         for line in open(p):
