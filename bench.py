@@ -60,7 +60,7 @@ def relaunch_multi_rank(n):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and os.environ.get("GSHELL_BENCH_SAME_DEVICE") != "1":
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node -- refusing to run fewer ranks than asked")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -79,12 +79,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
-    torch.cuda.set_device(local_rank)
+    # GSHELL_BENCH_SAME_DEVICE=1: plumbing test of the multi-rank path on a ONE-GPU box -- every rank uses device 0 and the
+    # ranks talk over gloo (RCCL refuses two ranks on one device).  Never a performance number; the JSON line says so.
+    same_device = os.environ.get("GSHELL_BENCH_SAME_DEVICE") == "1"
+    dev_index = 0 if same_device else local_rank
+    if torch.cuda.device_count() <= dev_index:
+        raise SystemExit(f"bench.py: rank {rank} has no device {dev_index} ({torch.cuda.device_count()} visible)")
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if same_device:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         world = dist.get_world_size()             # what RCCL actually sees
     from gshell_amd import _lib, workload
     from gshell_amd.train import ViewShard
@@ -156,7 +163,11 @@ def main():
         }
         if early is not None:
             out["early_schedule"] = early
-        roof = roofline(op_times, N, Ftets, V_aug, T, B_local, H, W, a.n_samples)
+        if same_device and world > 1:
+            out["data"] = "synthetic; PLUMBING TEST: all ranks share one device over gloo (GSHELL_BENCH_SAME_DEVICE=1) -- not a performance number"
+        # rows THIS rank pushes through the SDF-network kernel (the grid rows are sharded over the ranks of a multi-GPU job)
+        N_mlp = -(-N // world) if (world > 1 and getattr(trainer.FLAGS, 'shard_mlp_rows', False)) else N
+        roof = roofline(op_times, N_mlp, Ftets, V_aug, T, B_local, H, W, a.n_samples)
         if roof:
             out["roofline"] = roof
         out["hbm_kernels"] = hbm_kernels(op_times, N, Ftets, V_aug, T, B_local, H, W)
@@ -240,7 +251,7 @@ def roofline(op_times, N, Ftets, V_aug, T, B, H, W, n):
         executed = 2.0 * 256 * (48 + 5 * 256 + 304) * 3 * N
         tf = flops / (rec["ms"] * 1e-3) / 1e12
         return {"kernel": "k_h2_fwd<GRID> (gs_sdf_mlp_fwd_h2)", "bound": "mfma", "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": round(tf / 2500.0, 4), "traffic": pmc_traffic("k_h2_fwd") if N == 2282489 else None, "avg_launch_ms": round(rec["ms"], 4),
+                "frac": round(tf / 2500.0, 4), "traffic": pmc_traffic("k_h2_fwd") if N == 2282489 else None, "rows_per_launch": int(N), "avg_launch_ms": round(rec["ms"], 4),
                 "algorithmic_flops": flops, "executed_mfma_flops": executed, "executed_TFLOPs": round(executed / (rec["ms"] * 1e-3) / 1e12, 1),
                 "executed_frac_of_f16_peak": round(executed / (rec["ms"] * 1e-3) / 1e12 / 2500.0, 4), "vs_fp32_mfma_peak_157.3": round(tf / 157.3, 3),
                 "note": "v_mfma_f32_32x32x16_f16, operands = fp16 pairs (2^-22), fp32 accumulate; three products per algorithmic product; "

@@ -35,10 +35,12 @@ class NoiseStream:
 
     def __init__(self, seed=0, rank=0, world=1):
         self.seed, self.rank, self.world, self.it = int(seed), int(rank), int(world), 0
+        self.global_batch = None          # views of the global batch (None: local views x world)
         self._gens = {}
 
-    def set_iteration(self, it):
+    def set_iteration(self, it, global_batch=None):
         self.it = int(it)
+        self.global_batch = None if global_batch is None else int(global_batch)
 
     def generator(self, name, device):
         g = self._gens.get(str(device))
@@ -48,10 +50,13 @@ class NoiseStream:
         return g
 
     def normal(self, name, std, size, device):
-        """[B_local, ...] rows of the [B_local * world, ...] global-batch draw."""
-        full = torch.randn((size[0] * self.world,) + tuple(size[1:]), device=device, generator=self.generator(name, device))
+        """[B_local, ...] = this rank's rows (views rank, rank + world, ...) of the [B_global, ...] global-batch draw."""
+        B = self.global_batch if self.global_batch is not None else size[0] * self.world
+        full = torch.randn((B,) + tuple(size[1:]), device=device, generator=self.generator(name, device))
         if self.world > 1:
             full = full[self.rank::self.world]
+        if full.shape[0] != size[0]:
+            raise ValueError(f"NoiseStream: {size[0]} local views do not match views {self.rank}::{self.world} of a global batch of {B}")
         return (full * std).contiguous() if std != 1.0 else full.contiguous()
 
     def state_dict(self):

@@ -203,7 +203,7 @@ class Trainer:
         for o in (self.opt_mat, self.opt_mesh, self.opt_light):
             o.zero_grad()
         self.lgt.update_pdf()
-        self.FLAGS.noise_stream.set_iteration(self.it)
+        self.FLAGS.noise_stream.set_iteration(self.it, global_batch if self.shard.world > 1 else None)
         img_loss, depth_loss, reg_loss = self.geometry.tick(self.glctx, target, self.lgt, self.mat, self.loss_fn, self.it, denoiser=self.denoiser)
         if self.shard.world > 1:
             B_local = target['mvp'].shape[0]
