@@ -126,6 +126,9 @@ __device__ __forceinline__ float slope_from_value(float a) {
 #ifndef GS_H2_BPF
 #define GS_H2_BPF 0     // 1: double-buffer the LDS (activation) fragments as well
 #endif
+#ifndef GS_H2_ORDER
+#define GS_H2_ORDER 0   // 1: pin the MFMA order so that MFMAs on one accumulator are three issue slots apart
+#endif
 #ifndef GS_H2_PRIO
 #define GS_H2_PRIO 0    // 1: raise the wave priority around the MFMA cluster
 #endif
@@ -156,10 +159,12 @@ __device__ __forceinline__ void gemm_seg(v16f (&hi)[2], v16f (&lo)[2], const _Fl
 #endif
 #pragma unroll
     for (int st = 0; st < NSTEPS; ++st) {
+#ifndef GS_H2_NOW          // timing experiment: GS_H2_NOW keeps re-using the first weight fragments (wrong results)
         if (st + PD < NSTEPS) {
             a1[(st + PD) % (PD + 1)] = wp[(st + PD) * sstride];
             a2[(st + PD) % (PD + 1)] = wp[(st + PD) * sstride + 64];
         }
+#endif
 #if GS_H2_BPF
         const h8 b10 = c10, b11 = c11, b20 = c20, b21 = c21;
         if (st + 1 < NSTEPS) {
@@ -169,22 +174,46 @@ __device__ __forceinline__ void gemm_seg(v16f (&hi)[2], v16f (&lo)[2], const _Fl
             c21 = *reinterpret_cast<const h8*>(b2p + 32 * STRIDE + (st + 1) * 16);
         }
 #else
-        const h8 b10 = *reinterpret_cast<const h8*>(b1p + st * 16);
-        const h8 b11 = *reinterpret_cast<const h8*>(b1p + 32 * STRIDE + st * 16);
-        const h8 b20 = *reinterpret_cast<const h8*>(b2p + st * 16);
-        const h8 b21 = *reinterpret_cast<const h8*>(b2p + 32 * STRIDE + st * 16);
+#ifdef GS_H2_NOLDS        // timing experiment: re-use the first activation fragments (wrong results)
+        const int so = 0;
+#else
+        const int so = st * 16;
 #endif
+        const h8 b10 = *reinterpret_cast<const h8*>(b1p + so);
+        const h8 b11 = *reinterpret_cast<const h8*>(b1p + 32 * STRIDE + so);
+        const h8 b20 = *reinterpret_cast<const h8*>(b2p + so);
+        const h8 b21 = *reinterpret_cast<const h8*>(b2p + 32 * STRIDE + so);
+#endif
+#ifdef GS_H2_NOW
+        const h8 w1 = a1[0], w2 = a2[0];
+#else
         const h8 w1 = a1[st % (PD + 1)], w2 = a2[st % (PD + 1)];
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #if GS_H2_PRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
+#if GS_H2_ORDER
+        // same-accumulator MFMAs three issue slots apart in every step and across steps (lo0 . lo1 . hi0 . lo0 . lo1 . hi1)
+        lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b20, lo[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b21, lo[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        hi[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b10, hi[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, b10, lo[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, b11, lo[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        hi[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b11, hi[1], 0, 0, 0);
+#else
         hi[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b10, hi[0], 0, 0, 0);
         hi[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b11, hi[1], 0, 0, 0);
         lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b20, lo[0], 0, 0, 0);
         lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b21, lo[1], 0, 0, 0);
         lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, b10, lo[0], 0, 0, 0);
         lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, b11, lo[1], 0, 0, 0);
+#endif
 #if GS_H2_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -219,15 +248,21 @@ __device__ __forceinline__ bool tile_point(const H2Args& A, int64_t tile, int ro
 
 static_assert(EK == 48, "the encoding stage lays out 39 + 9 columns");
 
-template <int MODE>
-__global__ void __launch_bounds__(NT, 4) k_h2_fwd(H2Args A) {
+// DUAL: one 1024-thread workgroup carries TWO 64-row tiles (waves 0-7 and 8-15, all 160 KB of LDS) through the layers ONE
+// BARRIER STEP APART: while one half runs the k-loop of layer l (matrix pipe) the other runs the epilogue of its layer l - 1 /
+// l (VALU), then they swap -- the two halves share every s_barrier, so the anti-phase is deterministic.  Two independent
+// 512-thread workgroups per CU (DUAL = false) run the same code but settle IN phase (both in the k-loop, then both in the
+// epilogue): matrix pipe 49 % busy; starting the second one late changes nothing (measured, GS_H2_STAGGER experiment).
+template <int MODE, bool DUAL>
+__global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
-    _Float16* H1 = smem_h;                   // [TM][LDH]
+    const int half = DUAL ? (int)(threadIdx.x >> 9) : 0;
+    _Float16* H1 = smem_h + half * (2 * TM * LDH + 2 * TM * LDEH);   // [TM][LDH]
     _Float16* H2 = H1 + TM * LDH;            // [TM][LDH]
     _Float16* E1 = H2 + TM * LDH;            // [TM][LDEH]
     _Float16* E2 = E1 + TM * LDEH;           // [TM][LDEH]   (the output reduction scratch is overlaid on E1/E2 at the end)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t tile = blockIdx.x, r0 = tile * TM;
+    const int tid = threadIdx.x & (NT - 1), lane = tid & 63, wave = tid >> 6;
+    const int64_t tile = DUAL ? 2 * (int64_t)blockIdx.x + half : (int64_t)blockIdx.x, r0 = tile * TM;
 
     // encoding of the tile, zero padded to EK columns, zero rows past the end.  24 work items per row: 18 (frequency, axis)
     // pairs -- ONE sincosf serves the sin and the cos column (and, on tangent rows, both derivatives) --, the 3 coordinates,
@@ -264,6 +299,7 @@ __global__ void __launch_bounds__(NT, 4) k_h2_fwd(H2Args A) {
         }
     }
     __syncthreads();
+    if (DUAL && half == 1) __syncthreads();              // the second tile runs one barrier step behind the first
 
     const int n_base = wave * 32 + 4 * (lane >> 5);      // + 8 g + j  (g = reg >> 2, j = reg & 3)
     const int m_lane = lane & 31;                        // + 32 s
@@ -277,26 +313,37 @@ __global__ void __launch_bounds__(NT, 4) k_h2_fwd(H2Args A) {
             gemm_seg<LDH, D / 16>(hi, lo, H1, H2, A.wfrag[l], wave, 8, lane);
             if (l == A.skip_layer) gemm_seg<LDEH, EK / 16>(hi, lo, E1, E2, A.wfrag[l] + (D / 16) * 1024, wave, 8, lane);
         }
-        __syncthreads();     // every wave is done reading the planes: they are overwritten in place
+        // bias (and output weights) of this lane's 16 features: requested BEFORE the barrier, so that the L2 round trip is
+        // covered by the wait for the slowest wave instead of stalling the epilogue four times per layer (measured: 5.8 -> ? ms)
         const float* bl = A.bias[l] + n_base;
         const bool last = l + 1 == A.n_layers;
+        float4 b4v[4], w4v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            b4v[g] = *reinterpret_cast<const float4*>(bl + 8 * g);
+            w4v[g] = last ? *reinterpret_cast<const float4*>(A.w_out + n_base + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#ifndef GS_H2_NOBAR      // timing experiment: no barriers inside the layer loop (wrong results)
+        __syncthreads();     // every wave is done reading the planes: they are overwritten in place
+#endif
         f2 part[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 b4 = *reinterpret_cast<const float4*>(bl + 8 * g);
+            const float4 b4 = b4v[g];
             const f2 bj[2] = {f2{b4.x, b4.y}, f2{b4.z, b4.w}};
-            f2 wj[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
-            if (last) {
-                const float4 w4 = *reinterpret_cast<const float4*>(A.w_out + n_base + 8 * g);
-                wj[0] = f2{w4.x, w4.y};
-                wj[1] = f2{w4.z, w4.w};
-            }
+            const f2 wj[2] = {f2{w4v[g].x, w4v[g].y}, f2{w4v[g].z, w4v[g].w}};
             f2 v[2][2];          // [row half s][pair]
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int r = 4 * g + 2 * q;
                 const f2 z0 = f2{hi[0][r], hi[0][r + 1]} + f2{lo[0][r], lo[0][r + 1]} * LO_INV;
                 const f2 z1 = f2{hi[1][r], hi[1][r + 1]} + f2{lo[1][r], lo[1][r + 1]} * LO_INV;
+#ifdef GS_H2_NOEPI       // timing experiment only: no softplus (wrong results)
+                if (true) {
+                    v[0][q] = z0 + bj[q];
+                    v[1][q] = z1 + bj[q];
+                } else
+#endif
                 if (MODE != MODE_EIK) {
                     v[0][q] = softplus100_pair(z0 + bj[q]);
                     v[1][q] = softplus100_pair(z1 + bj[q]);
@@ -339,8 +386,13 @@ __global__ void __launch_bounds__(NT, 4) k_h2_fwd(H2Args A) {
                 if (lane < 32) red[wave * TM + 32 * s + lane] = p;
             }
         }
+#ifndef GS_H2_NOBAR
         __syncthreads();
+#else
+        if (last) __syncthreads();
+#endif
     }
+    if (DUAL && half == 0) __syncthreads();              // same number of barriers in both halves
     if (MODE != MODE_ROWS && tid < TM) {
         const float* red = reinterpret_cast<const float*>(E1);
         float s = 0.f;
@@ -352,7 +404,7 @@ __global__ void __launch_bounds__(NT, 4) k_h2_fwd(H2Args A) {
             if (r < A.N) A.out[r] = s;
             // fused geometry front end: the tile is one 64-bit word of the extraction's occupancy bits (strict > 0, ref gshell_tets.py:250)
             const uint64_t m = __ballot(r < A.N && s > 0.0f);
-            if (A.occ && tid == 0) A.occ[tile] = m;
+            if (A.occ && tid == 0 && r0 < A.N) A.occ[tile] = m;
         } else {
             A.out[r] = s;                                    // virtual rows: value rows lack b_out (unused), tangent rows = df/dx_d
         }
@@ -946,11 +998,20 @@ void fill_fwd_args(H2Args& A, const void* packed, const PackLayout& L) {
     A.w_out = tail + (int64_t)L.n_layers * D;
 }
 
+#ifndef GS_H2_DUAL
+#define GS_H2_DUAL 0    // 1: two tiles per 1024-thread workgroup, deterministically anti-phased (measured: same time)
+#endif
+
 template <int MODE>
 int launch_fwd(const H2Args& A, int64_t tiles, hipStream_t stream) {
     // per launch (cheap, and correct per device / per thread, unlike a process-wide "done" flag)
-    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_fwd<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES));
-    hipLaunchKernelGGL(k_h2_fwd<MODE>, dim3((unsigned)tiles), dim3(NT), SMEM_BYTES, stream, A);
+    if (GS_H2_DUAL) {
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_fwd<MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * SMEM_BYTES)));
+        hipLaunchKernelGGL((k_h2_fwd<MODE, true>), dim3((unsigned)gs::cdiv(tiles, 2)), dim3(2 * NT), 2 * SMEM_BYTES, stream, A);
+    } else {
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_fwd<MODE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES));
+        hipLaunchKernelGGL((k_h2_fwd<MODE, false>), dim3((unsigned)tiles), dim3(NT), SMEM_BYTES, stream, A);
+    }
     GS_LAUNCH_CHECK();
     return 0;
 }
@@ -994,8 +1055,8 @@ extern "C" int gs_sdf_mlp_fwd_h2(const float* x, int64_t N, const void* packed, 
     return launch_fwd<MODE_GRID>(A, gs::cdiv(N, TM), (hipStream_t)stream);
 }
 
-extern "C" int64_t gs_sdf_mlp_h2_rows_padded(int mode, int64_t n) {      // virtual rows of the saved planes (multiple of 64)
-    return mode == MODE_EIK ? gs::cdiv(n, 16) * TM : gs::cdiv(n, TM) * TM;
+extern "C" int64_t gs_sdf_mlp_h2_rows_padded(int mode, int64_t n) {      // virtual rows of the saved planes: whole PAIRS of 64-row tiles
+    return mode == MODE_EIK ? gs::cdiv(n, 32) * 2 * TM : gs::cdiv(n, 2 * TM) * 2 * TM;
 }
 
 // mode 1 (ROWS): recompute rows `rows[0..n)` of x;  mode 2 (EIK): value + 3 tangent rows of the n sample points x [n,3].
