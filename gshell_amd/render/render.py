@@ -326,10 +326,34 @@ def render_layer(FLAGS, v_pos_clip, rast, rast_deriv, mesh, view_pos, lgt, resol
     return buffers
 
 
+class _LazyVisible:
+    """`visible_triangles` of the reference (render.py:380-383: sorted unique triangle ids of the frame) costs a device ->
+    host round trip for its SIZE; the training loop only needs the per-triangle flags, so the index list is materialised on
+    first access."""
+
+    def __init__(self, flags):
+        self.flags = flags
+
+    def resolve(self):
+        return torch.nonzero(self.flags).reshape(-1)          # sorted ids == rast[...,-1].long().unique() - 1
+
+
 class FrameBuffers(dict):
     """The reference's dict of output buffers (render.py:436-444) + `.stacked` = (tensor [B,H,W,sum C], names, channel counts):
-    all buffers are channel slices of that one antialiased tensor, which lets the loss read the frame in a single pass."""
+    all buffers are channel slices of that one antialiased tensor, which lets the loss read the frame in a single pass;
+    `.visible_flags` [T] uint8 = the rasteriser's per-triangle visibility flags (what `visible_triangles` is the nonzero of)."""
     stacked = None
+    visible_flags = None
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if isinstance(v, _LazyVisible):
+            v = v.resolve()
+            dict.__setitem__(self, key, v)
+        return v
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
 
 
 _layout_cache = {}
@@ -373,7 +397,6 @@ def render_mesh(FLAGS, ctx, mesh, mtx_in, view_pos, lgt, resolution, spp=1, num_
 
     v_pos_clip = ru.xfm_points(mesh.v_pos[None, ...], mtx_in)
     rast, db, vis = dr.rasterize(ctx, v_pos_clip, tri, full_res, return_visible=True)
-    visible_triangles = torch.nonzero(vis).reshape(-1)          # sorted ids == rast[...,-1].long().unique() - 1
 
     buffers = render_layer(FLAGS, v_pos_clip, rast, db, mesh, view_pos, lgt, resolution, spp, msaa, optix_ctx, bsdf, denoiser, shadow_scale,
                            use_uv=use_uv, finetune_normal=finetune_normal, extra_dict=extra_dict, xfm_lgt=xfm_lgt, shade_data=shade_data, _defer=True)
@@ -419,7 +442,8 @@ def render_mesh(FLAGS, ctx, mesh, mtx_in, view_pos, lgt, resolution, spp=1, num_
     else:
         aa, sizes, out_list = None, [], []
 
-    out_buffers = FrameBuffers({'visible_triangles': visible_triangles})
+    out_buffers = FrameBuffers({'visible_triangles': _LazyVisible(vis)})
+    out_buffers.visible_flags = vis
     if aa is not None and spp == 1:
         out_buffers.stacked = (aa, keys, sizes)              # every buffer below is a channel slice of this tensor
     for key, accum in zip(keys, out_list):

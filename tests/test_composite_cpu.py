@@ -37,3 +37,28 @@ def test_stacked_composite_equals_per_buffer_loop():
         assert torch.allclose(x, y, rtol=0, atol=1e-6)
     # the 1-channel buffer is its own alpha: composite = cover * value (lerp(0, 1, cover * v))
     assert torch.equal(comp[..., 8:9], cover * bufs['msdf_image'])
+
+
+def test_visible_boundary_weight_equals_the_reference_mask():
+    """mSDF 'close' regulariser (reference gshell_tets_geometry.py:344-353): the sync-free scatter-max weight must select exactly
+    the boundary vertices the reference's unique -> gather -> boolean-mask chain selects, and the weighted Huber sum must equal
+    the Huber sum over the compacted values."""
+    import torch.nn.functional as F
+    from gshell_amd.geometry.gshell_tets_geometry import visible_boundary_weight
+    g = torch.Generator().manual_seed(0)
+    nwt, nb, T = 40, 90, 200
+    tri = torch.randint(0, nwt + nb, (T, 3), generator=g)
+    flags = (torch.rand(T, generator=g) < 0.3).to(torch.uint8)
+    msdf_boundary = torch.randn(nb, generator=g) * 0.01
+    w = visible_boundary_weight(tri, flags, nwt, nb)
+    vis_tris = torch.nonzero(flags).reshape(-1)
+    vis_verts = tri[vis_tris].reshape(-1)
+    mask = torch.zeros(nb, dtype=torch.bool)
+    mask[vis_verts[vis_verts >= nwt] - nwt] = True
+    assert torch.equal(w > 0, mask) and set(w.unique().tolist()) <= {0.0, 1.0}
+    eps = torch.full((1,), 1e-3)
+    bm = msdf_boundary[mask]
+    ref = F.huber_loss(bm.clamp(max=eps), eps.expand(bm.size(0)), reduction='sum')
+    new = (F.huber_loss(msdf_boundary.clamp(max=eps), eps.expand(nb), reduction='none') * w).sum()
+    assert torch.allclose(ref, new, rtol=1e-6, atol=1e-12)
+    assert float(visible_boundary_weight(tri, torch.zeros(T, dtype=torch.uint8), nwt, nb).sum()) == 0.0
