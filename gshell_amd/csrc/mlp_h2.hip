@@ -67,7 +67,8 @@ struct H2Args {
     float* out;           // MODE_GRID: [N] sdf;  MODE_EIK: [tiles*64] per virtual row (value rows: f - b_out; tangent rows: df/dx_d)
     float* A;             // saved activations [n_layers][Rpad][256] fp32 (value rows a_l, tangent rows a'_l)   (ROWS / EIK)
     float* EMB;           // saved encoding [Rpad][EK] fp32 (tangent rows: d enc / dx_d)                            (ROWS / EIK)
-    int64_t N;            // GRID: rows; ROWS: active rows R; EIK: samples
+    int64_t N;            // GRID: rows; ROWS: active rows R (capacity when n_dev is given); EIK: samples
+    const int64_t* n_dev; // ROWS: optional DEVICE-resident row count (<= N): tiles past it exit; lets the caller size by a bound, no host sync
     int64_t Rpad;         // tiles * 64
     int n_freq, E;
     int n_layers;         // hidden-producing layers (first + n_hidden)
@@ -230,16 +231,16 @@ __device__ __forceinline__ void zero_acc(v16f (&hi)[2], v16f (&lo)[2]) {
 
 // Point of tile row `row` (and, for EIK, which virtual row it is: c = 0 value, 1..3 tangent d = c - 1).
 template <int MODE>
-__device__ __forceinline__ bool tile_point(const H2Args& A, int64_t tile, int row, float (&p)[3], int& c) {
+__device__ __forceinline__ bool tile_point(const H2Args& A, int64_t n_act, int64_t tile, int row, float (&p)[3], int& c) {
     int64_t src;
     c = 0;
     if (MODE == MODE_EIK) {
         src = tile * 16 + (row & 15);
         c = row >> 4;
-        if (src >= A.N) return false;
+        if (src >= n_act) return false;
     } else {
         src = tile * TM + row;
-        if (src >= A.N) return false;
+        if (src >= n_act) return false;
         if (MODE == MODE_ROWS) src = A.rows[src];
     }
     p[0] = A.x[3 * src]; p[1] = A.x[3 * src + 1]; p[2] = A.x[3 * src + 2];
@@ -263,6 +264,8 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
     _Float16* E2 = E1 + TM * LDEH;           // [TM][LDEH]   (the output reduction scratch is overlaid on E1/E2 at the end)
     const int tid = threadIdx.x & (NT - 1), lane = tid & 63, wave = tid >> 6;
     const int64_t tile = DUAL ? 2 * (int64_t)blockIdx.x + half : (int64_t)blockIdx.x, r0 = tile * TM;
+    const int64_t n_act = (MODE == MODE_ROWS && A.n_dev) ? min(*A.n_dev, A.N) : A.N;
+    if (MODE == MODE_ROWS && (DUAL ? 2 * (int64_t)blockIdx.x : tile) * TM >= n_act) return;      // whole workgroup past the device-side count
 
     // encoding of the tile, zero padded to EK columns, zero rows past the end.  24 work items per row: 18 (frequency, axis)
     // pairs -- ONE sincosf serves the sin and the cos column (and, on tangent rows, both derivatives) --, the 3 coordinates,
@@ -278,7 +281,7 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
         const int row = idx / 24, slot = idx - row * 24;
         float p[3] = {0.f, 0.f, 0.f};
         int c = 0;
-        const bool valid = tile_point<MODE>(A, tile, row, p, c);
+        const bool valid = tile_point<MODE>(A, n_act, tile, row, p, c);
         if (slot < 18) {
             const int k = slot / 3, ax = slot - 3 * k;
             float vs = 0.f, vc = 0.f;
@@ -426,6 +429,7 @@ struct BwdArgs {
     const int32_t* rows;  // ROWS: [R]
     float* g_x;           // ROWS: [N,3] scatter target (rows are unique), or null
     int64_t R, Rpad;
+    const int64_t* n_dev; // optional device-resident row count (<= R), see H2Args
     int E, n_layers, skip_layer;
     const h8* wfragT[MAX_LAYERS];   // [n-step 16][block nbT(l)][piece 2][lane 64]
     int nblkT[MAX_LAYERS];
@@ -448,6 +452,8 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
     float* SC = GE + TM * LDG;                                 // [TM] 1 / row scale
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * TM;
+    const int64_t n_act = B.n_dev ? min(*B.n_dev, B.R) : B.R;
+    if (MODE == MODE_ROWS && r0 >= n_act) return;
     const int n_base = wave * 32 + 4 * (lane >> 5);
     const int m_lane = lane & 31;
     const bool low16 = (lane & 16) == 0;
@@ -561,7 +567,7 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
         if (tid < TM * 3) {
             const int row = tid / 3, c = tid - 3 * row;
             const int64_t r = r0 + row;
-            if (r < B.R) {
+            if (r < n_act) {
                 const float* ge = GE + row * LDG;
                 const float* em = B.EMB + r * EK;
                 float acc = ge[c];
@@ -590,13 +596,20 @@ struct WgradArgs {
     const float* EMB;     // [Rpad][EK]
     const float* D;       // [n_layers][Rpad][256]
     const float* g_out;   // [Rpad]
-    int64_t Rpad;
+    int64_t Rpad, n;      // rows of the planes; rows in use (ROWS: the count or its capacity; EIK: all of Rpad)
+    const int64_t* n_dev; // optional device-resident row count: only the tiles below it are reduced
     int E, n_layers, skip_layer, mode;
     int slabs_per_strip;  // 32-row slabs per workgroup
     int only_output;      // 1: k_h2_wgrad handles the output layer only (the hidden layers run in k_h2_wgrad16)
     float* dW[MAX_LAYERS + 1];     // torch layout [256][K_l]; [n_layers] = output layer [1][256]
     float* db[MAX_LAYERS + 1];     // [256]; the output layer's bias gradient is the caller's
 };
+
+__device__ __forceinline__ int64_t wgrad_rows(const WgradArgs& W) {      // rows to reduce: whole 64-row tiles below the (device-side) count
+    // the chain kernels skip tiles that lie entirely past the row count, so those plane rows are never written
+    const int64_t n = W.n_dev ? min(*W.n_dev, W.n) : W.n;
+    return min((n + TM - 1) / TM * TM, W.Rpad);
+}
 
 constexpr int WS = 32;                       // rows per slab
 constexpr int WG_D = WS * D;                 // floats of the D / X_h slab
@@ -606,9 +619,9 @@ constexpr int WG_BUF = 2 * WG_D + WG_E;      // one LDS buffer (floats)
 template <int NB, bool HAS_H, bool HAS_E>
 __device__ __forceinline__ void wgrad_layer(const WgradArgs& W, int l, float* smem, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
-    const int64_t slab0 = (int64_t)blockIdx.x * W.slabs_per_strip;
-    const int64_t nslabs_total = W.Rpad / WS;
-    const int64_t nslab = min((int64_t)W.slabs_per_strip, nslabs_total - slab0);
+    // slabs are dealt round-robin to the strips (workgroups): any prefix of valid slabs (device-side row count) stays balanced
+    const int64_t nslabs_total = wgrad_rows(W) / WS, stride = gridDim.x, slab0 = blockIdx.x;
+    const int64_t nslab = slab0 < nslabs_total ? (nslabs_total - slab0 + stride - 1) / stride : 0;
     if (nslab <= 0) return;
     const float* Dl = W.D + (int64_t)l * W.Rpad * D;
     const float* Xh = HAS_H ? W.A + (int64_t)(l - 1) * W.Rpad * D : nullptr;
@@ -650,7 +663,7 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs& W, int l, float* sm
     for (int64_t s = 0; s < nslab; ++s) {
         float* cur = smem + (s & 1) * WG_BUF;
         const bool more = s + 1 < nslab;
-        if (more) load_slab(slab0 + s + 1);
+        if (more) load_slab(slab0 + (s + 1) * stride);
         const float* ap = cur + (lane >> 5) * D + wave * 32 + (lane & 31);            // D[row = 2 ks + (lane >> 5)][n]
         const float* xp = cur + WG_D + (lane >> 5) * D + (lane & 31);
         const float* ep = cur + 2 * WG_D + (lane >> 5) * 64 + (lane & 31);
@@ -667,7 +680,7 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs& W, int l, float* sm
                     acc[(HAS_H ? 8 : 0) + b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ep[ks * 2 * 64 + 32 * b], acc[(HAS_H ? 8 : 0) + b], 0, 0, 0);
             }
         }
-        if (more) store_slab(smem + ((s + 1) & 1) * WG_BUF, slab0 + s + 1);
+        if (more) store_slab(smem + ((s + 1) & 1) * WG_BUF, slab0 + (s + 1) * stride);
         __syncthreads();
     }
     // flush: acc[b][reg] = dW[n = 32 wave + (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)][k = 32 b + (lane & 31)]
@@ -729,8 +742,8 @@ __device__ __forceinline__ void split_bf16_4(const float (&v)[4], bf4& hi, bf4& 
 template <int NB, bool HAS_H, bool HAS_E>
 __device__ __forceinline__ void wgrad16_layer(const WgradArgs& W, int l, __bf16* img, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
-    const int64_t slab0 = (int64_t)blockIdx.x * W.slabs_per_strip;
-    const int64_t nslab = min((int64_t)W.slabs_per_strip, W.Rpad / WS - slab0);
+    const int64_t nslabs_total = wgrad_rows(W) / WS, stride = gridDim.x, slab0 = blockIdx.x;      // round-robin slabs, as wgrad_layer
+    const int64_t nslab = slab0 < nslabs_total ? (nslabs_total - slab0 + stride - 1) / stride : 0;
     if (nslab <= 0) return;
     const float* Dl = W.D + (int64_t)l * W.Rpad * D;
     const float* Xh = HAS_H ? W.A + (int64_t)(l - 1) * W.Rpad * D : nullptr;
@@ -786,9 +799,9 @@ __device__ __forceinline__ void wgrad16_layer(const WgradArgs& W, int l, __bf16*
     };
     load_slab(slab0);
     for (int64_t s = 0; s < nslab; ++s) {
-        store_slab(slab0 + s);
+        store_slab(slab0 + s * stride);
         __syncthreads();
-        if (s + 1 < nslab) load_slab(slab0 + s + 1);        // in flight during the MFMAs below
+        if (s + 1 < nslab) load_slab(slab0 + (s + 1) * stride);        // in flight during the MFMAs below
         const int roff = 8 * (lane >> 5);
         const __bf16* ah = hi_img + (wave * 32 + (lane & 31)) * WB_RS + roff;
         const __bf16* al = lo_img + (wave * 32 + (lane & 31)) * WB_RS + roff;
@@ -849,10 +862,10 @@ __global__ void __launch_bounds__(NT, 2) k_h2_wgrad(WgradArgs W) {
     const int l = W.only_output ? W.n_layers : blockIdx.y, tid = threadIdx.x;
     if (l == W.n_layers) {
         // output layer: dw_out[n] = sum_rows g_out[row] a_{L-1}[row][n]  (tangent rows included: their g_out is dL/d(df/dx_d))
-        const int64_t slab0 = (int64_t)blockIdx.x * W.slabs_per_strip, nslabs_total = W.Rpad / WS;
+        const int64_t nslabs_total = wgrad_rows(W) / WS;
         const float* X = W.A + (int64_t)(W.n_layers - 1) * W.Rpad * D;
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t s = slab0; s < min(slab0 + W.slabs_per_strip, nslabs_total); ++s)
+        for (int64_t s = blockIdx.x; s < nslabs_total; s += gridDim.x)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t row = s * WS + (tid >> 6) + 8 * i;
@@ -876,6 +889,51 @@ __global__ void __launch_bounds__(NT, 2) k_h2_wgrad(WgradArgs W) {
     if (l == 0) wgrad_layer<2, false, true>(W, l, smem_f, tid);
     else if (l == W.skip_layer) wgrad_layer<10, true, true>(W, l, smem_f, tid);
     else wgrad_layer<8, true, false>(W, l, smem_f, tid);
+}
+
+
+// ---- device-side compaction of the rows that carry gradient ------------------------------------------------------------
+// rows[] = ascending indices i with g[i] != 0, g_rows[] = their values, count on the DEVICE: the chain kernels read it, so the
+// caller can size the planes by a bound (2 x crossing edges) instead of waiting for the exact count (a host sync costs
+// ~1.5 ms of launch-ahead per iteration).  count[1] is set when the bound was too small (checked by the caller off the hot path).
+constexpr int CZ_TILE = 1024;
+__global__ void __launch_bounds__(256) k_cnz_count(const float* __restrict__ g, int64_t N, int32_t* __restrict__ partial) {
+    __shared__ int lds[4];
+    const int64_t base = (int64_t)blockIdx.x * CZ_TILE + threadIdx.x * 4;
+    int c = 0;
+    for (int j = 0; j < 4; ++j) c += (base + j < N && g[base + j] != 0.0f) ? 1 : 0;
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+__global__ void __launch_bounds__(64) k_cnz_scan(int32_t* __restrict__ partial, int64_t nb, int64_t cap, int64_t* __restrict__ count) {
+    if (threadIdx.x == 0) {
+        int64_t run = 0;
+        for (int64_t b = 0; b < nb; ++b) { const int32_t v = partial[b]; partial[b] = (int32_t)min(run, (int64_t)0x7fffffff); run += v; }
+        count[0] = min(run, cap);
+        count[1] = run > cap ? 1 : 0;
+    }
+}
+__global__ void __launch_bounds__(256) k_cnz_write(const float* __restrict__ g, int64_t N, const int32_t* __restrict__ partial, int64_t cap,
+                                                   int32_t* __restrict__ rows, float* __restrict__ g_rows) {
+    __shared__ int lds[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * CZ_TILE + threadIdx.x * 4;
+    float v[4];
+    int c = 0;
+    for (int j = 0; j < 4; ++j) { v[j] = base + j < N ? g[base + j] : 0.0f; c += v[j] != 0.0f; }
+    int inc = c;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    int64_t pos = partial[blockIdx.x] + inc - c;
+    for (int w = 0; w < wave; ++w) pos += lds[w];
+    for (int j = 0; j < 4; ++j)
+        if (v[j] != 0.0f) {
+            if (pos < cap) { rows[pos] = (int32_t)(base + j); g_rows[pos] = v[j]; }
+            ++pos;
+        }
 }
 
 constexpr size_t SMEM_BYTES = (size_t)(2 * TM * LDH + 2 * TM * LDEH) * sizeof(_Float16);
@@ -1062,14 +1120,31 @@ extern "C" int64_t gs_sdf_mlp_h2_rows_padded(int mode, int64_t n) {      // virt
 // mode 1 (ROWS): recompute rows `rows[0..n)` of x;  mode 2 (EIK): value + 3 tangent rows of the n sample points x [n,3].
 // A [n_hidden+1][Rpad][256], EMB [Rpad][48] WRITTEN (Rpad = gs_sdf_mlp_h2_rows_padded);  out [Rpad] WRITTEN in mode 2
 // (tile-major virtual rows: entry 64 t + 16 c + i belongs to sample 16 t + i; c = 0: f - b_out, c = 1..3: df/dx_{c-1}).
-extern "C" int gs_sdf_mlp_h2_save_fwd(int mode, const float* x, const int32_t* rows, int64_t n, const void* packed, int n_freq, int n_hidden,
-                                      int skip_layer, float* A_save, float* EMB_save, float* out, gs_stream_t stream) {
+extern "C" int64_t gs_compact_rows_scratch_bytes(int64_t N) { return gs::cdiv(N, CZ_TILE) * (int64_t)sizeof(int32_t) + 16; }
+
+// rows [cap] i32 = ascending indices with g[i] != 0, g_rows [>= cap] f32 = those values (the caller zero-fills the tail),
+// count_dev [2] i64 = (min(count, cap), count > cap) -- all on the device, no synchronisation.
+extern "C" int gs_compact_rows(const float* g, int64_t N, int64_t cap, void* scratch, int32_t* rows, float* g_rows, int64_t* count_dev,
+                               gs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GS_REQUIRE(g && scratch && rows && g_rows && count_dev && cap >= 0, "gs_compact_rows: null pointer");
+    const int64_t nb = gs::cdiv(N, CZ_TILE);
+    if (nb == 0) { GS_HIP_CHECK(hipMemsetAsync(count_dev, 0, 16, stream)); return 0; }
+    hipLaunchKernelGGL(k_cnz_count, dim3((unsigned)nb), dim3(256), 0, stream, g, N, (int32_t*)scratch);
+    hipLaunchKernelGGL(k_cnz_scan, dim3(1), dim3(64), 0, stream, (int32_t*)scratch, nb, cap, count_dev);
+    hipLaunchKernelGGL(k_cnz_write, dim3((unsigned)nb), dim3(256), 0, stream, g, N, (const int32_t*)scratch, cap, rows, g_rows);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_sdf_mlp_h2_save_fwd(int mode, const float* x, const int32_t* rows, int64_t n, const int64_t* n_dev, const void* packed, int n_freq,
+                                      int n_hidden, int skip_layer, float* A_save, float* EMB_save, float* out, gs_stream_t stream) {
     if (n == 0) return 0;
     GS_REQUIRE(mode == MODE_ROWS || mode == MODE_EIK, "gs_sdf_mlp_h2_save_fwd: mode must be 1 (rows) or 2 (eikonal)");
     GS_REQUIRE(x && packed && A_save && EMB_save && (mode == MODE_EIK ? out != nullptr : rows != nullptr), "gs_sdf_mlp_h2_save_fwd: null pointer");
     if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
     H2Args A{};
-    A.x = x; A.rows = rows; A.out = out; A.N = n; A.n_freq = n_freq; A.A = A_save; A.EMB = EMB_save;
+    A.x = x; A.rows = rows; A.out = out; A.N = n; A.n_dev = mode == MODE_ROWS ? n_dev : nullptr; A.n_freq = n_freq; A.A = A_save; A.EMB = EMB_save;
     A.Rpad = gs_sdf_mlp_h2_rows_padded(mode, n);
     fill_fwd_args(A, packed, make_layout(n_freq, n_hidden, skip_layer));
     return mode == MODE_ROWS ? launch_fwd<MODE_ROWS>(A, A.Rpad / TM, (hipStream_t)stream) : launch_fwd<MODE_EIK>(A, A.Rpad / TM, (hipStream_t)stream);
@@ -1078,8 +1153,9 @@ extern "C" int gs_sdf_mlp_h2_save_fwd(int mode, const float* x, const int32_t* r
 // Backward chain over the saved planes: D [n_hidden+1][Rpad][256] WRITTEN (dL/d pre-activation of every layer, per virtual
 // row); mode 1 with g_x != NULL: g_x[rows[r]] (of [N,3]) WRITTEN for r < n (dL/dx through the encoding).  g_out [Rpad]:
 // upstream gradient per virtual row, 0 on padding rows.
-extern "C" int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* rows, int64_t n, const void* packed, int n_freq, int n_hidden,
-                                 int skip_layer, const float* A_save, const float* EMB_save, float* D_save, float* g_x, gs_stream_t stream) {
+extern "C" int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* rows, int64_t n, const int64_t* n_dev, const void* packed, int n_freq,
+                                 int n_hidden, int skip_layer, const float* A_save, const float* EMB_save, float* D_save, float* g_x,
+                                 gs_stream_t stream) {
     if (n == 0) return 0;
     GS_REQUIRE(mode == MODE_ROWS || mode == MODE_EIK, "gs_sdf_mlp_h2_bwd: mode must be 1 (rows) or 2 (eikonal)");
     GS_REQUIRE(g_out && packed && A_save && EMB_save && D_save && (mode == MODE_EIK || rows != nullptr), "gs_sdf_mlp_h2_bwd: null pointer");
@@ -1087,7 +1163,7 @@ extern "C" int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* ro
     PackLayout L = make_layout(n_freq, n_hidden, skip_layer);
     BwdArgs B{};
     B.g_out = g_out; B.A = A_save; B.EMB = EMB_save; B.Dsave = D_save; B.rows = rows; B.g_x = mode == MODE_ROWS ? g_x : nullptr;
-    B.R = n; B.Rpad = gs_sdf_mlp_h2_rows_padded(mode, n); B.E = L.E; B.n_layers = L.n_layers; B.skip_layer = L.skip_layer;
+    B.R = n; B.n_dev = mode == MODE_ROWS ? n_dev : nullptr; B.Rpad = gs_sdf_mlp_h2_rows_padded(mode, n); B.E = L.E; B.n_layers = L.n_layers; B.skip_layer = L.skip_layer;
     for (int l = 0; l < L.n_layers; ++l) {
         B.wfragT[l] = (const h8*)packed + L.fragT_off[l];
         B.nblkT[l] = L.nblkT[l];
@@ -1108,14 +1184,17 @@ extern "C" int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* ro
 // Weight / bias gradients from the saved planes, ACCUMULATED (float atomics) into torch-layout tensors:
 // dW, db = HOST arrays of n_hidden + 2 DEVICE pointers (Linear.weight.grad [out,in], Linear.bias.grad), output layer last;
 // db[n_hidden + 1] (the output bias, = sum of g_out over the value rows) is not touched.
-extern "C" int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, int n_freq, int n_hidden, int skip_layer, const float* A_save,
-                                   const float* EMB_save, const float* D_save, float* const* dW, float* const* db, int exact_fp32, gs_stream_t stream) {
+extern "C" int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, const int64_t* n_dev, int n_freq, int n_hidden, int skip_layer,
+                                   const float* A_save, const float* EMB_save, const float* D_save, float* const* dW, float* const* db, int exact_fp32,
+                                   gs_stream_t stream) {
     if (n == 0) return 0;
     GS_REQUIRE(mode == MODE_ROWS || mode == MODE_EIK, "gs_sdf_mlp_h2_wgrad: mode must be 1 (rows) or 2 (eikonal)");
     GS_REQUIRE(g_out && A_save && EMB_save && D_save && dW && db, "gs_sdf_mlp_h2_wgrad: null pointer");
     if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
     WgradArgs W{};
     W.A = A_save; W.EMB = EMB_save; W.D = D_save; W.g_out = g_out; W.Rpad = gs_sdf_mlp_h2_rows_padded(mode, n);
+    W.n_dev = mode == MODE_ROWS ? n_dev : nullptr;
+    W.n = mode == MODE_ROWS ? n : W.Rpad;
     W.E = 3 * (2 * n_freq + 1); W.n_layers = n_hidden + 1; W.skip_layer = skip_layer; W.mode = mode;
     for (int l = 0; l <= W.n_layers; ++l) {
         GS_REQUIRE(dW[l] && (l == W.n_layers || db[l]), "gs_sdf_mlp_h2_wgrad: null gradient pointer");

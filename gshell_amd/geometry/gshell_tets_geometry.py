@@ -190,6 +190,11 @@ class GShellTetsGeometry(torch.nn.Module):
         msdf = self.msdf
         v_deformed = v_deformed + self.offset
         verts, faces, uvs, uv_idx, v_tng, extra = self.gshell_tets(v_deformed, sdf, msdf, self.indices)
+        if self.FLAGS.use_sdf_mlp and getattr(self.FLAGS, "sync_free_rows", False):
+            # d loss / d sdf is non-zero only at end points of sign-crossing edges (extraction backward + sign regulariser): a bound
+            # that lets the row-sparse backward size its planes without waiting for the exact count (geometry/mlp.py).  Measured on
+            # MI355X (r02): 31.0 ms / iteration with it, 30.8 without (3x larger planes, three more launches) -- off by default.
+            self.sdf_net._gs_rows_bound = 2 * int(extra['n_verts_watertight']) + 128
         imesh = mesh.Mesh(verts, faces, v_tex=uvs, t_tex_idx=uv_idx, material=material)
         imesh.t_pos_idx_i32 = extra['faces_i32']
         with torch.no_grad():

@@ -306,9 +306,10 @@ def _ptr_array(tensors):
 class _SavedChain:
     """Saved planes of one pass of the h2 chain kernels over n (virtual) rows: A [layers, Rpad, 256], EMB [Rpad, 48]."""
 
-    def __init__(self, net, mode, x, rows, n):
+    def __init__(self, net, mode, x, rows, n, n_dev=None):
+        """n = number of (virtual) rows, or their CAPACITY when `n_dev` (device int64 tensor, [0] = the count) is given."""
         L = _lib.lib()
-        self.net, self.mode, self.n = net, mode, int(n)
+        self.net, self.mode, self.n, self.n_dev = net, mode, int(n), n_dev
         self.lin, self.n_hidden, self.skip = _layer_structure(net)
         self.nf = net.emb.N_freqs
         self.packed, _, _ = pack_weights_h2(net)
@@ -320,7 +321,7 @@ class _SavedChain:
         self.out = torch.empty((self.Rpad,), dtype=torch.float32, device=dev) if mode == 2 else None
         self.rows = rows
         with torch.cuda.device(dev):
-            check(L.gs_sdf_mlp_h2_save_fwd(c_int(mode), ptr(x, torch.float32, "x"), ptr(rows, torch.int32, "rows"), c_int64(self.n), ptr(self.packed),
+            check(L.gs_sdf_mlp_h2_save_fwd(c_int(mode), ptr(x, torch.float32, "x"), ptr(rows, torch.int32, "rows"), c_int64(self.n), ptr(self.n_dev), ptr(self.packed),
                                            c_int(self.nf), c_int(self.n_hidden), c_int(self.skip), ptr(self.A), ptr(self.EMB), ptr(self.out), stream()),
                   "gs_sdf_mlp_h2_save_fwd")
 
@@ -334,10 +335,12 @@ class _SavedChain:
         dW = [grads[id(m.weight)] for m in self.lin]
         db = [grads[id(m.bias)] for m in self.lin]
         with torch.cuda.device(dev):
-            check(L.gs_sdf_mlp_h2_bwd(c_int(self.mode), ptr(g_out, torch.float32, "g_out"), ptr(self.rows, torch.int32, "rows"), c_int64(self.n), ptr(self.packed),
+            check(L.gs_sdf_mlp_h2_bwd(c_int(self.mode), ptr(g_out, torch.float32, "g_out"), ptr(self.rows, torch.int32, "rows"), c_int64(self.n), ptr(self.n_dev),
+                                      ptr(self.packed),
                                       c_int(self.nf), c_int(self.n_hidden), c_int(self.skip), ptr(self.A), ptr(self.EMB), ptr(D), ptr(g_x), stream()),
                   "gs_sdf_mlp_h2_bwd")
-            check(L.gs_sdf_mlp_h2_wgrad(c_int(self.mode), ptr(g_out), c_int64(self.n), c_int(self.nf), c_int(self.n_hidden), c_int(self.skip), ptr(self.A),
+            check(L.gs_sdf_mlp_h2_wgrad(c_int(self.mode), ptr(g_out), c_int64(self.n), ptr(self.n_dev), c_int(self.nf), c_int(self.n_hidden), c_int(self.skip),
+                                        ptr(self.A),
                                         ptr(self.EMB), ptr(D), _ptr_array(dW), _ptr_array(db), c_int(1 if SDF_MLP_WGRAD_FP32 else 0), stream()),
                   "gs_sdf_mlp_h2_wgrad")
         if self.mode == 1:      # output bias: sum of the upstream gradient over the (value) rows
@@ -351,9 +354,26 @@ def row_sparse_backward(net, x, g_y, need_x):
     planes -> backward chain -> weight gradients on the matrix cores); the full-grid forward pass keeps no activations."""
     if not (_fusable(net, x) and g_y.is_cuda):
         return row_sparse_backward_torch(net, x, g_y, need_x)
-    g = g_y.detach().reshape(-1).float()
-    rows = torch.nonzero(g != 0).reshape(-1).int()                  # one host sync (the count sizes the saved planes)
+    g = g_y.detach().reshape(-1).contiguous().float()
     g_x = torch.zeros_like(x) if need_x else None
+    bound = getattr(net, "_gs_rows_bound", None)
+    if bound is not None:
+        # no host sync: the rows with gradient are compacted on the device and the planes are sized by the caller's bound
+        # (GShellTetsGeometry.getMesh: 2 x crossing edges -- d loss / d sdf is non-zero only at their end points)
+        _check_rows_overflow(net)
+        L = _lib.lib()
+        N = g.numel()
+        cap = max(int(min(N, bound)), 1)
+        rows = torch.empty(cap, dtype=torch.int32, device=x.device)
+        count = torch.empty(2, dtype=torch.int64, device=x.device)
+        scratch = torch.empty(int(L.gs_compact_rows_scratch_bytes(c_int64(N))) // 4 + 4, dtype=torch.int32, device=x.device)
+        g_rows = torch.zeros((int(L.gs_sdf_mlp_h2_rows_padded(c_int(1), c_int64(cap))),), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(L.gs_compact_rows(ptr(g), c_int64(N), c_int64(cap), ptr(scratch), ptr(rows), ptr(g_rows), ptr(count), stream()), "gs_compact_rows")
+        _watch_rows_overflow(net, count)
+        saved = _SavedChain(net, 1, x.detach().contiguous(), rows, cap, n_dev=count)
+        return g_x, saved.backward(g_rows, g_x)
+    rows = torch.nonzero(g != 0).reshape(-1).int()                  # one host sync (the count sizes the saved planes)
     n = int(rows.numel())
     if n == 0:
         return g_x, [torch.zeros_like(p) for p in net.parameters()]
@@ -361,6 +381,29 @@ def row_sparse_backward(net, x, g_y, need_x):
     g_rows = torch.zeros((saved.Rpad,), dtype=torch.float32, device=x.device)
     g_rows[:n] = g[rows.long()]
     return g_x, saved.backward(g_rows, g_x)
+
+
+def _watch_rows_overflow(net, count):
+    """The bound on the rows with gradient is checked OFF the hot path: the (count, overflow) pair is copied to pinned host memory
+    asynchronously and inspected at the next call, by which time the copy has long completed (no stall)."""
+    host = getattr(net, "_gs_rows_host", None)
+    if host is None:                     # pinned once: a hipHostMalloc per step costs more than the sync it replaces
+        host = net._gs_rows_host = torch.empty(2, dtype=torch.int64, pin_memory=True)
+    if getattr(net, "_gs_rows_watch", None) is not None:
+        return                           # the previous copy has not been inspected yet: keep watching that one
+    host.copy_(count, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    net._gs_rows_watch = (host, ev)
+
+
+def _check_rows_overflow(net):
+    w = getattr(net, "_gs_rows_watch", None)
+    if w is not None and w[1].query():
+        net._gs_rows_watch = None
+        if int(w[0][1]) != 0:
+            raise _lib.GShellHipError(f"row-sparse SDF backward: more than the {getattr(net, '_gs_rows_bound', '?')} rows promised by net._gs_rows_bound carried "
+                                      "gradient in the previous step (a loss touches sdf values off the crossing edges?) -- unset the bound")
 
 
 class _EikonalFn(torch.autograd.Function):

@@ -478,13 +478,19 @@ int gs_sdf_mlp_fwd_h2(const float* x, int64_t N, const void* packed, int n_freq,
  *   dW / db: HOST arrays of n_hidden + 2 DEVICE pointers (torch layout, output layer last), ACCUMULATED; db[last] untouched.
  * ---------------------------------------------------------------------------------- */
 int64_t gs_sdf_mlp_h2_rows_padded(int mode, int64_t n);
-int gs_sdf_mlp_h2_save_fwd(int mode, const float* x, const int32_t* rows, int64_t n, const void* packed,
-                           int n_freq, int n_hidden, int skip_layer, float* A_save, float* EMB_save,
-                           float* out, gs_stream_t stream);
-int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* rows, int64_t n, const void* packed,
-                      int n_freq, int n_hidden, int skip_layer, const float* A_save,
+/*   Without a host sync (mode 1): gs_compact_rows turns d loss / d sdf [N] into (rows, g_rows, count) entirely on the device;
+ *   n is then a CAPACITY (an upper bound on the rows with gradient, e.g. 2 x crossing edges) and n_dev -> count_dev[0];
+ *   tiles past the device-side count exit.  n_dev = NULL: n is the exact count (the caller synchronised). */
+int64_t gs_compact_rows_scratch_bytes(int64_t N);
+int gs_compact_rows(const float* g, int64_t N, int64_t cap, void* scratch, int32_t* rows, float* g_rows,
+                    int64_t* count_dev /* [2]: min(count, cap), overflow flag */, gs_stream_t stream);
+int gs_sdf_mlp_h2_save_fwd(int mode, const float* x, const int32_t* rows, int64_t n, const int64_t* n_dev,
+                           const void* packed, int n_freq, int n_hidden, int skip_layer, float* A_save,
+                           float* EMB_save, float* out, gs_stream_t stream);
+int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* rows, int64_t n, const int64_t* n_dev,
+                      const void* packed, int n_freq, int n_hidden, int skip_layer, const float* A_save,
                       const float* EMB_save, float* D_save, float* g_x, gs_stream_t stream);
-int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, int n_freq, int n_hidden, int skip_layer,
+int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, const int64_t* n_dev, int n_freq, int n_hidden, int skip_layer,
                         const float* A_save, const float* EMB_save, const float* D_save,
                         float* const* dW, float* const* db,
                         int exact_fp32 /* 0: bf16-pair operands on the bf16 matrix path (default); 1: fp32 MFMA */,

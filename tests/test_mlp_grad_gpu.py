@@ -103,3 +103,30 @@ def test_eikonal_gradient_of_network_output_equals_autograd():
     lin = [m for m in net64.net if isinstance(m, torch.nn.Linear)]
     assert float((f.double() + lin[-1].bias - y[:, 0]).abs().max()) < 2e-6
     assert float((J.double() - gr).abs().max()) < 1e-5 * float(gr.abs().max())
+
+
+def test_row_sparse_backward_without_host_sync_equals_the_synchronising_path():
+    """net._gs_rows_bound (set by GShellTetsGeometry.getMesh to 2 x crossing edges) switches the row-sparse backward to the
+    device-side compaction (gs_compact_rows) with planes sized by the bound and the count kept on the device: same gradients as
+    the path that waits for torch.nonzero; a violated bound is reported at the next call, not silently truncated."""
+    from gshell_amd.geometry.mlp import row_sparse_backward
+    from gshell_amd._lib import GShellHipError
+    net = _net()
+    g = torch.Generator(device=DEV).manual_seed(4)
+    N = 9000 + 5
+    x = (torch.rand(N, 3, device=DEV, generator=g) * 1.4 - 0.7).contiguous()
+    gy = torch.zeros(N, 1, device=DEV)
+    idx = torch.randperm(N, device=DEV, generator=g)[:1500].sort().values
+    gy[idx, 0] = torch.randn(idx.numel(), device=DEV, generator=g) * 1e-4
+    gx_a, grads_a = row_sparse_backward(net, x, gy, True)
+    net._gs_rows_bound = 4000                                     # > 1500 rows, < N
+    gx_b, grads_b = row_sparse_backward(net, x, gy, True)
+    assert torch.allclose(gx_a, gx_b, rtol=1e-5, atol=1e-12)
+    for a, b in zip(grads_a, grads_b):
+        assert _rel(b, a) < 2e-5                                  # float-atomic order of the strip sums
+    net._gs_rows_bound = 1000                                     # too small: flagged ...
+    row_sparse_backward(net, x, gy, False)
+    torch.cuda.synchronize()
+    with pytest.raises(GShellHipError):
+        row_sparse_backward(net, x, gy, False)                    # ... at the next call
+    del net._gs_rows_bound
