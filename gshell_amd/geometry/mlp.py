@@ -331,7 +331,12 @@ class _SavedChain:
         dev = g_out.device
         D = torch.empty_like(self.A)
         params = list(self.net.parameters())
-        grads = {id(p): torch.zeros_like(p) for p in params}
+        # one zero-filled buffer, one view per parameter (16 fills -> 1)
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+        grads, off = {}, 0
+        for p in params:
+            grads[id(p)] = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
         dW = [grads[id(m.weight)] for m in self.lin]
         db = [grads[id(m.bias)] for m in self.lin]
         with torch.cuda.device(dev):

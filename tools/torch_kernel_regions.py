@@ -114,3 +114,16 @@ for k, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
     if t / ITERS / 1e3 > 1.0:
         for kn, kt in sorted(kern[k].items(), key=lambda kv: -kv[1])[:6]:
             print(f"            {kt / ITERS / 1e3:8.3f} ms  {kn}")
+
+# torch / rocPRIM / runtime kernels (everything that is not a hand-written kernel of this library), by total time
+allk = collections.defaultdict(lambda: [0.0, 0])
+for e in evs:
+    for k in getattr(e, "kernels", []):
+        hand = "anonymous namespace)::k_" in k.name or k.name.startswith("(anonymous namespace)::k_")
+        if not hand:
+            allk[k.name[:110]][0] += k.duration
+            allk[k.name[:110]][1] += 1
+tot_other = sum(v[0] for v in allk.values())
+print(f"\nnot hand-written (ATen / rocPRIM / memcpy) kernels: {tot_other / ITERS / 1e3:.2f} ms per iteration in {sum(v[1] for v in allk.values()) / ITERS:.0f} launches")
+for k, (t, n) in sorted(allk.items(), key=lambda kv: -kv[1][0])[:25]:
+    print(f"{t / ITERS / 1e3:8.3f} ms {n / ITERS:6.1f} x  {k}")
