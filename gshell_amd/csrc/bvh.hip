@@ -39,15 +39,20 @@ __device__ __forceinline__ bool load_tri(const float* __restrict__ v, const int3
     return fin;
 }
 
+// Grid-stride over the triangles, one atomic per bound and WORKGROUP (the first version issued six atomics per wave onto the
+// same six words: 21 k serialised atomics = 0.25 ms for a 0.23 M-triangle mesh).
 __global__ void __launch_bounds__(256) k_centroid_bounds(const float* __restrict__ v, const int32_t* __restrict__ tri, int64_t T, int64_t V,
                                                          uint32_t* __restrict__ bounds) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float s_lo[4][3], s_hi[4][3];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    float3 a, b, c;
-    if (t < T && load_tri(v, tri, t, V, a, b, c)) {
-        lo[0] = hi[0] = (a.x + b.x + c.x) * (1.0f / 3.0f);
-        lo[1] = hi[1] = (a.y + b.y + c.y) * (1.0f / 3.0f);
-        lo[2] = hi[2] = (a.z + b.z + c.z) * (1.0f / 3.0f);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (int64_t)gridDim.x * blockDim.x) {
+        float3 a, b, c;
+        if (load_tri(v, tri, t, V, a, b, c)) {
+            const float cx = (a.x + b.x + c.x) * (1.0f / 3.0f), cy = (a.y + b.y + c.y) * (1.0f / 3.0f), cz = (a.z + b.z + c.z) * (1.0f / 3.0f);
+            lo[0] = fminf(lo[0], cx); hi[0] = fmaxf(hi[0], cx);
+            lo[1] = fminf(lo[1], cy); hi[1] = fmaxf(hi[1], cy);
+            lo[2] = fminf(lo[2], cz); hi[2] = fmaxf(hi[2], cz);
+        }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -56,13 +61,20 @@ __global__ void __launch_bounds__(256) k_centroid_bounds(const float* __restrict
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o, 64));
         }
     }
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
         for (int k = 0; k < 3; ++k) {
-            if (lo[k] <= hi[k]) {
-                atomicMin(&bounds[k], f2ord(lo[k]));
-                atomicMax(&bounds[3 + k], f2ord(hi[k]));
-            }
+            s_lo[wave][k] = lo[k];
+            s_hi[wave][k] = hi[k];
+        }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        const float l = fminf(fminf(s_lo[0][k], s_lo[1][k]), fminf(s_lo[2][k], s_lo[3][k]));
+        const float h = fmaxf(fmaxf(s_hi[0][k], s_hi[1][k]), fmaxf(s_hi[2][k], s_hi[3][k]));
+        if (l <= h) {
+            atomicMin(&bounds[k], f2ord(l));
+            atomicMax(&bounds[3 + k], f2ord(h));
         }
     }
 }
@@ -266,7 +278,7 @@ extern "C" int gs_bvh_build(gs_bvh* b, const float* verts, int64_t V, const int3
         b->cap_internal = b->n_internal;
     }
     hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, stream, b->bounds);
-    hipLaunchKernelGGL(k_centroid_bounds, dim3((unsigned)gs::cdiv(T, 256)), dim3(256), 0, stream, verts, tris, T, V, b->bounds);
+    hipLaunchKernelGGL(k_centroid_bounds, dim3((unsigned)std::min<int64_t>(gs::cdiv(T, 256), 256)), dim3(256), 0, stream, verts, tris, T, V, b->bounds);
     hipLaunchKernelGGL(k_morton, dim3((unsigned)gs::cdiv(T, 256)), dim3(256), 0, stream, verts, tris, T, V, b->bounds, b->keys, b->vals);
     size_t tmp = b->sort_tmp_bytes;
     GS_HIP_CHECK(rocprim::radix_sort_pairs(b->sort_tmp, tmp, b->keys, b->keys2, b->vals, b->vals2, (size_t)T, 0, 30, stream));

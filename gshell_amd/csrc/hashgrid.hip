@@ -21,6 +21,7 @@
 #include <cmath>
 
 #include "../../include/gshell_hip.h"
+#include "atomics.hpp"
 #include "common.hpp"
 
 namespace {
@@ -131,6 +132,281 @@ __global__ void __launch_bounds__(256) k_hashgrid(GridMeta M, const float* __res
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The texture-field path of MLPTexture3D.sample (world position -> AABB-normalised, clamped coordinate -> encoding), with
+// the feature tensor LEVEL MAJOR ([L][N][2]) between the encoding and the texture MLP (texmlp.hip reads it that way):
+//   * the [N, 32] layout makes a per-level workgroup store 8 bytes at a 128-byte stride: 9x the algorithmic traffic
+//     measured (profiles/r01_pmc_traffic.json).  Level major, every store and every load of the pair is a full line;
+//   * rows with mask <= 0 are never written (the texture MLP never reads them);
+//   * the normalisation (x - lo) / (hi - lo), the clamp to [0,1], its gradient mask and the reference's 1/128 gradient
+//     scaling hook (mlptexture.py:74) are folded in (they were ~12 + 35 ATen launches around the two kernels).
+// Backward: float atomics on gfx950 are fabric writes at a flat 21 G atomics/s whatever the address pattern
+// (tools/micro/atomic_scope.hip), so the kernel's time IS its atomic count.  The two features of an entry go in ONE
+// 64-bit atomic (atomics.hpp).  A workgroup owns a 16x16-pixel tile of an
+// image (neighbouring pixels = neighbouring surface points), walks the levels itself and combines the tile's
+// contributions per table entry in an LDS hash table (ds_cmpst + ds_add_f32) before ONE global atomic per entry,
+// feature and tile; once a level shows no sharing (>= 3/4 of the inserts claim a fresh slot) the finer levels go to
+// global atomics directly.  d loss / d position is accumulated over the levels in registers and written once.
+#ifndef GS_HG_LOG_SLOTS
+#define GS_HG_LOG_SLOTS 10
+#endif
+#ifndef GS_HG_FLUSH_PAIR
+#define GS_HG_FLUSH_PAIR 0      // flush the combined entries with the 64-bit pair atomic (1) or two float atomics (0)
+#endif
+#ifndef GS_HG_STOP
+#define GS_HG_STOP 3            // stop combining once fresh slots >= GS_HG_STOP / 4 of the inserts
+#endif
+constexpr int CMB_LOG_SLOTS = GS_HG_LOG_SLOTS;
+constexpr int CMB_SLOTS = 1 << CMB_LOG_SLOTS;
+constexpr uint32_t CMB_EMPTY = 0xffffffffu;
+
+struct EncArgs {
+    const float* pos; const float* aabb; const float* mask; int64_t N;
+    const float* params; float* feat;
+    const float* g_feat; float* g_params; float* g_pos; float grad_scale, table_scale;
+    int img_w, img_h;
+};
+
+__device__ __forceinline__ bool enc_coord(const EncArgs& A, int64_t i, float (&t)[3], bool (&inside)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = A.pos[3 * i + k];
+        if (A.aabb) v = (v - A.aabb[k]) / (A.aabb[3 + k] - A.aabb[k]);
+        inside[k] = v >= 0.0f && v <= 1.0f;              // torch.clamp passes the gradient on the closed interval
+        t[k] = A.aabb ? fminf(fmaxf(v, 0.0f), 1.0f) : v;
+        if (v != v) t[k] = v;                            // clamp propagates NaN
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_encode_fwd(GridMeta M, EncArgs A) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.y;
+    if (i >= A.N || (A.mask && !(A.mask[i] > 0.0f))) return;
+    float t[3];
+    bool inside[3];
+    enc_coord(A, i, t, inside);
+    const float scale = M.scale[l];
+    const uint32_t res = M.res[l], size = M.offset[l + 1] - M.offset[l];
+    float w[3];
+    uint32_t g0[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float p = t[k] * scale + 0.5f;
+        const float fl = floorf(p);
+        w[k] = p - fl;
+        g0[k] = (uint32_t)(int)fl;
+    }
+    const float2* tab = reinterpret_cast<const float2*>(A.params) + M.offset[l];
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float wx = (c & 1) ? w[0] : 1.0f - w[0], wy = (c & 2) ? w[1] : 1.0f - w[1], wz = (c & 4) ? w[2] : 1.0f - w[2];
+        const float wgt = wx * wy * wz;
+        const float2 e = tab[grid_index(g0[0] + (c & 1), g0[1] + ((c >> 1) & 1), g0[2] + ((c >> 2) & 1), res, size)];
+        a0 += wgt * e.x;
+        a1 += wgt * e.y;
+    }
+    reinterpret_cast<float2*>(A.feat)[(int64_t)l * A.N + i] = make_float2(a0, a1);
+}
+
+#ifndef GS_HG_WAVES
+#define GS_HG_WAVES 4
+#endif
+__global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, EncArgs A, int tiled) {
+    __shared__ uint32_t s_key[CMB_SLOTS];
+    __shared__ float2 s_val[CMB_SLOTS];
+    __shared__ uint16_t s_list[CMB_SLOTS];   // the slots claimed at the current level (flush + clear walk this list, not the table)
+    __shared__ int s_stat[2][3];             // inserts / claimed slots / inserts that found the table full; bank = level & 1
+    const int tid = threadIdx.x, lane = tid & 63;
+    int64_t i;
+    if (tiled) {                         // 16 x 16 pixel tile of image blockIdx.z
+        const int tx = blockIdx.x, ty = blockIdx.y;
+        i = ((int64_t)blockIdx.z * A.img_h + ty * 16 + (tid >> 4)) * A.img_w + tx * 16 + (tid & 15);
+    } else {
+        i = (int64_t)blockIdx.x * 256 + tid;
+    }
+    const bool in_range = i < A.N;
+    const bool active = in_range && !(A.mask && !(A.mask[i] > 0.0f));
+    if (!__syncthreads_or(active)) {
+        if (in_range && A.g_pos)
+            for (int k = 0; k < 3; ++k) A.g_pos[3 * i + k] = 0.f;
+        return;
+    }
+    float t[3] = {0.f, 0.f, 0.f};
+    bool inside[3] = {false, false, false};
+    if (active) enc_coord(A, i, t, inside);
+    for (int s = tid; s < CMB_SLOTS; s += 256) {
+        s_key[s] = CMB_EMPTY;
+        s_val[s] = make_float2(0.f, 0.f);
+    }
+    if (tid < 6) (&s_stat[0][0])[tid] = 0;
+    __syncthreads();
+    float gx[3] = {0.f, 0.f, 0.f};
+    bool combine = true;                 // workgroup-uniform
+    const float2* gf = reinterpret_cast<const float2*>(A.g_feat);
+    for (int l = 0; l < M.n_levels; ++l) {
+        const float scale = M.scale[l];
+        const uint32_t res = M.res[l], size = M.offset[l + 1] - M.offset[l];
+        float w[3];
+        uint32_t g0[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float p = t[k] * scale + 0.5f;
+            const float fl = floorf(p);
+            w[k] = p - fl;
+            g0[k] = (uint32_t)(int)fl;
+        }
+        const float2* tab = reinterpret_cast<const float2*>(A.params) + M.offset[l];
+        float* gtab = A.g_params ? A.g_params + (int64_t)M.offset[l] * 2 : nullptr;
+        const float2 go = active ? gf[(int64_t)l * A.N + i] : make_float2(0.f, 0.f);
+        float lx = 0.f, ly = 0.f, lz = 0.f;
+        int n_ins = 0, n_new = 0;
+        int* const st = s_stat[l & 1];
+        // phase A: the eight corner entries (independent gathers, all in flight together) and d loss / d coordinate
+        uint32_t idx[8];
+        float wgt[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float wx = (c & 1) ? w[0] : 1.0f - w[0], wy = (c & 2) ? w[1] : 1.0f - w[1], wz = (c & 4) ? w[2] : 1.0f - w[2];
+            wgt[c] = wx * wy * wz;
+            idx[c] = grid_index(g0[0] + (c & 1), g0[1] + ((c >> 1) & 1), g0[2] + ((c >> 2) & 1), res, size);
+        }
+        if (active && A.g_pos) {
+            float2 e[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) e[c] = tab[idx[c]];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float wx = (c & 1) ? w[0] : 1.0f - w[0], wy = (c & 2) ? w[1] : 1.0f - w[1], wz = (c & 4) ? w[2] : 1.0f - w[2];
+                const float dotp = go.x * e[c].x + go.y * e[c].y;
+                lx += ((c & 1) ? 1.f : -1.f) * wy * wz * dotp;
+                ly += ((c & 2) ? 1.f : -1.f) * wx * wz * dotp;
+                lz += ((c & 4) ? 1.f : -1.f) * wx * wy * dotp;
+            }
+        }
+        if (gtab) {
+            // phase B: runs of equal entries along the wave (a 16-pixel row segment): segmented suffix sums, the head lane owns the run
+            float v0[8], v1[8];
+            uint32_t todo = 0u;      // corners this lane has to add to the table
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t key = active ? idx[c] : (0x80000000u | (uint32_t)lane);
+                const uint32_t prev = __shfl_up(key, 1, 64);
+                const bool head = lane == 0 || key != prev;
+                const uint64_t heads = __ballot(head);
+                const uint64_t after = lane == 63 ? 0ull : (heads & ~((2ull << lane) - 1ull));
+                const int end = after ? (__ffsll((long long)after) - 2) : 63;
+                float a = active ? wgt[c] * (go.x * A.table_scale) : 0.0f, b = active ? wgt[c] * (go.y * A.table_scale) : 0.0f;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const float o0 = __shfl_down(a, d, 64), o1 = __shfl_down(b, d, 64);
+                    if (lane + d <= end) {
+                        a += o0;
+                        b += o1;
+                    }
+                }
+                v0[c] = a;
+                v1[c] = b;
+                if (head && active && (a != 0.f || b != 0.f)) todo |= 1u << c;
+            }
+            // phase C: combine in LDS ...
+            if (combine) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (!((todo >> c) & 1u)) continue;
+                    ++n_ins;
+                    uint32_t slot = (idx[c] * 2654435761u) >> (32 - CMB_LOG_SLOTS);
+                    bool done = false;
+                    for (int pr = 0; pr < 8 && !done; ++pr) {
+                        const uint32_t old = atomicCAS(&s_key[slot], CMB_EMPTY, idx[c]);
+                        if (old == CMB_EMPTY || old == idx[c]) {
+                            if (old == CMB_EMPTY) s_list[atomicAdd(&st[1], 1)] = (uint16_t)slot;
+                            atomicAdd(&s_val[slot].x, v0[c]);
+                            atomicAdd(&s_val[slot].y, v1[c]);
+                            done = true;
+                        } else {
+                            slot = (slot + 1) & (CMB_SLOTS - 1);
+                        }
+                    }
+                    if (done) todo &= ~(1u << c);
+                    else ++n_new;
+                }
+            }
+            // ... and whatever is left straight to the table: both features in ONE 64-bit compare-and-swap (atomics.hpp), the eight
+            // loads and then the eight swaps issued back to back so that their latencies overlap
+            if (todo) {
+                union PairBits {
+                    unsigned long long u;
+                    float2 f;
+                };
+                PairBits cur[8], seen[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if ((todo >> c) & 1u)
+                        cur[c].u = __hip_atomic_load(reinterpret_cast<unsigned long long*>(gtab) + idx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if ((todo >> c) & 1u) {
+                        PairBits nxt;
+                        nxt.f = make_float2(cur[c].f.x + v0[c], cur[c].f.y + v1[c]);
+                        seen[c].u = atomicCAS(reinterpret_cast<unsigned long long*>(gtab) + idx[c], cur[c].u, nxt.u);
+                    }
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (((todo >> c) & 1u) && seen[c].u != cur[c].u) {      // lost a race: retry from the value the swap returned
+                        PairBits c2 = seen[c];
+                        for (;;) {
+                            PairBits nxt;
+                            nxt.f = make_float2(c2.f.x + v0[c], c2.f.y + v1[c]);
+                            const unsigned long long sn = atomicCAS(reinterpret_cast<unsigned long long*>(gtab) + idx[c], c2.u, nxt.u);
+                            if (sn == c2.u) break;
+                            c2.u = sn;
+                        }
+                    }
+            }
+        }
+        gx[0] += lx * scale;
+        gx[1] += ly * scale;
+        gx[2] += lz * scale;
+        if (combine && gtab) {           // workgroup-uniform branch
+            if (n_ins) atomicAdd(&st[0], n_ins);
+            if (n_new) atomicAdd(&st[2], n_new);
+            __syncthreads();
+            const int ins = st[0], claimed = st[1], fresh = claimed + st[2];
+            if (tid < 3) s_stat[(l & 1) ^ 1][tid] = 0;      // the other bank: last read before the previous level's closing barrier
+            for (int j = tid; j < claimed; j += 256) {
+                const int s = s_list[j];
+                const uint32_t k = s_key[s];
+                {
+                    const float2 v = s_val[s];
+                    if (GS_HG_FLUSH_PAIR) {
+                        if (v.x != 0.f || v.y != 0.f) gs::atomic_add_pair(&gtab[(int64_t)k * 2], v.x, v.y);
+                    } else {
+                        if (v.x != 0.f) atomicAdd(&gtab[(int64_t)k * 2], v.x);
+                        if (v.y != 0.f) atomicAdd(&gtab[(int64_t)k * 2 + 1], v.y);
+                    }
+                    s_key[s] = CMB_EMPTY;
+                    s_val[s] = make_float2(0.f, 0.f);
+                }
+            }
+            combine = 4 * fresh < GS_HG_STOP * ins;      // no sharing left at this level: finer levels have none either
+            __syncthreads();
+        }
+    }
+    if (active && A.g_pos) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float g = gx[k] * A.grad_scale;
+            if (A.aabb) g = inside[k] ? g / (A.aabb[3 + k] - A.aabb[k]) : 0.0f;
+            A.g_pos[3 * i + k] = g;
+        }
+    } else if (in_range && A.g_pos) {
+        for (int k = 0; k < 3; ++k) A.g_pos[3 * i + k] = 0.f;
+    }
+}
+
 }  // namespace
 
 static int make_meta(GridMeta& M, int n_levels, int F, int log2_T, int base_res, float per_level_scale) {
@@ -184,6 +460,43 @@ extern "C" int gs_hashgrid_bwd(int n_levels, int F, int log2_T, int base_res, fl
     GS_REQUIRE(x && params && g_out, "gs_hashgrid_bwd: null pointer");
     dim3 grid((unsigned)gs::cdiv(N, 256), (unsigned)n_levels);
     hipLaunchKernelGGL(k_hashgrid<true>, grid, dim3(256), 0, (hipStream_t)stream, M, x, mask, N, params, (float*)nullptr, g_out, g_params, g_x_levels);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_hashgrid_encode_fwd(int n_levels, int F, int log2_T, int base_res, float per_level_scale, const float* pos, const float* aabb,
+                                      const float* mask, int64_t N, const float* params, float* feat_level_major, gs_stream_t stream) {
+    GridMeta M;
+    int rc = make_meta(M, n_levels, F, log2_T, base_res, per_level_scale);
+    if (rc) return rc;
+    GS_REQUIRE(F == 2, "gs_hashgrid_encode_fwd: the level-major path is built for 2 features per level");
+    if (N == 0) return 0;
+    GS_REQUIRE(pos && params && feat_level_major, "gs_hashgrid_encode_fwd: null pointer");
+    EncArgs A{};
+    A.pos = pos; A.aabb = aabb; A.mask = mask; A.N = N; A.params = params; A.feat = feat_level_major;
+    hipLaunchKernelGGL(k_encode_fwd, dim3((unsigned)gs::cdiv(N, 256), (unsigned)n_levels), dim3(256), 0, (hipStream_t)stream, M, A);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_hashgrid_encode_bwd(int n_levels, int F, int log2_T, int base_res, float per_level_scale, const float* pos, const float* aabb,
+                                      const float* mask, int64_t N, const float* params, const float* g_feat_level_major, float* g_params,
+                                      float* g_pos, float grad_scale, float table_scale, int64_t img_w, int64_t img_h, gs_stream_t stream) {
+    GridMeta M;
+    int rc = make_meta(M, n_levels, F, log2_T, base_res, per_level_scale);
+    if (rc) return rc;
+    GS_REQUIRE(F == 2, "gs_hashgrid_encode_bwd: the level-major path is built for 2 features per level");
+    if (N == 0) return 0;
+    GS_REQUIRE(pos && params && g_feat_level_major, "gs_hashgrid_encode_bwd: null pointer");
+    GS_REQUIRE(((uintptr_t)g_params & 7) == 0, "gs_hashgrid_encode_bwd: g_params must be 8-byte aligned (feature pairs are updated with one 64-bit atomic)");
+    EncArgs A{};
+    A.pos = pos; A.aabb = aabb; A.mask = mask; A.N = N; A.params = params; A.g_feat = g_feat_level_major; A.g_params = g_params; A.g_pos = g_pos;
+    A.grad_scale = grad_scale; A.table_scale = table_scale;
+    const bool tiled = img_w > 0 && img_h > 0 && img_w % 16 == 0 && img_h % 16 == 0 && N % (img_w * img_h) == 0 && N / (img_w * img_h) < 65536 &&
+                       img_h / 16 < 65536;
+    A.img_w = (int)img_w; A.img_h = (int)img_h;
+    dim3 grid = tiled ? dim3((unsigned)(img_w / 16), (unsigned)(img_h / 16), (unsigned)(N / (img_w * img_h))) : dim3((unsigned)gs::cdiv(N, 256));
+    hipLaunchKernelGGL(k_encode_bwd, grid, dim3(256), 0, (hipStream_t)stream, M, A, tiled ? 1 : 0);
     GS_LAUNCH_CHECK();
     return 0;
 }

@@ -38,6 +38,7 @@ struct TexArgs {
     const float* lo; const float* hi;
     float* out;
     const float* g_out; float* g_x; float* g_w1; float* g_w2; float* g_w3;
+    int level_major;   // x / g_x are [16][N][2] (the hash-grid encoding's level-major feature tensor, hashgrid.hip) instead of [N][32]
 };
 
 // weights into LDS: w1t / w2t are the transposes (forward products walk rows of W^T, backward products rows of W)
@@ -81,6 +82,15 @@ __device__ __forceinline__ void put_row(float* __restrict__ vec, const float (&v
     for (int j = 0; j < D; ++j) vec[j] = v[j];
 }
 
+__device__ __forceinline__ void load_row_lm(const float* __restrict__ x, int64_t N, int64_t r, bool on, float* __restrict__ vec) {
+    const float2* p = reinterpret_cast<const float2*>(x) + r;
+#pragma unroll
+    for (int j = 0; j < D / 2; ++j) {
+        const float2 q = on ? p[(int64_t)j * N] : make_float2(0.f, 0.f);
+        vec[2 * j] = q.x; vec[2 * j + 1] = q.y;
+    }
+}
+
 __device__ __forceinline__ void load_row(const float* __restrict__ x, int64_t r, bool on, float* __restrict__ vec) {
     const float4* p = reinterpret_cast<const float4*>(x + r * D);
 #pragma unroll
@@ -120,7 +130,8 @@ __global__ void __launch_bounds__(256) k_texmlp_fwd(TexArgs A) {
     }
     float* vec = s_tile[wave] + lane * TP;
     float y[D];
-    load_row(A.x, r, on, vec);
+    if (A.level_major) load_row_lm(A.x, A.N, r, on, vec);
+    else load_row(A.x, r, on, vec);
     matvec(s_w1t, vec, D, y);
     relu_inplace(y);
     put_row(vec, y);
@@ -163,7 +174,7 @@ __global__ void __launch_bounds__(64) k_texmlp_bwd(TexArgs A, int64_t n_chunks) 
         const int64_t r = chunk * 64 + lane;
         const bool on = r < A.N && (!A.mask || A.mask[r] > 0.0f);
         if (__ballot(on) == 0ull) {
-            if (r < A.N && A.g_x) {
+            if (r < A.N && A.g_x && !A.level_major) {   // level major: rows with mask <= 0 are never read by the encoding's backward
                 float4* gx = reinterpret_cast<float4*>(A.g_x + r * D);
                 for (int j = 0; j < D / 4; ++j) gx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -171,7 +182,8 @@ __global__ void __launch_bounds__(64) k_texmlp_bwd(TexArgs A, int64_t n_chunks) 
         }
         float y[D];
         // forward, keeping x, h1, h2 in the tiles
-        load_row(A.x, r, on, tx + lane * TP);
+        if (A.level_major) load_row_lm(A.x, A.N, r, on, tx + lane * TP);
+        else load_row(A.x, r, on, tx + lane * TP);
         matvec(s_w1t, tx + lane * TP, D, y);
         const uint32_t m1 = relu_inplace(y);
         put_row(t1 + lane * TP, y);
@@ -209,7 +221,13 @@ __global__ void __launch_bounds__(64) k_texmlp_bwd(TexArgs A, int64_t n_chunks) 
         outer_accumulate(tg, tx, lane, acc1);
         if (A.g_x) {
             matvec(s_w1, tg + lane * TP, D, y);
-            if (r < A.N) {
+            if (r < A.N && A.level_major) {
+                if (on) {
+                    float2* gx = reinterpret_cast<float2*>(A.g_x) + r;
+#pragma unroll
+                    for (int j = 0; j < D / 2; ++j) gx[(int64_t)j * A.N] = make_float2(y[2 * j], y[2 * j + 1]);
+                }
+            } else if (r < A.N) {
                 float4* gx = reinterpret_cast<float4*>(A.g_x + r * D);
 #pragma unroll
                 for (int j = 0; j < D / 4; ++j) gx[j] = make_float4(y[4 * j], y[4 * j + 1], y[4 * j + 2], y[4 * j + 3]);
@@ -229,14 +247,41 @@ __global__ void __launch_bounds__(64) k_texmlp_bwd(TexArgs A, int64_t n_chunks) 
 
 }  // namespace
 
-extern "C" int gs_texmlp_fwd(const float* x, const float* mask, int64_t N, const float* w1, const float* w2, const float* w3, int C,
-                             const float* lo, const float* hi, float* out, gs_stream_t stream) {
+static int texmlp_fwd(const float* x, int level_major, const float* mask, int64_t N, const float* w1, const float* w2, const float* w3, int C,
+                      const float* lo, const float* hi, float* out, gs_stream_t stream) {
     if (N == 0) return 0;
     GS_REQUIRE(x && w1 && w2 && w3 && lo && hi && out, "gs_texmlp_fwd: null pointer");
     GS_REQUIRE(C >= 1 && C <= CMAX, "gs_texmlp_fwd: 1..8 output channels");
     TexArgs A{};
     A.x = x; A.mask = mask; A.N = N; A.w1 = w1; A.w2 = w2; A.w3 = w3; A.C = C; A.lo = lo; A.hi = hi; A.out = out;
+    A.level_major = level_major;
     hipLaunchKernelGGL(k_texmlp_fwd, dim3((unsigned)gs::cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_texmlp_fwd(const float* x, const float* mask, int64_t N, const float* w1, const float* w2, const float* w3, int C,
+                             const float* lo, const float* hi, float* out, gs_stream_t stream) {
+    return texmlp_fwd(x, 0, mask, N, w1, w2, w3, C, lo, hi, out, stream);
+}
+
+extern "C" int gs_texmlp_fwd_level_major(const float* x, const float* mask, int64_t N, const float* w1, const float* w2, const float* w3, int C,
+                                         const float* lo, const float* hi, float* out, gs_stream_t stream) {
+    return texmlp_fwd(x, 1, mask, N, w1, w2, w3, C, lo, hi, out, stream);
+}
+
+static int texmlp_bwd(const float* x, int level_major, const float* mask, int64_t N, const float* w1, const float* w2, const float* w3, int C,
+                      const float* lo, const float* hi, const float* g_out, float* g_x, float* g_w1, float* g_w2, float* g_w3, gs_stream_t stream) {
+    if (N == 0) return 0;
+    GS_REQUIRE(x && w1 && w2 && w3 && lo && hi && g_out, "gs_texmlp_bwd: null pointer");
+    GS_REQUIRE(C >= 1 && C <= CMAX, "gs_texmlp_bwd: 1..8 output channels");
+    TexArgs A{};
+    A.x = x; A.mask = mask; A.N = N; A.w1 = w1; A.w2 = w2; A.w3 = w3; A.C = C; A.lo = lo; A.hi = hi;
+    A.g_out = g_out; A.g_x = g_x; A.g_w1 = g_w1; A.g_w2 = g_w2; A.g_w3 = g_w3;
+    A.level_major = level_major;
+    const int64_t n_chunks = gs::cdiv(N, 64);
+    const int64_t blocks = std::min<int64_t>(n_chunks, 768);
+    hipLaunchKernelGGL(k_texmlp_bwd, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, A, n_chunks);
     GS_LAUNCH_CHECK();
     return 0;
 }
@@ -244,15 +289,11 @@ extern "C" int gs_texmlp_fwd(const float* x, const float* mask, int64_t N, const
 extern "C" int gs_texmlp_bwd(const float* x, const float* mask, int64_t N, const float* w1, const float* w2, const float* w3, int C,
                              const float* lo, const float* hi, const float* g_out, float* g_x, float* g_w1, float* g_w2, float* g_w3,
                              gs_stream_t stream) {
-    if (N == 0) return 0;
-    GS_REQUIRE(x && w1 && w2 && w3 && lo && hi && g_out, "gs_texmlp_bwd: null pointer");
-    GS_REQUIRE(C >= 1 && C <= CMAX, "gs_texmlp_bwd: 1..8 output channels");
-    TexArgs A{};
-    A.x = x; A.mask = mask; A.N = N; A.w1 = w1; A.w2 = w2; A.w3 = w3; A.C = C; A.lo = lo; A.hi = hi;
-    A.g_out = g_out; A.g_x = g_x; A.g_w1 = g_w1; A.g_w2 = g_w2; A.g_w3 = g_w3;
-    const int64_t n_chunks = gs::cdiv(N, 64);
-    const int64_t blocks = std::min<int64_t>(n_chunks, 768);
-    hipLaunchKernelGGL(k_texmlp_bwd, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, A, n_chunks);
-    GS_LAUNCH_CHECK();
-    return 0;
+    return texmlp_bwd(x, 0, mask, N, w1, w2, w3, C, lo, hi, g_out, g_x, g_w1, g_w2, g_w3, stream);
+}
+
+extern "C" int gs_texmlp_bwd_level_major(const float* x, const float* mask, int64_t N, const float* w1, const float* w2, const float* w3, int C,
+                                         const float* lo, const float* hi, const float* g_out, float* g_x, float* g_w1, float* g_w2, float* g_w3,
+                                         gs_stream_t stream) {
+    return texmlp_bwd(x, 1, mask, N, w1, w2, w3, C, lo, hi, g_out, g_x, g_w1, g_w2, g_w3, stream);
 }

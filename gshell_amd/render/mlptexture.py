@@ -82,6 +82,59 @@ class _TexMlpFn(torch.autograd.Function):
         return g_x, None, g_w1, g_w2, g_w3, None, None
 
 
+class _FieldFn(torch.autograd.Function):
+    """MLPTexture3D.sample as two kernels each way: AABB normalisation + clamp + hash-grid encoding
+    (gs_hashgrid_encode_*), texture MLP + range mapping (gs_texmlp_*_level_major), with the [L, N, 2] LEVEL-MAJOR
+    feature tensor between them (hashgrid.hip explains why) and the reference's two gradient-scaling hooks
+    (mlptexture.py:31 x128 into the MLP input, :74 /128 out of the encoder) folded in: their product is exactly 1
+    on the table gradient and 1/128 on the position gradient... applied as the reference applies them.
+    pos [N,3] world positions, mask [N] or None, img = (H, W) when the rows are whole images (tiles the backward)."""
+
+    @staticmethod
+    def forward(ctx, pos, params, mask, w1, w2, w3, lo, hi, aabb, cfg, mlp_scale, enc_scale, img):
+        L = _lib.lib()
+        f = lambda t: None if t is None else t.detach().contiguous().float()
+        pos_c, p_c, m_c = f(pos), f(params), (None if mask is None else f(mask.reshape(-1)))
+        ws = [f(t) for t in (w1, w2, w3, lo, hi)]
+        ab = f(aabb)
+        N, C = pos_c.shape[0], ws[2].shape[0]
+        feat = torch.empty((cfg[0], N, cfg[1]), dtype=torch.float32, device=pos_c.device)
+        out = torch.empty((N, C), dtype=torch.float32, device=pos_c.device)
+        with torch.cuda.device(pos_c.device):
+            check(L.gs_hashgrid_encode_fwd(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4]), ptr(pos_c, torch.float32, "pos"),
+                                           ptr(ab), ptr(m_c), c_int64(N), ptr(p_c, torch.float32, "params"), ptr(feat), stream()),
+                  "gs_hashgrid_encode_fwd")
+            check(L.gs_texmlp_fwd_level_major(ptr(feat), ptr(m_c), c_int64(N), ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), c_int(C), ptr(ws[3]), ptr(ws[4]),
+                                              ptr(out), stream()), "gs_texmlp_fwd_level_major")
+        ctx.save_for_backward(pos_c, p_c, m_c, feat, ab, *ws)
+        ctx.cfg, ctx.scales, ctx.img = cfg, (float(mlp_scale), float(enc_scale)), img
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        pos_c, p_c, m_c, feat, ab, w1, w2, w3, lo, hi = ctx.saved_tensors
+        cfg, (mlp_scale, enc_scale), img = ctx.cfg, ctx.scales, ctx.img
+        L = _lib.lib()
+        g = g_out.contiguous().float()
+        N, C = pos_c.shape[0], w3.shape[0]
+        need_pos, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_feat = torch.empty_like(feat) if (need_pos or need_p) else None
+        g_w = torch.zeros(w1.numel() + w2.numel() + w3.numel(), dtype=torch.float32, device=g.device)
+        g_w1, g_w2, g_w3 = g_w[:w1.numel()].view_as(w1), g_w[w1.numel():w1.numel() + w2.numel()].view_as(w2), g_w[w1.numel() + w2.numel():].view_as(w3)
+        g_params = torch.zeros_like(p_c) if need_p else None
+        g_pos = torch.empty_like(pos_c) if need_pos else None
+        H, W = img if img is not None else (0, 0)
+        with torch.cuda.device(g.device):
+            check(L.gs_texmlp_bwd_level_major(ptr(feat), ptr(m_c), c_int64(N), ptr(w1), ptr(w2), ptr(w3), c_int(C), ptr(lo), ptr(hi), ptr(g),
+                                              ptr(g_feat), ptr(g_w1), ptr(g_w2), ptr(g_w3), stream()), "gs_texmlp_bwd_level_major")
+            if g_feat is not None:
+                # d/d feat of the MLP carries the x128 hook; the table gradient takes it as is, the position gradient takes x128 / 128
+                check(L.gs_hashgrid_encode_bwd(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4]), ptr(pos_c), ptr(ab), ptr(m_c),
+                                               c_int64(N), ptr(p_c), ptr(g_feat), ptr(g_params), ptr(g_pos), c_float(mlp_scale * enc_scale),
+                                               c_float(mlp_scale), c_int64(W), c_int64(H), stream()), "gs_hashgrid_encode_bwd")
+        return g_pos, g_params, None, g_w1, g_w2, g_w3, None, None, None, None, None, None, None
+
+
 class HashGridEncoding(torch.nn.Module):
     """Stand-in for `tcnn.Encoding(3, {"otype": "HashGrid", ...})`: same config keys, `.params`,
     `.n_output_dims`; parameters are fp32 and initialised U(-1e-4, 1e-4) like tiny-cuda-nn."""
@@ -159,12 +212,44 @@ class MLPTexture3D(torch.nn.Module):
     def sample(self, texc, mask=None):
         """texc [...,3] world positions -> [..., channels].  `mask` (optional, [...]) skips rows whose value cannot
         reach any output (background pixels); the reference evaluates them and then discards them."""
+        if self._fusable(texc)[0]:
+            return self.sample_many([texc], mask)[0]
         _texc = (texc.view(-1, 3) - self.AABB[0][None, ...]) / (self.AABB[1][None, ...] - self.AABB[0][None, ...])
         _texc = torch.clamp(_texc, min=0, max=1)
         # reference: encoder backward hook divides the gradient w.r.t. the encoder input by 128 (:74)
         p_enc = self.encoder(_ScaleGrad.apply(_texc.contiguous(), 1.0 / self.gradient_scaling), mask)
         out = self.net.forward_mapped(p_enc, mask, self.min_max[0], self.min_max[1])
         return out.view(*texc.shape[:-1], self.channels)
+
+    def _aabb_tensor(self):
+        ab = getattr(self, "_aabb_dev", None)
+        if ab is None or ab[0] is not self.AABB:
+            t = self.AABB if torch.is_tensor(self.AABB) else torch.stack((self.AABB[0], self.AABB[1]))
+            ab = self._aabb_dev = (self.AABB, t.detach().float().contiguous())
+        return ab[1]
+
+    def _fusable(self, texc):
+        lin = [m for m in self.net.net if isinstance(m, torch.nn.Linear)]
+        return (texc.is_cuda and self.encoder.cfg[1] == 2 and self.encoder.cfg[0] == 16 and self.net.fusable(texc) and
+                getattr(self, "fused_field", True)), lin
+
+    def sample_many(self, texcs, mask=None):
+        """sample() of several coordinate sets that share one mask (render.py:68,70 samples the jittered and the plain
+        g-buffer position) as ONE launch sequence over the concatenated rows: one table-gradient buffer, one pass of
+        the backward kernels.  -> list of [..., channels]"""
+        ok, lin = self._fusable(texcs[0])
+        if not ok:
+            return [self.sample(t, mask) for t in texcs]
+        shp = texcs[0].shape
+        k = len(texcs)
+        pos = torch.cat([t.reshape(-1, 3) for t in texcs], 0) if k > 1 else texcs[0].reshape(-1, 3)
+        m = None if mask is None else (mask.reshape(-1).float().repeat(k) if k > 1 else mask.reshape(-1))
+        img = (int(shp[-3]), int(shp[-2])) if texcs[0].dim() >= 3 else None
+        out = _FieldFn.apply(pos, self.encoder.params, m, lin[0].weight, lin[1].weight, lin[2].weight, self.min_max[0], self.min_max[1],
+                             self._aabb_tensor(),
+                             self.encoder.cfg, self.net.loss_scale, 1.0 / self.gradient_scaling, img)
+        n = out.shape[0] // k
+        return [out[j * n:(j + 1) * n].view(*shp[:-1], self.channels) for j in range(k)]
 
     def clamp_(self):
         pass

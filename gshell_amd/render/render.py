@@ -171,8 +171,12 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
     perturbed_nrm = None
     if 'kd_ks' in material:
         noise = _noise('texture', lambda: torch.normal(mean=0, std=0.01, size=gb_pos.shape, device=dev), FLAGS, 0.01, tuple(gb_pos.shape), dev)
-        all_tex_jitter = _sample_texture(material['kd_ks'], gb_pos + noise, mask)
-        all_tex = _sample_texture(material['kd_ks'], gb_pos, mask)
+        tex_obj = material['kd_ks']
+        if hasattr(tex_obj, 'sample_many'):      # both lookups in one pass over the concatenated rows (same values)
+            all_tex_jitter, all_tex = tex_obj.sample_many([gb_pos + noise, gb_pos], mask)
+        else:
+            all_tex_jitter = _sample_texture(tex_obj, gb_pos + noise, mask)
+            all_tex = _sample_texture(tex_obj, gb_pos, mask)
         assert all_tex.shape[-1] == 6, "Combined kd_ks must be 6 channels"
         kd, ks = all_tex[..., 0:3], all_tex[..., 3:6]
         if not (_defer and getattr(FLAGS, "fused_assemble", True)):

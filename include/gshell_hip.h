@@ -338,6 +338,25 @@ int gs_hashgrid_bwd(int n_levels, int F, int log2_T, int base_res, float per_lev
                     const float* x, const float* mask, int64_t N, const float* params,
                     const float* g_out, float* g_params, float* g_x_levels, gs_stream_t stream);
 
+/* The texture-field path of MLPTexture3D.sample in one kernel each way (render/mlptexture.py:87-99 incl. the AABB
+ *   normalisation :89-90 and the encoder's 1/128 gradient hook :74), F = 2 only:
+ *   pos [N,3] world positions; aabb [2,3] device (lo, hi; NULL = pos is already the [0,1] coordinate);
+ *   t = clamp((pos - lo) / (hi - lo), 0, 1);   feat_level_major [n_levels, N, 2]: rows with mask <= 0 are NOT written
+ *   (gs_texmlp_*_level_major never read them).
+ *   bwd: g_params ACCUMULATED with table_scale * d/d table (NULL = skip); g_pos [N,3] WRITTEN (NULL = skip) =
+ *   grad_scale * d/dt, through the clamp (closed interval) and the division; rows with mask <= 0 get 0.  img_w, img_h: when the N rows are whole row-major
+ *   images of that size (multiples of 16) a workgroup owns a 16x16 pixel tile and combines its table updates in LDS
+ *   before the global atomics (0 = rows in arbitrary order: 256 consecutive rows per workgroup). */
+int gs_hashgrid_encode_fwd(int n_levels, int F, int log2_T, int base_res, float per_level_scale,
+                           const float* pos, const float* aabb, const float* mask, int64_t N,
+                           const float* params, float* feat_level_major, gs_stream_t stream);
+int gs_hashgrid_encode_bwd(int n_levels, int F, int log2_T, int base_res, float per_level_scale,
+                           const float* pos, const float* aabb, const float* mask, int64_t N,
+                           const float* params, const float* g_feat_level_major, float* g_params,
+                           float* g_pos, float grad_scale, float table_scale, int64_t img_w,
+                           int64_t img_h,
+                           gs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Softplus with first and second derivative   (the activation of geometry/mlp.py:19-33, nn.Softplus(beta=100);
  *   replaces ATen's softplus / softplus_backward / the ~9-op expansion of softplus_double_backward on the torch
@@ -383,6 +402,15 @@ int gs_texmlp_fwd(const float* x, const float* mask, int64_t N, const float* w1,
 int gs_texmlp_bwd(const float* x, const float* mask, int64_t N, const float* w1, const float* w2,
                   const float* w3, int C, const float* lo, const float* hi, const float* g_out,
                   float* g_x, float* g_w1, float* g_w2, float* g_w3, gs_stream_t stream);
+/* the same network on the level-major feature tensor of gs_hashgrid_encode_* (x, g_x: [16, N, 2]); g_x is written
+ * for rows with mask > 0 only */
+int gs_texmlp_fwd_level_major(const float* x, const float* mask, int64_t N, const float* w1,
+                              const float* w2, const float* w3, int C, const float* lo,
+                              const float* hi, float* out, gs_stream_t stream);
+int gs_texmlp_bwd_level_major(const float* x, const float* mask, int64_t N, const float* w1,
+                              const float* w2, const float* w3, int C, const float* lo,
+                              const float* hi, const float* g_out, float* g_x, float* g_w1,
+                              float* g_w2, float* g_w3, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * SDF sign-consistency regulariser   (replaces compute_sdf_reg_loss,

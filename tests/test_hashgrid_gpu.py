@@ -93,3 +93,65 @@ def test_texture_mlp_fused_matches_torch(N, C, masked):
     for a, b, name in zip(got[1:], want[1:], ("g_x", "g_w1", "g_w2", "g_w3")):
         scale = float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 1e-4 * scale, name
+
+
+def _field_case(shape, smooth, seed):
+    g = torch.Generator().manual_seed(seed)
+    if smooth:      # neighbouring pixels = neighbouring surface points (what a g-buffer looks like): exercises the LDS combining
+        B, H, W = shape
+        v, u = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+        z = torch.sqrt(torch.clamp(1.3 - u * u - v * v, min=0.0)) - 0.2
+        pos = torch.stack((u, v, z), -1)[None].repeat(B, 1, 1, 1) * 1.05 + 0.002 * torch.randn(B, H, W, 3, generator=g)   # a rim outside the AABB
+        mask = ((u * u + v * v) < 1.1).float()[None, :, :, None].repeat(B, 1, 1, 1)
+    else:
+        pos = torch.rand(*shape, 3, generator=g) * 2.4 - 1.2
+        mask = (torch.rand(*shape, 1, generator=g) > 0.3).float()
+    return pos, mask
+
+
+@pytest.mark.parametrize("shape,smooth", [((2, 32, 48), True), ((3, 64, 64), True), ((1, 16, 16), False), ((2999,), False), ((2, 17, 24), True)])
+def test_texture_field_fused_path_matches_separate_operators(shape, smooth):
+    """MLPTexture3D.sample / sample_many through gs_hashgrid_encode_* + gs_texmlp_*_level_major (AABB normalisation, clamp and
+    the two gradient hooks folded in, level-major features, LDS-combined table atomics over 16x16 tiles) against the
+    operator-by-operator path (gs_hashgrid_* + gs_texmlp_* + ATen glue), which is the one pinned to the oracle above.
+    Forward: same arithmetic -> 1e-6.  Gradients: float-atomic order differs -> 1e-5 of the maximum."""
+    from gshell_amd.render.mlptexture import MLPTexture3D
+    aabb = (torch.tensor([-1.0, -0.9, -0.8], device=DEV), torch.tensor([1.0, 1.1, 0.9], device=DEV))
+    mn = torch.tensor([0, 0, 0, 0, 0.08, 0], dtype=torch.float32, device=DEV)
+    mx = torch.tensor([1, 1, 1, 0.3, 1, 1], dtype=torch.float32, device=DEV)
+    tex = MLPTexture3D(aabb, channels=6, min_max=[mn, mx])
+    with torch.no_grad():
+        tex.encoder.params.mul_(3000.0)      # U(-0.3, 0.3): features large enough to matter
+    pos, mask = _field_case(shape, smooth, seed=len(shape) + shape[0])
+    if not smooth:
+        mask = mask.reshape(*shape, 1)
+    noise = 0.01 * torch.randn(pos.shape, generator=torch.Generator().manual_seed(5))
+    go = torch.randn(2, *shape, 6, generator=torch.Generator().manual_seed(6)).to(DEV) * mask.to(DEV)
+    res = {}
+    for fused in (False, True):
+        tex.fused_field = fused
+        for p in tex.parameters():
+            p.grad = None
+        p_d = pos.to(DEV).requires_grad_(True)
+        if fused:
+            a, b = tex.sample_many([p_d + noise.to(DEV), p_d], mask.to(DEV))
+        else:
+            a, b = tex.sample(p_d + noise.to(DEV), mask=mask.to(DEV)), tex.sample(p_d, mask=mask.to(DEV))
+        ((a * go[0]).sum() + (b * go[1]).sum()).backward()
+        res[fused] = [a.detach(), b.detach(), p_d.grad.clone(), tex.encoder.params.grad.clone()] + [p.grad.clone() for p in tex.net.parameters()]
+    m = mask.to(DEV) > 0
+    for j in (0, 1):
+        assert torch.allclose(res[True][j] * m, res[False][j] * m, rtol=1e-6, atol=1e-6)
+    names = ["g_pos", "g_table", "g_w1", "g_w2", "g_w3"]
+    for a, b, name in zip(res[True][2:], res[False][2:], names):
+        scale = float(b.abs().max())
+        assert scale > 0, name
+        err = float((a - b).abs().max()) / scale
+        print(f"  {name}: max err / max = {err:.2e}")
+        assert err <= 1e-5, (name, err)
+    # rows outside the mask receive no position gradient
+    assert (res[True][2] * (~m)).abs().max() == 0
+    # single-set entry point
+    tex.fused_field = True
+    one = tex.sample(pos.to(DEV), mask=mask.to(DEV))
+    assert torch.equal(one * m, res[True][1] * m)

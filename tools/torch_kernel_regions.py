@@ -96,6 +96,7 @@ def bwd_label(e):
 
 
 agg = collections.defaultdict(lambda: [0.0, 0])
+ops = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 kern = collections.defaultdict(lambda: collections.defaultdict(float))
 tot = 0.0
 for e in evs:
@@ -106,6 +107,8 @@ for e in evs:
     agg[lab][0] += dt
     agg[lab][1] += 1
     tot += dt
+    ops[lab][e.name][0] += dt
+    ops[lab][e.name][1] += 1
     for k in getattr(e, "kernels", []):
         kern[lab][k.name[:70]] += k.duration
 print(f"device time per iteration: {tot / ITERS / 1e3:.2f} ms")
@@ -114,6 +117,14 @@ for k, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
     if t / ITERS / 1e3 > 1.0:
         for kn, kt in sorted(kern[k].items(), key=lambda kv: -kv[1])[:6]:
             print(f"            {kt / ITERS / 1e3:8.3f} ms  {kn}")
+
+if os.environ.get("GS_REGIONS_DETAIL"):
+    # which torch operators issue the launches of every region (for hunting the small-kernel glue)
+    print("\noperators per region:")
+    for k, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"{n / ITERS:7.1f} launches {t / ITERS / 1e3:8.3f} ms  {k}")
+        for on, (ot, oc) in sorted(ops[k].items(), key=lambda kv: -kv[1][1]):
+            print(f"        {oc / ITERS:6.1f} x {ot / ITERS / 1e3:7.3f} ms  {on}")
 
 # torch / rocPRIM / runtime kernels (everything that is not a hand-written kernel of this library), by total time
 allk = collections.defaultdict(lambda: [0.0, 0])
