@@ -151,12 +151,6 @@ __global__ void __launch_bounds__(256) k_hashgrid(GridMeta M, const float* __res
 #ifndef GS_HG_LOG_SLOTS
 #define GS_HG_LOG_SLOTS 10
 #endif
-#ifndef GS_HG_FLUSH_PAIR
-#define GS_HG_FLUSH_PAIR 0      // flush the combined entries with the 64-bit pair atomic (1) or two float atomics (0)
-#endif
-#ifndef GS_HG_STOP
-#define GS_HG_STOP 3            // stop combining once fresh slots >= GS_HG_STOP / 4 of the inserts
-#endif
 constexpr int CMB_LOG_SLOTS = GS_HG_LOG_SLOTS;
 constexpr int CMB_SLOTS = 1 << CMB_LOG_SLOTS;
 constexpr uint32_t CMB_EMPTY = 0xffffffffu;
@@ -214,18 +208,29 @@ __global__ void __launch_bounds__(256) k_encode_fwd(GridMeta M, EncArgs A) {
 #ifndef GS_HG_WAVES
 #define GS_HG_WAVES 4
 #endif
+#ifndef GS_HG_RUNS
+#define GS_HG_RUNS 8            // a wave combines in LDS at a level when < GS_HG_RUNS / 8 of its (lane, corner) updates head a run
+                                // (measured, ms per backward of both lookups: 6 -> 2.16, 7 -> 1.84, 8 = any run at all -> 1.60, always -> 1.87,
+                                //  never = compare-and-swap on contended coarse entries -> 4.9; float atomics instead of the pair swap: 2.2)
+#endif
+#ifndef GS_HG_ALTERNATE
+#define GS_HG_ALTERNATE 1       // odd workgroups walk the levels fine -> coarse
+#endif
 __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, EncArgs A, int tiled) {
     __shared__ uint32_t s_key[CMB_SLOTS];
     __shared__ float2 s_val[CMB_SLOTS];
     __shared__ uint16_t s_list[CMB_SLOTS];   // the slots claimed at the current level (flush + clear walk this list, not the table)
-    __shared__ int s_stat[2][3];             // inserts / claimed slots / inserts that found the table full; bank = level & 1
+    __shared__ int s_claimed[2];             // bank = level step & 1
     const int tid = threadIdx.x, lane = tid & 63;
     int64_t i;
+    int wg_linear;
     if (tiled) {                         // 16 x 16 pixel tile of image blockIdx.z
         const int tx = blockIdx.x, ty = blockIdx.y;
         i = ((int64_t)blockIdx.z * A.img_h + ty * 16 + (tid >> 4)) * A.img_w + tx * 16 + (tid & 15);
+        wg_linear = tx + ty;
     } else {
         i = (int64_t)blockIdx.x * 256 + tid;
+        wg_linear = blockIdx.x;
     }
     const bool in_range = i < A.N;
     const bool active = in_range && !(A.mask && !(A.mask[i] > 0.0f));
@@ -241,12 +246,16 @@ __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, Enc
         s_key[s] = CMB_EMPTY;
         s_val[s] = make_float2(0.f, 0.f);
     }
-    if (tid < 6) (&s_stat[0][0])[tid] = 0;
+    if (tid < 2) s_claimed[tid] = 0;
     __syncthreads();
     float gx[3] = {0.f, 0.f, 0.f};
-    bool combine = true;                 // workgroup-uniform
     const float2* gf = reinterpret_cast<const float2*>(A.g_feat);
-    for (int l = 0; l < M.n_levels; ++l) {
+    const int n_active8 = 8 * __popcll(__ballot(active));
+    // The coarse levels are LDS / barrier latency, the fine levels are global-atomic throughput: neighbouring workgroups walk the
+    // levels in opposite directions so that the chip always has both kinds of work in flight.
+    const bool descending = GS_HG_ALTERNATE && (wg_linear & 1);
+    for (int step = 0; step < M.n_levels; ++step) {
+        const int l = descending ? M.n_levels - 1 - step : step;
         const float scale = M.scale[l];
         const uint32_t res = M.res[l], size = M.offset[l + 1] - M.offset[l];
         float w[3];
@@ -262,8 +271,7 @@ __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, Enc
         float* gtab = A.g_params ? A.g_params + (int64_t)M.offset[l] * 2 : nullptr;
         const float2 go = active ? gf[(int64_t)l * A.N + i] : make_float2(0.f, 0.f);
         float lx = 0.f, ly = 0.f, lz = 0.f;
-        int n_ins = 0, n_new = 0;
-        int* const st = s_stat[l & 1];
+        int* const claimed = &s_claimed[step & 1];
         // phase A: the eight corner entries (independent gathers, all in flight together) and d loss / d coordinate
         uint32_t idx[8];
         float wgt[8];
@@ -286,113 +294,115 @@ __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, Enc
                 lz += ((c & 4) ? 1.f : -1.f) * wx * wy * dotp;
             }
         }
-        if (gtab) {
-            // phase B: runs of equal entries along the wave (a 16-pixel row segment): segmented suffix sums, the head lane owns the run
-            float v0[8], v1[8];
-            uint32_t todo = 0u;      // corners this lane has to add to the table
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t key = active ? idx[c] : (0x80000000u | (uint32_t)lane);
-                const uint32_t prev = __shfl_up(key, 1, 64);
-                const bool head = lane == 0 || key != prev;
-                const uint64_t heads = __ballot(head);
-                const uint64_t after = lane == 63 ? 0ull : (heads & ~((2ull << lane) - 1ull));
-                const int end = after ? (__ffsll((long long)after) - 2) : 63;
-                float a = active ? wgt[c] * (go.x * A.table_scale) : 0.0f, b = active ? wgt[c] * (go.y * A.table_scale) : 0.0f;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const float o0 = __shfl_down(a, d, 64), o1 = __shfl_down(b, d, 64);
-                    if (lane + d <= end) {
-                        a += o0;
-                        b += o1;
-                    }
-                }
-                v0[c] = a;
-                v1[c] = b;
-                if (head && active && (a != 0.f || b != 0.f)) todo |= 1u << c;
-            }
-            // phase C: combine in LDS ...
-            if (combine) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    if (!((todo >> c) & 1u)) continue;
-                    ++n_ins;
-                    uint32_t slot = (idx[c] * 2654435761u) >> (32 - CMB_LOG_SLOTS);
-                    bool done = false;
-                    for (int pr = 0; pr < 8 && !done; ++pr) {
-                        const uint32_t old = atomicCAS(&s_key[slot], CMB_EMPTY, idx[c]);
-                        if (old == CMB_EMPTY || old == idx[c]) {
-                            if (old == CMB_EMPTY) s_list[atomicAdd(&st[1], 1)] = (uint16_t)slot;
-                            atomicAdd(&s_val[slot].x, v0[c]);
-                            atomicAdd(&s_val[slot].y, v1[c]);
-                            done = true;
-                        } else {
-                            slot = (slot + 1) & (CMB_SLOTS - 1);
-                        }
-                    }
-                    if (done) todo &= ~(1u << c);
-                    else ++n_new;
-                }
-            }
-            // ... and whatever is left straight to the table: both features in ONE 64-bit compare-and-swap (atomics.hpp), the eight
-            // loads and then the eight swaps issued back to back so that their latencies overlap
-            if (todo) {
-                union PairBits {
-                    unsigned long long u;
-                    float2 f;
-                };
-                PairBits cur[8], seen[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    if ((todo >> c) & 1u)
-                        cur[c].u = __hip_atomic_load(reinterpret_cast<unsigned long long*>(gtab) + idx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    if ((todo >> c) & 1u) {
-                        PairBits nxt;
-                        nxt.f = make_float2(cur[c].f.x + v0[c], cur[c].f.y + v1[c]);
-                        seen[c].u = atomicCAS(reinterpret_cast<unsigned long long*>(gtab) + idx[c], cur[c].u, nxt.u);
-                    }
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    if (((todo >> c) & 1u) && seen[c].u != cur[c].u) {      // lost a race: retry from the value the swap returned
-                        PairBits c2 = seen[c];
-                        for (;;) {
-                            PairBits nxt;
-                            nxt.f = make_float2(c2.f.x + v0[c], c2.f.y + v1[c]);
-                            const unsigned long long sn = atomicCAS(reinterpret_cast<unsigned long long*>(gtab) + idx[c], c2.u, nxt.u);
-                            if (sn == c2.u) break;
-                            c2.u = sn;
-                        }
-                    }
-            }
-        }
         gx[0] += lx * scale;
         gx[1] += ly * scale;
         gx[2] += lz * scale;
-        if (combine && gtab) {           // workgroup-uniform branch
-            if (n_ins) atomicAdd(&st[0], n_ins);
-            if (n_new) atomicAdd(&st[2], n_new);
-            __syncthreads();
-            const int ins = st[0], claimed = st[1], fresh = claimed + st[2];
-            if (tid < 3) s_stat[(l & 1) ^ 1][tid] = 0;      // the other bank: last read before the previous level's closing barrier
-            for (int j = tid; j < claimed; j += 256) {
-                const int s = s_list[j];
-                const uint32_t k = s_key[s];
-                {
-                    const float2 v = s_val[s];
-                    if (GS_HG_FLUSH_PAIR) {
-                        if (v.x != 0.f || v.y != 0.f) gs::atomic_add_pair(&gtab[(int64_t)k * 2], v.x, v.y);
-                    } else {
-                        if (v.x != 0.f) atomicAdd(&gtab[(int64_t)k * 2], v.x);
-                        if (v.y != 0.f) atomicAdd(&gtab[(int64_t)k * 2 + 1], v.y);
-                    }
-                    s_key[s] = CMB_EMPTY;
-                    s_val[s] = make_float2(0.f, 0.f);
+        if (!gtab) continue;
+        // phase B: runs of equal entries along the wave (16-pixel row segments): segmented suffix sums, the head lane owns the run
+        float v0[8], v1[8];
+        uint32_t todo = 0u;      // corners this lane has to add to the table
+        int n_heads = 0;         // wave-uniform
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t key = active ? idx[c] : (0x80000000u | (uint32_t)lane);
+            const uint32_t prev = __shfl_up(key, 1, 64);
+            const bool head = lane == 0 || key != prev;
+            const uint64_t heads = __ballot(head);
+            n_heads += __popcll(__ballot(head && active));
+            const uint64_t after = lane == 63 ? 0ull : (heads & ~((2ull << lane) - 1ull));
+            const int end = after ? (__ffsll((long long)after) - 2) : 63;
+            float a = active ? wgt[c] * (go.x * A.table_scale) : 0.0f, b = active ? wgt[c] * (go.y * A.table_scale) : 0.0f;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const float o0 = __shfl_down(a, d, 64), o1 = __shfl_down(b, d, 64);
+                if (lane + d <= end) {
+                    a += o0;
+                    b += o1;
                 }
             }
-            combine = 4 * fresh < GS_HG_STOP * ins;      // no sharing left at this level: finer levels have none either
+            v0[c] = a;
+            v1[c] = b;
+            if (head && active && (a != 0.f || b != 0.f)) todo |= 1u << c;
+        }
+        // phase C: where neighbouring pixels share entries along the rows they share them across the rows too: combine the tile's
+        // updates per entry in LDS (stateless per level and wave, so the level order is free) ...
+        const bool combine = 8 * n_heads < GS_HG_RUNS * n_active8;       // wave-uniform
+        if (combine) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (!((todo >> c) & 1u)) continue;
+                uint32_t slot = (idx[c] * 2654435761u) >> (32 - CMB_LOG_SLOTS);
+                bool done = false;
+                for (int pr = 0; pr < 8 && !done; ++pr) {
+                    const uint32_t old = atomicCAS(&s_key[slot], CMB_EMPTY, idx[c]);
+                    if (old == CMB_EMPTY || old == idx[c]) {
+                        if (old == CMB_EMPTY) s_list[atomicAdd(claimed, 1)] = (uint16_t)slot;
+                        atomicAdd(&s_val[slot].x, v0[c]);
+                        atomicAdd(&s_val[slot].y, v1[c]);
+                        done = true;
+                    } else {
+                        slot = (slot + 1) & (CMB_SLOTS - 1);
+                    }
+                }
+                if (done) todo &= ~(1u << c);
+            }
+        }
+        // ... and whatever is left straight to the table: both features in ONE 64-bit compare-and-swap (atomics.hpp), the eight
+        // loads and then the eight swaps issued back to back so that their latencies overlap
+#ifndef GS_HG_DIRECT_PAIR
+#define GS_HG_DIRECT_PAIR 1
+#endif
+        if (todo && !GS_HG_DIRECT_PAIR) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if ((todo >> c) & 1u) {
+                    if (v0[c] != 0.f) atomicAdd(&gtab[(int64_t)idx[c] * 2], v0[c]);
+                    if (v1[c] != 0.f) atomicAdd(&gtab[(int64_t)idx[c] * 2 + 1], v1[c]);
+                }
+        } else if (todo) {
+            union PairBits {
+                unsigned long long u;
+                float2 f;
+            };
+            PairBits cur[8], seen[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if ((todo >> c) & 1u)
+                    cur[c].u = __hip_atomic_load(reinterpret_cast<unsigned long long*>(gtab) + idx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if ((todo >> c) & 1u) {
+                    PairBits nxt;
+                    nxt.f = make_float2(cur[c].f.x + v0[c], cur[c].f.y + v1[c]);
+                    seen[c].u = atomicCAS(reinterpret_cast<unsigned long long*>(gtab) + idx[c], cur[c].u, nxt.u);
+                }
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (((todo >> c) & 1u) && seen[c].u != cur[c].u) {      // lost a race: retry from the value the swap returned
+                    PairBits c2 = seen[c];
+                    for (;;) {
+                        PairBits nxt;
+                        nxt.f = make_float2(c2.f.x + v0[c], c2.f.y + v1[c]);
+                        const unsigned long long sn = atomicCAS(reinterpret_cast<unsigned long long*>(gtab) + idx[c], c2.u, nxt.u);
+                        if (sn == c2.u) break;
+                        c2.u = sn;
+                    }
+                }
+        }
+        if (__syncthreads_or(combine)) {           // workgroup-uniform; the barrier also orders the inserts before the flush
+            const int n = *claimed;
+            for (int j = tid; j < n; j += 256) {
+                const int s = s_list[j];
+                const uint32_t k = s_key[s];
+                const float2 v = s_val[s];
+                // two float atomics: coarse entries are shared by many tiles, where compare-and-swap retries cost what they save
+                if (v.x != 0.f) atomicAdd(&gtab[(int64_t)k * 2], v.x);
+                if (v.y != 0.f) atomicAdd(&gtab[(int64_t)k * 2 + 1], v.y);
+                s_key[s] = CMB_EMPTY;
+                s_val[s] = make_float2(0.f, 0.f);
+            }
             __syncthreads();
+            if (tid == 0) *claimed = 0;      // this bank is next used two steps on, behind the next step's barrier
         }
     }
     if (active && A.g_pos) {
