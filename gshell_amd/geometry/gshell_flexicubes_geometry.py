@@ -74,5 +74,5 @@ class GShellFlexiCubesGeometry(GShellTetsGeometry):
     def tick(self, glctx, target, lgt, opt_material, loss_fn, iteration, denoiser):
         img_loss, depth_loss, reg_loss = GShellTetsGeometry.tick(self, glctx, target, lgt, opt_material, loss_fn, iteration, denoiser)
         flexi_reg = self.gflexi_reg_loss * 0.25                                # reference :358
-        self.last_terms['global'] = self.last_terms['global'] + flexi_reg
+        self.last_terms.add('global', flexi_reg)
         return img_loss, depth_loss, reg_loss + flexi_reg

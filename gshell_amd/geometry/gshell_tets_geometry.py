@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib
-from .._lib import c_int64, check, ptr, stream
+from .._lib import c_float, c_int64, check, ptr, stream
 from ..render import mesh, optixutils as ou, regularizer, render
 from .gshell_tets import GShell_Tets
 from .mlp import MLP, eikonal_sq_sum, forward_row_sharded, forward_row_sparse_backward
@@ -46,6 +46,64 @@ def compute_sdf_reg_loss(sdf, all_edges):
     if all_edges.dtype != torch.int32:
         all_edges = all_edges.int()
     return _SdfRegFn.apply(sdf, all_edges.contiguous())
+
+
+class _MsdfRegFn(torch.autograd.Function):
+    """(open_w * sum_i huber(clamp(msdf_i, min=-eps) + eps),  close_w * sum_j w_j huber(clamp(b_j, max=eps) - eps)) as one kernel
+    each way (gs_msdf_reg_*): the mSDF regularisers of the reference's tick (:326-358)."""
+
+    @staticmethod
+    def forward(ctx, msdf, boundary, weight, eps, open_w, close_w):
+        m = msdf.detach().reshape(-1).contiguous().float()
+        b = boundary.detach().reshape(-1).contiguous().float()
+        w = None if weight is None else weight.detach().reshape(-1).contiguous().float()
+        out = torch.empty(2, dtype=torch.float32, device=m.device)
+        with torch.cuda.device(m.device):
+            check(_lib.lib().gs_msdf_reg_fwd(ptr(m, torch.float32, "msdf"), c_int64(m.numel()), ptr(b), ptr(w), c_int64(b.numel()), c_float(eps),
+                                             c_float(open_w), c_float(close_w), ptr(out), stream()), "gs_msdf_reg_fwd")
+        ctx.save_for_backward(m, b, w)
+        ctx.k = (float(eps), float(open_w), float(close_w), msdf.shape, boundary.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        m, b, w = ctx.saved_tensors
+        eps, open_w, close_w, sm, sb = ctx.k
+        g_c = g.detach().contiguous().float()
+        g_m = torch.empty_like(m) if ctx.needs_input_grad[0] else None
+        g_b = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(m.device):
+            check(_lib.lib().gs_msdf_reg_bwd(ptr(m), c_int64(m.numel()), ptr(b), ptr(w), c_int64(b.numel()), c_float(eps), c_float(open_w),
+                                             c_float(close_w), ptr(g_c), ptr(g_m), ptr(g_b), stream()), "gs_msdf_reg_bwd")
+        return (None if g_m is None else g_m.reshape(sm)), (None if g_b is None else g_b.reshape(sb)), None, None, None, None
+
+
+class _LossTerms:
+    """tick's loss terms by how they combine across view-sharded ranks; a group is summed when it is asked for"""
+
+    def __init__(self, groups, total):
+        self._groups, self._total = groups, total
+
+    def __getitem__(self, k):
+        return self._total(self._groups[k])
+
+    def get(self, k, default=None):
+        return self[k] if k in self._groups else default
+
+    def __setitem__(self, k, v):
+        self._groups[k] = [v]
+
+    def add(self, k, t):
+        self._groups[k] = list(self._groups[k]) + [t]
+
+
+def boundary_weight(tri_i32, flags_u8, n_watertight, n_boundary):
+    """visible_boundary_weight as ONE kernel (gs_boundary_weight: plain stores of 1.0, no atomics, no index arithmetic in ATen)."""
+    w = torch.empty(n_boundary, dtype=torch.float32, device=tri_i32.device)
+    with torch.cuda.device(tri_i32.device):
+        check(_lib.lib().gs_boundary_weight(ptr(tri_i32, torch.int32, "tri"), ptr(flags_u8, torch.uint8, "flags"), c_int64(tri_i32.shape[0]),
+                                            c_int64(n_watertight), c_int64(n_boundary), ptr(w), stream()), "gs_boundary_weight")
+    return w
 
 
 def visible_boundary_weight(tri, tri_flags, n_watertight, n_boundary):
@@ -252,6 +310,18 @@ class GShellTetsGeometry(torch.nn.Module):
                                                          shadow_scale=shadow_scale, extra_dict={'msdf': d['msdf']})
         return d
 
+    def _frame_sum_weights(self, dev, n_px, with_msdf, with_light):
+        """constant weight vectors over regularizer.frame_sums' nine sums: (image terms, regulariser terms); cached on the device"""
+        FL = self.FLAGS
+        key = (str(dev), n_px, with_msdf, with_light, FL.lambda_diffuse, FL.lambda_kd, FL.lambda_ks, FL.lambda_nrm)
+        cache = self.__dict__.setdefault('_fs_weights', {})
+        if key not in cache:
+            w_img = [1.0 / n_px, 0.5 / n_px if with_msdf else 0.0, 0.5 / n_px if with_msdf else 0.0, 0, 0, 0, 0, 0, 0]
+            w_reg = [0, 0, 0, FL.lambda_diffuse / n_px if with_light else 0.0, 0, 0, FL.lambda_kd / n_px, FL.lambda_ks / (3 * n_px),
+                     FL.lambda_nrm / (3 * n_px)]
+            cache[key] = (torch.tensor(w_img, dtype=torch.float32, device=dev), torch.tensor(w_reg, dtype=torch.float32, device=dev))
+        return cache[key]
+
     def tick(self, glctx, target, lgt, opt_material, loss_fn, iteration, denoiser):
         FL = self.FLAGS
         t_iter = iteration / FL.iter
@@ -269,22 +339,27 @@ class GShellTetsGeometry(torch.nn.Module):
         stacked = getattr(buffers, 'stacked', None)
         fs = regularizer.frame_sums(stacked, color_ref) if (stacked is not None and getattr(FL, "fused_frame_sums", True)) else None
         n_px = float(gt_mask.numel())
+        shard = getattr(FL, "view_shard", None)
+        world = shard.world if shard is not None else 1
+        use_fs_msdf = fs is not None and 'msdf_image' in buffers
+        has_spec = fs is not None and 'diffuse_light' in buffers and 'specular_light' in buffers
         if fs is not None:
-            img_loss = fs[0] / n_px
+            # every term that is LINEAR in the nine frame sums comes out of two dot products with constant weight vectors (the scalar
+            # algebra of the reference's tick is ~140 five-microsecond launches per iteration when written operator by operator)
+            w_img, w_reg = self._frame_sum_weights(dev, n_px, use_fs_msdf, 'diffuse_light' in buffers)
+            img_loss = torch.dot(fs, w_img)
         else:
             img_loss = F.mse_loss(buffers['shaded'][..., 3:], gt_mask)
         img_loss = img_loss + loss_fn(buffers['shaded'][..., 0:3] * gt_mask, color_ref[..., 0:3] * gt_mask)
-        if fs is not None and 'msdf_image' in buffers:
-            img_loss = img_loss + 5e-1 * (fs[1] + fs[2]) / n_px
-        else:
+        if not use_fs_msdf:
             msdf_img = buffers['msdf_image']
             img_loss = img_loss + 5e-1 * F.l1_loss(msdf_img.clamp(min=0) * (gt_mask == 0).float(), torch.zeros_like(gt_mask))
             img_loss = img_loss + 5e-1 * F.l1_loss(msdf_img.clamp(max=0) * (gt_mask == 1).float(), torch.ones_like(gt_mask))
         depth_loss = torch.zeros((), device=dev)         # use_depth is off in every reference config
 
-        shard = getattr(FL, "view_shard", None)
-        world = shard.world if shard is not None else 1
-        presharded = torch.zeros((), device=dev)      # terms whose SUM over ranks is the single-GPU term (weight 1 in the sharded loss)
+        glob = []            # terms that do not depend on the local views (identical on every rank)
+        presharded = []      # terms whose SUM over ranks is the single-GPU term (weight 1 in the sharded loss)
+        per_view = []        # per-view means besides img_loss
 
         # ---- eikonal on the SDF network at surface samples (reference :302-324)
         if d.get('eikonal') is not None:
@@ -295,76 +370,68 @@ class GShellTetsGeometry(torch.nn.Module):
                 eik_coeff = 3e-1 if iteration < 500 else (1e-1 if iteration < 2000 else 1e-2)
             else:
                 eik_coeff = FL.eikonal_scale
-            if world > 1:
-                presharded = presharded + eik_coeff * eik_sum / n_total
-                eik_loss = torch.zeros((), device=dev)
-            else:
-                eik_loss = eik_coeff * eik_sum / n_total
-        else:
-            eik_loss = torch.zeros((), device=dev)
+            (presharded if world > 1 else glob).append(eik_sum * (eik_coeff / n_total))
 
-        # ---- mSDF open / close regularisers (reference :326-358)
-        if FL.use_mesh_msdf_reg:
+        # ---- mSDF open / close regularisers (reference :326-358), one kernel each way
+        if FL.use_mesh_msdf_reg and (FL.msdf_reg_open_scale > 0 or FL.msdf_reg_close_scale != 0):
             regscale = (64 / self.grid_res) ** 3
-            eps = torch.full((1,), 1e-3, device=dev)          # torch.full: no host->device copy (a pageable H2D copy stalls the queue)
-            if FL.msdf_reg_open_scale > 0:
-                m = d['msdf'].clamp(min=-eps).reshape(-1)
-                msdf_reg = FL.msdf_reg_open_scale * regscale * F.huber_loss(m, -eps.expand(d['msdf'].size(0)), reduction='sum')
-            else:
-                msdf_reg = torch.zeros((), device=dev)
+            vis_w = None
             if FL.msdf_reg_close_scale != 0:
                 # boundary vertices of the triangles seen by ANY view (reference :344-348), without the reference's two
-                # data-dependent compactions (unique ids -> index list -> boolean mask): the rasteriser's per-triangle flags are
-                # scattered (max) onto the boundary vertices and the Huber terms are summed under that 0/1 weight -- no host sync
+                # data-dependent compactions (unique ids -> index list -> boolean mask): the rasteriser's per-triangle flags
+                # are scattered onto the boundary vertices and the Huber terms are summed under that 0/1 weight -- no host sync
                 with torch.no_grad():
                     nwt = d['n_verts_watertight']
-                    tri = d['imesh'].t_pos_idx
+                    imesh = d['imesh']
+                    tri_i32 = imesh.faces_i32() if hasattr(imesh, 'faces_i32') else imesh.t_pos_idx.int()
                     flags = getattr(buffers, 'visible_flags', None)
                     if flags is None:
-                        flags = torch.zeros(tri.size(0), dtype=torch.int32, device=dev)
+                        flags = torch.zeros(tri_i32.size(0), dtype=torch.uint8, device=dev)
                         flags[buffers['visible_triangles']] = 1
-                    flags = flags.to(torch.int32)
                     if world > 1:     # union over the views of the global batch
-                        flags = flags.clone()
-                        shard.all_reduce_max(flags)
-                    vis_w = visible_boundary_weight(tri, flags, nwt, d['msdf_boundary'].size(0))
-                bm_all = d['msdf_boundary'].reshape(-1)
-                msdf_reg = msdf_reg + FL.msdf_reg_close_scale * regscale * (
-                    F.huber_loss(bm_all.clamp(max=eps), eps.expand(bm_all.size(0)), reduction='none') * vis_w).sum()
-        else:
-            msdf_reg = torch.zeros((), device=dev)
+                        fl32 = flags.to(torch.int32)
+                        shard.all_reduce_max(fl32)
+                        flags = fl32.to(torch.uint8)
+                    vis_w = boundary_weight(tri_i32.contiguous(), flags.to(torch.uint8).contiguous(), int(nwt), d['msdf_boundary'].size(0))
+            two = _MsdfRegFn.apply(d['msdf'], d['msdf_boundary'], vis_w, 1e-3, max(FL.msdf_reg_open_scale, 0.0) * regscale,
+                                   FL.msdf_reg_close_scale * regscale)
+            glob.append(two.sum())
 
         sdf_weight = FL.sdf_regularizer - (FL.sdf_regularizer - 0.01) * min(1.0, 4.0 * t_iter)
-        sdf_reg = compute_sdf_reg_loss(d['sdf'], self.all_edges).mean() * sdf_weight
+        glob.append(compute_sdf_reg_loss(d['sdf'], self.all_edges) * sdf_weight)
 
-        if 'diffuse_light' not in buffers:
-            monochrome = torch.zeros_like(img_loss)
-        elif fs is not None and 'specular_light' in buffers and world > 1:
-            # the specular / diffuse energy ratio is a ratio of GLOBAL-batch means (regularizer.py:43-51): all-reduce the two
-            # luma sums (no_grad) and back-propagate the linearisation  d(S4/S5) = ds4_r / S5 - S4 / S5^2 ds5_r  per rank;
-            # the values sum to the global ratio over the ranks, the gradients sum to its gradient
-            with torch.no_grad():
-                S = torch.stack((fs[4], fs[5]))
-                shard.all_reduce_sum(S)
-            n_glob = n_px * world
-            ratio = fs[4] / S[1] - (S[0] / (S[1] * S[1])) * (fs[5] - fs[5].detach())
-            clamped = fs[4] / (1e-3 * n_glob)
-            presharded = presharded + torch.where(S[1] / n_glob >= 1e-3, ratio, clamped) * FL.lambda_specular
-            monochrome = fs[3] / n_px * FL.lambda_diffuse
-        elif fs is not None and 'specular_light' in buffers:
-            monochrome = fs[3] / n_px * FL.lambda_diffuse + (fs[4] / n_px) / (fs[5] / n_px).clamp_min(1e-3) * FL.lambda_specular
-        else:
-            monochrome = regularizer.shading_loss(buffers['diffuse_light'], buffers['specular_light'], color_ref, FL.lambda_diffuse,
-                                                  FL.lambda_specular)
         if fs is not None:
-            mtl_smooth = fs[6] / n_px * FL.lambda_kd + fs[7] / (3 * n_px) * FL.lambda_ks + fs[8] / (3 * n_px) * FL.lambda_nrm
+            per_view.append(torch.dot(fs, w_reg))        # diffuse monochrome term + material smoothness
+            if has_spec and world > 1:
+                # the specular / diffuse energy ratio is a ratio of GLOBAL-batch means (regularizer.py:43-51): all-reduce the two
+                # luma sums (no_grad) and back-propagate the linearisation  d(S4/S5) = ds4_r / S5 - S4 / S5^2 ds5_r  per rank;
+                # the values sum to the global ratio over the ranks, the gradients sum to its gradient
+                with torch.no_grad():
+                    S = torch.stack((fs[4], fs[5]))
+                    shard.all_reduce_sum(S)
+                n_glob = n_px * world
+                ratio = fs[4] / S[1] - (S[0] / (S[1] * S[1])) * (fs[5] - fs[5].detach())
+                clamped = fs[4] / (1e-3 * n_glob)
+                presharded.append(torch.where(S[1] / n_glob >= 1e-3, ratio, clamped) * FL.lambda_specular)
+            elif has_spec:
+                per_view.append(fs[4] / fs[5].clamp_min(1e-3 * n_px) * FL.lambda_specular)      # = mean / clamp(mean, 1e-3)
         else:
-            mtl_smooth = regularizer.material_smoothness_grad(buffers['kd_grad'], buffers['ks_grad'], buffers['normal_grad'], lambda_kd=FL.lambda_kd,
-                                                              lambda_ks=FL.lambda_ks, lambda_nrm=FL.lambda_nrm)
-        chroma = regularizer.chroma_loss(buffers['kd'], color_ref, FL.lambda_chroma) if FL.lambda_chroma != 0 else torch.zeros_like(img_loss)
-        reg_loss = (sdf_reg + eik_loss + msdf_reg) + (monochrome + mtl_smooth + chroma) + presharded
+            if 'diffuse_light' in buffers:
+                per_view.append(regularizer.shading_loss(buffers['diffuse_light'], buffers['specular_light'], color_ref, FL.lambda_diffuse,
+                                                         FL.lambda_specular))
+            per_view.append(regularizer.material_smoothness_grad(buffers['kd_grad'], buffers['ks_grad'], buffers['normal_grad'],
+                                                                 lambda_kd=FL.lambda_kd, lambda_ks=FL.lambda_ks, lambda_nrm=FL.lambda_nrm))
+        if FL.lambda_chroma != 0:
+            per_view.append(regularizer.chroma_loss(buffers['kd'], color_ref, FL.lambda_chroma))
+
+        def total(ts):
+            acc = None
+            for t in ts:
+                acc = t if acc is None else acc + t
+            return acc if acc is not None else torch.zeros((), device=dev)
+
+        reg_loss = total(glob + per_view + presharded)
         # decomposition for view-sharded training: per-view means, terms that do not depend on the local views (identical on
-        # every rank), and terms already split over the ranks (eikonal samples, linearised energy ratio)
-        self.last_terms = {'per_view': img_loss + monochrome + mtl_smooth + chroma, 'global': sdf_reg + eik_loss + msdf_reg,
-                           'presharded': presharded}
+        # every rank), and terms already split over the ranks (eikonal samples, linearised energy ratio); summed on demand
+        self.last_terms = _LossTerms({'per_view': [img_loss] + per_view, 'global': glob, 'presharded': presharded}, total)
         return img_loss, depth_loss, reg_loss

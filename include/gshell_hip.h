@@ -413,6 +413,24 @@ int gs_texmlp_bwd_level_major(const float* x, const float* mask, int64_t N, cons
                               float* g_w2, float* g_w3, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * mSDF open / close regularisers   (replaces geometry/gshell_tets_geometry.py:326-358: Huber (delta 1) of
+ *   clamp(msdf, min=-eps) to -eps over ALL grid values, and of clamp(msdf_boundary, max=eps) to +eps over the boundary
+ *   vertices of the triangles some view saw)
+ *   gs_boundary_weight: weight [n_boundary] f32 WRITTEN: 1 where mesh vertex n_watertight + k belongs to a triangle with
+ *     flags[t] != 0 (the rasteriser's per-triangle visibility flags, u8), else 0 -- the reference's vis_mask (:344-348).
+ *   fwd: out2 [2] f32 WRITTEN = (open_w * sum_i huber, close_w * sum_j weight_j huber)  (weight NULL = no close term).
+ *   bwd: g_out2_dev [2] device; g_msdf [N], g_boundary [n_boundary] WRITTEN (either may be NULL).
+ * ---------------------------------------------------------------------------------- */
+int gs_boundary_weight(const int32_t* tri, const uint8_t* flags, int64_t T, int64_t n_watertight,
+                       int64_t n_boundary, float* weight, gs_stream_t stream);
+int gs_msdf_reg_fwd(const float* msdf, int64_t N, const float* msdf_boundary, const float* weight,
+                    int64_t n_boundary, float eps, float open_w, float close_w, float* out2,
+                    gs_stream_t stream);
+int gs_msdf_reg_bwd(const float* msdf, int64_t N, const float* msdf_boundary, const float* weight,
+                    int64_t n_boundary, float eps, float open_w, float close_w,
+                    const float* g_out2_dev, float* g_msdf, float* g_boundary, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * SDF sign-consistency regulariser   (replaces compute_sdf_reg_loss,
  *   geometry/gshell_tets_geometry.py:33-39, evaluated over ALL grid edges every iteration :361-362)
  *   sdf [N] f32, edges [E,2] i32 (the static sorted edge list of gs_mtets_topo).

@@ -247,3 +247,45 @@ def test_sdf_net_torch_formulation_fast_paths_match_plain_modules():
     assert float((g1 - g0).abs().max()) <= 1e-4 * float(g0.abs().max())
     for a, b in zip(p1, p0):
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize("N,nb,T", [(5000, 700, 1500), (300001, 40000, 90000), (64, 0, 10)])
+def test_msdf_regularisers_match_the_reference_formulation(N, nb, T):
+    """gs_boundary_weight + gs_msdf_reg_fwd/bwd vs the reference's operator sequence (geometry/gshell_tets_geometry.py:326-358:
+    clamp -> huber_loss(reduction='sum') against -eps / +eps, the close term over the boundary vertices of visible triangles).
+    Values 2e-6 relative (fp32 sums in a different order), gradients 1e-6 (fp32 v + eps against the float64 reference)."""
+    import torch.nn.functional as F
+    from gshell_amd.geometry.gshell_tets_geometry import _MsdfRegFn, boundary_weight, visible_boundary_weight
+    g = torch.Generator().manual_seed(N)
+    msdf = (torch.randn(N, generator=g) * 0.8)
+    msdf[:8] = torch.tensor([-1e-3, 1e-3, 0.0, -2.0, 2.0, -0.9995, 0.9995, 1.5])
+    nwt = 1000
+    bnd = torch.randn(nb, 1, generator=g) * 0.7
+    tri = torch.randint(0, nwt + max(nb, 1), (T, 3), generator=g).int()
+    flags = (torch.rand(T, generator=g) > 0.6).to(torch.uint8)
+    open_w, close_w, eps = 0.37, 1.3, 1e-3
+    # reference formulation, float64 on the CPU
+    m64 = msdf.double().requires_grad_(True)
+    b64 = bnd.double().requires_grad_(True)
+    vis = torch.zeros(nb, dtype=torch.bool)
+    vt = tri[flags.bool()].reshape(-1).long() - nwt
+    vt = vt[(vt >= 0) & (vt < nb)]
+    vis[vt] = True
+    e = torch.full((1,), eps, dtype=torch.float64)
+    want_open = open_w * F.huber_loss(m64.clamp(min=-e), -e.expand(N), reduction='sum')
+    bm = b64.reshape(-1)[vis]
+    want_close = close_w * F.huber_loss(bm.clamp(max=e), e.expand(bm.numel()), reduction='sum') if bm.numel() else torch.zeros((), dtype=torch.float64)
+    (2.0 * want_open + 3.0 * want_close).backward()
+    # HIP
+    md, bd = msdf.to(DEV).requires_grad_(True), bnd.to(DEV).requires_grad_(True)
+    w = boundary_weight(tri.to(DEV), flags.to(DEV), nwt, nb)
+    assert torch.equal(w.cpu() > 0, vis)
+    if nb:
+        assert torch.equal(w, visible_boundary_weight(tri.to(DEV).long(), flags.to(DEV).int(), nwt, nb))
+    two = _MsdfRegFn.apply(md, bd, w, eps, open_w, close_w)
+    (2.0 * two[0] + 3.0 * two[1]).backward()
+    assert abs(float(two[0]) - float(want_open)) <= 2e-6 * abs(float(want_open)) + 1e-12
+    assert abs(float(two[1]) - float(want_close)) <= 2e-6 * abs(float(want_close)) + 1e-12
+    assert torch.allclose(md.grad.cpu().double(), m64.grad, rtol=1e-6, atol=1e-9)
+    if nb:
+        assert torch.allclose(bd.grad.cpu().double(), b64.grad, rtol=1e-6, atol=1e-9)
