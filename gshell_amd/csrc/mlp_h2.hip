@@ -1074,6 +1074,38 @@ int launch_fwd(const H2Args& A, int64_t tiles, hipStream_t stream) {
     return 0;
 }
 
+
+// Eikonal term on the <EIK> planes: virtual row 64 t + 16 c + j holds f (c = 0) and df/dx_{c-1} (c = 1..3) of sample 16 t + j.
+// loss += sum_i (|J_i| - 1)^2;  g_unit = d loss / d (virtual row outputs) -- scaled by the upstream scalar in the backward pass.
+__global__ void __launch_bounds__(256) k_eikonal_loss(const float* __restrict__ out, int64_t n, int64_t tiles, float* __restrict__ loss,
+                                                      float* __restrict__ g_unit) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float acc = 0.f;
+    if (s < tiles * 16) {
+        const int64_t base = (s >> 4) * 64 + (s & 15);
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (s < n) {
+            const float jx = out[base + 16], jy = out[base + 32], jz = out[base + 48];
+            const float nrm = sqrtf(jx * jx + jy * jy + jz * jz);
+            acc = (nrm - 1.0f) * (nrm - 1.0f);
+            const float k = 2.0f * (nrm - 1.0f) / fmaxf(nrm, 1e-20f);
+            gx = k * jx; gy = k * jy; gz = k * jz;
+        }
+        g_unit[base] = 0.f;
+        g_unit[base + 16] = gx;
+        g_unit[base + 32] = gy;
+        g_unit[base + 48] = gz;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    __shared__ float sw[4];
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+        if (t != 0.f) atomicAdd(loss, t);
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t gs_sdf_mlp_h2_packed_bytes(int n_freq, int n_hidden, int skip_layer) {
@@ -1214,6 +1246,17 @@ extern "C" int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, cons
         W.only_output = 1;
         hipLaunchKernelGGL(k_h2_wgrad, dim3((unsigned)strips, 1), dim3(NT), SMEM_WGRAD_BYTES, (hipStream_t)stream, W);
     }
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_sdf_eikonal_loss(const float* out_rows, int64_t n, int64_t rows_padded, float* loss, float* g_unit, gs_stream_t stream) {
+    GS_REQUIRE(loss && (rows_padded == 0 || (out_rows && g_unit)), "gs_sdf_eikonal_loss: null pointer");
+    GS_REQUIRE(rows_padded % 64 == 0 && 4 * n <= rows_padded, "gs_sdf_eikonal_loss: rows_padded must be gs_sdf_mlp_h2_rows_padded(2, n)");
+    GS_HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream));
+    const int64_t tiles = rows_padded / 64;
+    if (tiles == 0) return 0;
+    hipLaunchKernelGGL(k_eikonal_loss, dim3((unsigned)gs::cdiv(tiles * 16, 256)), dim3(256), 0, (hipStream_t)stream, out_rows, n, tiles, loss, g_unit);
     GS_LAUNCH_CHECK();
     return 0;
 }

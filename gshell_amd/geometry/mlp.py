@@ -4,6 +4,7 @@ skip-concatenation of the encoding -> Linear(d_hidden, d_out).  Module / paramet
 `state_dict()` round-trips ("sdf_net.net.<i>.weight").
 
 This file is the plain-torch (rocBLAS) formulation; the fused MFMA kernel path is gshell_amd/csrc/mlp.hip."""
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -253,6 +254,54 @@ def fused_forward(net, x, precision=None, occ_bits_ptr=None):
     return out[:, None]
 
 
+class _ParamGate(torch.autograd.Function):
+    """All parameters of the network behind ONE autograd edge.  The chain kernels write every parameter gradient of a pass into
+    one flat buffer; with the 16 parameters as 16 inputs of each pass the engine sums the grid pass and the eikonal pass with
+    16 `add` launches and zero-fills 16 buffers per pass.  The gate's output is an uninitialised flat TOKEN (its values are
+    never read: the kernels take the parameters' own device pointers); a pass returns its flat gradient for the token, the
+    engine adds the passes with one launch, and the gate hands each parameter its view of the sum."""
+
+    @staticmethod
+    def forward(ctx, *params):
+        ctx.shapes = [p.shape for p in params]
+        return torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=params[0].device)
+
+    @staticmethod
+    def backward(ctx, g):
+        out, off = [], 0
+        for shp in ctx.shapes:
+            n = int(np.prod(shp)) if len(shp) else 1
+            out.append(g[off:off + n].view(shp))
+            off += n
+        return tuple(out)
+
+
+def param_gate(net, reuse=False):
+    """a token for this forward pass; `reuse` = take the one the grid pass of the same iteration left on the network"""
+    if reuse:
+        g = net.__dict__.pop("_gs_gate", None)
+        if g is not None:
+            return g
+    g = _ParamGate.apply(*list(net.parameters()))
+    if not reuse:
+        net.__dict__["_gs_gate"] = g
+    return g
+
+
+def split_param_grads(net, flat):
+    """flat gradient (parameter order) -> list of views shaped like net.parameters()"""
+    out, off = [], 0
+    for p in net.parameters():
+        out.append(flat[off:off + p.numel()].view(p.shape))
+        off += p.numel()
+    return out
+
+
+def _flat_grads(params, grads):
+    """list of per-parameter gradients -> one flat tensor (the torch fallback paths)"""
+    return torch.cat([(torch.zeros_like(p) if g is None else g).reshape(-1).float() for p, g in zip(params, grads)])
+
+
 class _RowSparseBackward(torch.autograd.Function):
     """y = net(x) over ALL rows, backward only over the rows whose upstream gradient is non-zero.
 
@@ -264,7 +313,7 @@ class _RowSparseBackward(torch.autograd.Function):
     recomputed in the backward pass."""
 
     @staticmethod
-    def forward(ctx, x, net, sign_sink, *params):
+    def forward(ctx, x, net, sign_sink, gate):
         with torch.no_grad():
             presign = sign_sink is not None and SDF_MLP_PRECISION == "h2" and _fusable(net, x) and sign_sink.N == x.shape[0]
             y = (fused_forward(net, x, occ_bits_ptr=sign_sink.occ_bits_ptr() if presign else None) if _fusable(net, x) else net(x))
@@ -276,8 +325,8 @@ class _RowSparseBackward(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_y):
         (x,) = ctx.saved_tensors
-        g_x, g_params = row_sparse_backward(ctx.net, x, g_y, ctx.needs_input_grad[0])
-        return (g_x, None, None) + tuple(g_params)
+        g_x, g_flat = row_sparse_backward(ctx.net, x, g_y, ctx.needs_input_grad[0])
+        return g_x, None, None, g_flat
 
 
 def row_sparse_backward_torch(net, x, g_y, need_x):
@@ -287,7 +336,7 @@ def row_sparse_backward_torch(net, x, g_y, need_x):
     rows = torch.nonzero(g_y.reshape(x.shape[0], -1).abs().sum(dim=1) != 0).reshape(-1)      # one host sync
     g_x = torch.zeros_like(x) if need_x else None
     if rows.numel() == 0:
-        return g_x, [torch.zeros_like(p) for p in params]
+        return g_x, _flat_grads(params, [None] * len(params))
     x_a = x[rows].detach().requires_grad_(need_x)
     with torch.enable_grad():
         y_a = net(x_a)
@@ -295,7 +344,7 @@ def row_sparse_backward_torch(net, x, g_y, need_x):
     if need_x:
         g_x[rows] = grads[0]
         grads = grads[1:]
-    return g_x, [torch.zeros_like(p) if g is None else g for p, g in zip(params, grads)]
+    return g_x, _flat_grads(params, grads)
 
 
 def _ptr_array(tensors):
@@ -326,7 +375,8 @@ class _SavedChain:
                   "gs_sdf_mlp_h2_save_fwd")
 
     def backward(self, g_out, g_x=None):
-        """g_out [Rpad] per virtual row -> ([d loss / d p for p in net.parameters()]); g_x [N,3] is filled in place (mode 1)."""
+        """g_out [Rpad] per virtual row -> the gradients of net.parameters() as ONE flat tensor (parameter order); g_x [N,3] is
+        filled in place (mode 1)."""
         L = _lib.lib()
         dev = g_out.device
         D = torch.empty_like(self.A)
@@ -350,11 +400,11 @@ class _SavedChain:
                   "gs_sdf_mlp_h2_wgrad")
         if self.mode == 1:      # output bias: sum of the upstream gradient over the (value) rows
             db[-1].copy_(g_out.sum().reshape(db[-1].shape))
-        return [grads[id(p)] for p in params]
+        return flat
 
 
 def row_sparse_backward(net, x, g_y, need_x):
-    """(d loss / d x [N,3] or None, [d loss / d p for p in net.parameters()]) from the upstream gradient g_y [N,1],
+    """(d loss / d x [N,3] or None, flat gradient of net.parameters()) from the upstream gradient g_y [N,1],
     touching only the rows where g_y != 0: they are recomputed by the h2 chain kernels (csrc/mlp_h2.hip: forward with saved
     planes -> backward chain -> weight gradients on the matrix cores); the full-grid forward pass keeps no activations."""
     if not (_fusable(net, x) and g_y.is_cuda):
@@ -381,7 +431,7 @@ def row_sparse_backward(net, x, g_y, need_x):
     rows = torch.nonzero(g != 0).reshape(-1).int()                  # one host sync (the count sizes the saved planes)
     n = int(rows.numel())
     if n == 0:
-        return g_x, [torch.zeros_like(p) for p in net.parameters()]
+        return g_x, torch.zeros(sum(p.numel() for p in net.parameters()), dtype=torch.float32, device=x.device)
     saved = _SavedChain(net, 1, x.detach().contiguous(), rows, n)
     g_rows = torch.zeros((saved.Rpad,), dtype=torch.float32, device=x.device)
     g_rows[:n] = g[rows.long()]
@@ -417,36 +467,30 @@ class _EikonalFn(torch.autograd.Function):
     (4 virtual rows per sample), then ONE reverse pass over those rows -- no double backward, no hipBLASLt."""
 
     @staticmethod
-    def forward(ctx, pts, net, *params):
+    def forward(ctx, pts, net, gate):
         n = pts.shape[0]
         saved = _SavedChain(net, 2, pts.detach().contiguous().float(), None, n)
-        tiles = saved.Rpad // 64
-        J = saved.out.view(tiles, 4, 16)[:, 1:4, :].permute(0, 2, 1).reshape(tiles * 16, 3)[:n]
-        nrm = J.pow(2).sum(dim=-1).sqrt()
-        ctx.saved, ctx.n = saved, n
-        ctx.save_for_backward(J, nrm)
-        return (nrm - 1).pow(2).sum()
+        loss = torch.empty(1, dtype=torch.float32, device=pts.device)
+        g_unit = torch.empty_like(saved.out)
+        with torch.cuda.device(pts.device):
+            check(_lib.lib().gs_sdf_eikonal_loss(ptr(saved.out), c_int64(n), c_int64(saved.Rpad), ptr(loss), ptr(g_unit), stream()), "gs_sdf_eikonal_loss")
+        ctx.saved, ctx.g_unit = saved, g_unit
+        return loss[0]
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
-        J, nrm = ctx.saved_tensors
-        saved, n = ctx.saved, ctx.n
-        tiles = saved.Rpad // 64
-        gJ = (g * 2.0 * (nrm - 1) / nrm.clamp_min(1e-20))[:, None] * J                  # [n,3]
-        gv = torch.zeros((tiles * 16, 4), dtype=torch.float32, device=J.device)
-        gv[:n, 1:4] = gJ
-        g_out = gv.view(tiles, 16, 4).permute(0, 2, 1).contiguous().reshape(-1)       # virtual-row order 64 t + 16 c + i
-        grads = saved.backward(g_out)
-        ctx.saved = None
-        return (None, None) + tuple(grads)
+        saved, g_unit = ctx.saved, ctx.g_unit
+        g_flat = saved.backward(g_unit * g)            # virtual-row order 64 t + 16 c + i
+        ctx.saved = ctx.g_unit = None
+        return None, None, g_flat
 
 
 def eikonal_sq_sum(net, pts):
     """sum_i (|d net / d x (pts_i)| - 1)^2, differentiable w.r.t. the parameters of `net` (the points are constants, as in the
     reference, which detaches them)."""
     if _fusable(net, pts):
-        return _EikonalFn.apply(pts, net, *list(net.parameters()))
+        return _EikonalFn.apply(pts, net, param_gate(net, reuse=True))
     v = pts.detach().requires_grad_(True)
     grad = torch.autograd.grad(net(v).sum(), v, create_graph=True)[0]
     return (grad.pow(2).sum(dim=-1).sqrt() - 1).pow(2).sum()
@@ -461,7 +505,7 @@ class _RowShardedForward(torch.autograd.Function):
     so the replicated extraction still yields identical meshes."""
 
     @staticmethod
-    def forward(ctx, x, net, shard, *params):
+    def forward(ctx, x, net, shard, gate):
         N, world, rank = x.shape[0], shard.world, shard.rank
         per = (N + world - 1) // world
         lo, hi = min(rank * per, N), min((rank + 1) * per, N)
@@ -484,24 +528,24 @@ class _RowShardedForward(torch.autograd.Function):
         g_pad[:N] = g_y.reshape(-1)
         g_loc = ctx.shard.reduce_scatter_sum(g_pad)[:hi - lo]
         need_x = ctx.needs_input_grad[0]
-        g_x_loc, g_params = row_sparse_backward(ctx.net, x[lo:hi].contiguous(), g_loc[:, None], need_x)
+        g_x_loc, g_flat = row_sparse_backward(ctx.net, x[lo:hi].contiguous(), g_loc[:, None], need_x)
         g_x = None
         if need_x:
             g_x = torch.zeros_like(x)
             g_x[lo:hi] = g_x_loc
-        return (g_x, None, None) + tuple(g_params)
+        return g_x, None, None, g_flat
 
 
 def forward_row_sharded(net, x, shard):
     """net(x) with rows sharded over the ranks of `shard` (see _RowShardedForward)."""
-    return _RowShardedForward.apply(x, net, shard, *list(net.parameters()))
+    return _RowShardedForward.apply(x, net, shard, param_gate(net))
 
 
 def forward_row_sparse_backward(net, x, sign_sink=None):
     """net(x) with the row-sparse backward described above (first-order gradients only).  `sign_sink` (a TetTopology): the
     kernel's epilogue also writes the sign bits of the result straight into the extractor's occupancy array; the returned
     tensor is tagged (`_gs_presigned`) so that GShell_Tets skips its own sign pass."""
-    y = _RowSparseBackward.apply(x, net, sign_sink, *list(net.parameters()))
+    y = _RowSparseBackward.apply(x, net, sign_sink, param_gate(net))
     if sign_sink is not None and SDF_MLP_PRECISION == "h2" and _fusable(net, x) and sign_sink.N == x.shape[0]:
         sign_sink.sign_epoch += 1
         y._gs_presigned = (sign_sink, sign_sink.sign_epoch, y._version)

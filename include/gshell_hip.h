@@ -541,6 +541,12 @@ int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, const int64_t* 
                         float* const* dW, float* const* db,
                         int exact_fp32 /* 0: bf16-pair operands on the bf16 matrix path (default); 1: fp32 MFMA */,
                         gs_stream_t stream);
+/* eikonal term on the output column of a mode-2 (value + 3 tangents) gs_sdf_mlp_h2_save_fwd pass of n samples:
+ *   loss [1] WRITTEN = sum_i (|grad f(p_i)| - 1)^2  (geometry/gshell_tets_geometry.py:302-324);
+ *   g_unit [rows_padded] WRITTEN = d loss / d (virtual-row outputs): multiply by the upstream scalar and hand it to
+ *   gs_sdf_mlp_h2_bwd / _wgrad as g_out. */
+int gs_sdf_eikonal_loss(const float* out_rows, int64_t n, int64_t rows_padded, float* loss,
+                        float* g_unit, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * G-FlexiCubes topology   (replaces the index machinery of GShellFlexiCubes.__call__,

@@ -29,7 +29,7 @@ def _rel(a, b):
 @pytest.mark.parametrize("n_hidden,skip_in,need_x,wgrad_fp32", [(6, (3,), True, False), (6, (3,), False, True), (2, (), True, False)])
 def test_row_sparse_backward_matches_float64_autograd(n_hidden, skip_in, need_x, wgrad_fp32, monkeypatch):
     from gshell_amd.geometry import mlp as mlp_mod
-    from gshell_amd.geometry.mlp import row_sparse_backward, row_sparse_backward_torch
+    from gshell_amd.geometry.mlp import row_sparse_backward, row_sparse_backward_torch, split_param_grads
     monkeypatch.setattr(mlp_mod, "SDF_MLP_WGRAD_FP32", wgrad_fp32)       # bf16-pair weight gradients (default) / the exact-fp32 MFMA version
     net = _net(n_hidden, skip_in)
     g = torch.Generator(device=DEV).manual_seed(1)
@@ -39,7 +39,8 @@ def test_row_sparse_backward_matches_float64_autograd(n_hidden, skip_in, need_x,
     idx = torch.arange(0, N, 3, device=DEV)
     # upstream gradients spanning six decades (means over 10^6 pixels give 1e-8 .. 1e-2 in training)
     gy[idx, 0] = torch.randn(idx.numel(), device=DEV, generator=g) * torch.pow(10.0, torch.rand(idx.numel(), device=DEV, generator=g) * 6 - 8)
-    g_x, grads = row_sparse_backward(net, x, gy, need_x)
+    g_x, flat = row_sparse_backward(net, x, gy, need_x)
+    grads = split_param_grads(net, flat)
     net64 = copy.deepcopy(net).double()
     x64 = x.double().requires_grad_(True)
     ref = torch.autograd.grad(net64(x64), [x64] + list(net64.parameters()), gy.double())
@@ -56,7 +57,8 @@ def test_row_sparse_backward_matches_float64_autograd(n_hidden, skip_in, need_x,
         assert a.shape == b.shape
         assert _rel(a, b) < 1e-4, (name, _rel(a, b))
     # and the fp32 torch formulation it replaces is no closer to float64 than a factor of a few
-    _, grads_t = row_sparse_backward_torch(net, x, gy, False)
+    _, flat_t = row_sparse_backward_torch(net, x, gy, False)
+    grads_t = split_param_grads(net, flat_t)
     worst_hip = max(_rel(a, b) for a, b in zip(grads, ref[1:]))
     worst_torch = max(_rel(a, b) for a, b in zip(grads_t, ref[1:]))
     assert worst_hip < max(20 * worst_torch, 2e-6 if wgrad_fp32 else 3e-5), (worst_hip, worst_torch)
@@ -109,7 +111,7 @@ def test_row_sparse_backward_without_host_sync_equals_the_synchronising_path():
     """net._gs_rows_bound (set by GShellTetsGeometry.getMesh to 2 x crossing edges) switches the row-sparse backward to the
     device-side compaction (gs_compact_rows) with planes sized by the bound and the count kept on the device: same gradients as
     the path that waits for torch.nonzero; a violated bound is reported at the next call, not silently truncated."""
-    from gshell_amd.geometry.mlp import row_sparse_backward
+    from gshell_amd.geometry.mlp import row_sparse_backward, split_param_grads
     from gshell_amd._lib import GShellHipError
     net = _net()
     g = torch.Generator(device=DEV).manual_seed(4)
@@ -118,9 +120,11 @@ def test_row_sparse_backward_without_host_sync_equals_the_synchronising_path():
     gy = torch.zeros(N, 1, device=DEV)
     idx = torch.randperm(N, device=DEV, generator=g)[:1500].sort().values
     gy[idx, 0] = torch.randn(idx.numel(), device=DEV, generator=g) * 1e-4
-    gx_a, grads_a = row_sparse_backward(net, x, gy, True)
+    gx_a, flat_a = row_sparse_backward(net, x, gy, True)
+    grads_a = split_param_grads(net, flat_a)
     net._gs_rows_bound = 4000                                     # > 1500 rows, < N
-    gx_b, grads_b = row_sparse_backward(net, x, gy, True)
+    gx_b, flat_b = row_sparse_backward(net, x, gy, True)
+    grads_b = split_param_grads(net, flat_b)
     assert torch.allclose(gx_a, gx_b, rtol=1e-5, atol=1e-12)
     for a, b in zip(grads_a, grads_b):
         assert _rel(b, a) < 2e-5                                  # float-atomic order of the strip sums
