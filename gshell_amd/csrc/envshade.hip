@@ -710,8 +710,26 @@ __host__ __device__ inline int bil_row_stride(int R) {   // pixels; >= 32 + 2R, 
 template <bool BWD>
 __global__ void __launch_bounds__(BIL_NT, 2) k_bilateral_tile(const float* __restrict__ col, const float* __restrict__ nrm, const float* __restrict__ zdz,
                                                                int H, int W, float sigma, int R, float* __restrict__ out,
-                                                               const float* __restrict__ g_out, float* __restrict__ g_col) {
+                                                               const float* __restrict__ g_out, float* __restrict__ g_col,
+                                                               const float* __restrict__ mask) {
     extern __shared__ __attribute__((aligned(16))) float4 bil_smem[];
+    // `mask` (optional): pixels with mask <= 0 are pixels whose filtered value nobody reads (no triangle covers them: the
+    // composite multiplies their buffers by alpha = 0, the shader never looks at their gradient).  They still act as TAPS of
+    // their neighbours, but their own 529-tap loops are skipped -- 85 % of the pixels of the benchmark's views; a tile without a
+    // wanted pixel does not even stage its halo.  Their outputs are written as (0, 0, 0, 1e-4) / zero gradient.
+    bool wanted = true;
+    if (mask) {
+        const int mx = blockIdx.x * BIL_TX + (threadIdx.x & (BIL_TX - 1)), my = blockIdx.y * BIL_TY + threadIdx.x / BIL_TX;
+        wanted = mx < W && my < H && mask[(int64_t)blockIdx.z * H * W + (int64_t)my * W + mx] > 0.0f;
+        if (!__syncthreads_or(wanted)) {
+            if (mx < W && my < H) {
+                const int64_t ci = (int64_t)blockIdx.z * H * W + (int64_t)my * W + mx;
+                if (!BWD) *reinterpret_cast<float4*>(out + 4 * ci) = make_float4(0.f, 0.f, 0.f, 0.0001f);
+                else { g_col[3 * ci] = 0.f; g_col[3 * ci + 1] = 0.f; g_col[3 * ci + 2] = 0.f; }
+            }
+            return;
+        }
+    }
     const int RS = bil_row_stride(R), TH = BIL_TY + 2 * R, TW = BIL_TX + 2 * R;
     float4* sA = bil_smem;                 // [TH][RS]  (nx, ny, nz, z)
     float4* sB = sA + TH * RS;             // [TH][RS]  (dz, c0, c1, c2)   c = colour (fwd) / upstream gradient (bwd)
@@ -747,7 +765,8 @@ __global__ void __launch_bounds__(BIL_NT, 2) k_bilateral_tile(const float* __res
     const float4 ca = sA[(ly + R) * RS + lx + R];
     const float cdz = sB[(ly + R) * RS + lx + R].x;
     float acc_w = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
-    for (int fy = -R; fy <= R; ++fy) {
+    const int R_eff = (mask && __ballot(wanted) == 0ull) ? -1 : R;       // a wave (two tile rows) without a wanted pixel: no taps
+    for (int fy = -R_eff; fy <= R_eff; ++fy) {
         const float4* rowA = sA + (ly + R + fy) * RS + lx + R;
         const float4* rowB = sB + (ly + R + fy) * RS + lx + R;
         const float2* rowT = sT + (fy < 0 ? -fy : fy) * (R + 1);
@@ -771,6 +790,7 @@ __global__ void __launch_bounds__(BIL_NT, 2) k_bilateral_tile(const float* __res
     }
     if (x >= W || y >= H) return;
     const int64_t ci = base + (int64_t)y * W + x;
+    if (!wanted) ax = ay = az = acc_w = 0.f;
     if (!BWD) {
         *reinterpret_cast<float4*>(out + 4 * ci) = make_float4(ax, ay, az, fmaxf(acc_w, 0.0001f));
     } else {
@@ -784,12 +804,14 @@ __global__ void __launch_bounds__(BIL_NT, 2) k_bilateral_tile(const float* __res
 template <bool BWD>
 __global__ void __launch_bounds__(256) k_bilateral_direct(const float* __restrict__ col, const float* __restrict__ nrm, const float* __restrict__ zdz,
                                                           int64_t B, int H, int W, float sigma, int rad, float* __restrict__ out,
-                                                          const float* __restrict__ g_out, float* __restrict__ g_col) {
+                                                          const float* __restrict__ g_out, float* __restrict__ g_col,
+                                                          const float* __restrict__ mask) {
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     int64_t b = blockIdx.z;
     if (x >= W || y >= H) return;
     int64_t base = b * (int64_t)H * W;
     int64_t ci = base + (int64_t)y * W + x;
+    if (mask && !(mask[ci] > 0.0f)) rad = -1;
     float cnx = nrm[3 * ci], cny = nrm[3 * ci + 1], cnz = nrm[3 * ci + 2];
     float cz = zdz[2 * ci], cdz = zdz[2 * ci + 1];
     float variance = sigma * sigma;
@@ -840,18 +862,18 @@ size_t bilateral_smem_bytes(int R) {
 }
 
 template <bool BWD>
-int launch_bilateral(const float* col, const float* nrm, const float* zdz, int64_t B, int64_t H, int64_t W, float sigma, float* out, const float* g_out,
-                     float* g_col, hipStream_t stream) {
+int launch_bilateral(const float* col, const float* nrm, const float* zdz, const float* mask, int64_t B, int64_t H, int64_t W, float sigma, float* out,
+                     const float* g_out, float* g_col, hipStream_t stream) {
     const int R = bilateral_radius(sigma);
     const size_t smem = bilateral_smem_bytes(R);
     if (smem <= 80 * 1024) {      // two workgroups per CU (160 KB of LDS)
         // set on every launch: the attribute is per device / per function, and a per-process flag would be neither
         GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bilateral_tile<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         dim3 grid((unsigned)gs::cdiv(W, BIL_TX), (unsigned)gs::cdiv(H, BIL_TY), (unsigned)B);
-        hipLaunchKernelGGL(k_bilateral_tile<BWD>, grid, dim3(BIL_NT), smem, stream, col, nrm, zdz, (int)H, (int)W, sigma, R, out, g_out, g_col);
+        hipLaunchKernelGGL(k_bilateral_tile<BWD>, grid, dim3(BIL_NT), smem, stream, col, nrm, zdz, (int)H, (int)W, sigma, R, out, g_out, g_col, mask);
     } else {
         dim3 grid((unsigned)gs::cdiv(W, 16), (unsigned)gs::cdiv(H, 16), (unsigned)B);
-        hipLaunchKernelGGL(k_bilateral_direct<BWD>, grid, dim3(256), 0, stream, col, nrm, zdz, B, (int)H, (int)W, sigma, R, out, g_out, g_col);
+        hipLaunchKernelGGL(k_bilateral_direct<BWD>, grid, dim3(256), 0, stream, col, nrm, zdz, B, (int)H, (int)W, sigma, R, out, g_out, g_col, mask);
     }
     GS_LAUNCH_CHECK();
     return 0;
@@ -924,12 +946,26 @@ extern "C" int gs_bilateral_fwd(const float* col, const float* nrm, const float*
                                 gs_stream_t stream) {
     if (B * H * W == 0) return 0;
     GS_REQUIRE(col && nrm && zdz && out && sigma > 0.f, "gs_bilateral_fwd: null pointer / sigma <= 0");
-    return launch_bilateral<false>(col, nrm, zdz, B, H, W, sigma, out, nullptr, nullptr, (hipStream_t)stream);
+    return launch_bilateral<false>(col, nrm, zdz, nullptr, B, H, W, sigma, out, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int gs_bilateral_fwd_masked(const float* col, const float* nrm, const float* zdz, const float* mask, int64_t B, int64_t H, int64_t W,
+                                       float sigma, float* out, gs_stream_t stream) {
+    if (B * H * W == 0) return 0;
+    GS_REQUIRE(col && nrm && zdz && out && sigma > 0.f, "gs_bilateral_fwd_masked: null pointer / sigma <= 0");
+    return launch_bilateral<false>(col, nrm, zdz, mask, B, H, W, sigma, out, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int gs_bilateral_bwd(const float* nrm, const float* zdz, int64_t B, int64_t H, int64_t W, float sigma, const float* g_out, float* g_col,
                                 gs_stream_t stream) {
     if (B * H * W == 0) return 0;
     GS_REQUIRE(nrm && zdz && g_out && g_col && sigma > 0.f, "gs_bilateral_bwd: null pointer / sigma <= 0");
-    return launch_bilateral<true>(nullptr, nrm, zdz, B, H, W, sigma, nullptr, g_out, g_col, (hipStream_t)stream);
+    return launch_bilateral<true>(nullptr, nrm, zdz, nullptr, B, H, W, sigma, nullptr, g_out, g_col, (hipStream_t)stream);
+}
+
+extern "C" int gs_bilateral_bwd_masked(const float* nrm, const float* zdz, const float* mask, int64_t B, int64_t H, int64_t W, float sigma,
+                                       const float* g_out, float* g_col, gs_stream_t stream) {
+    if (B * H * W == 0) return 0;
+    GS_REQUIRE(nrm && zdz && g_out && g_col && sigma > 0.f, "gs_bilateral_bwd_masked: null pointer / sigma <= 0");
+    return launch_bilateral<true>(nullptr, nrm, zdz, mask, B, H, W, sigma, nullptr, g_out, g_col, (hipStream_t)stream);
 }

@@ -19,10 +19,10 @@ class BilateralDenoiser(torch.nn.Module):
         self.variance = self.sigma * self.sigma
         self.N = 2 * math.ceil(2.5 * self.sigma) + 1        # filter radius used by the kernel
 
-    def filter_raw(self, rgb, nrm_unit, zdz):
+    def filter_raw(self, rgb, nrm_unit, zdz, mask=None):
         """(sum_t w c_t, max(sum_t w, 1e-4)) [...,4] of the filter -- the division is done by the caller (render.shade fuses it
-        into the buffer assembly).  `nrm_unit` must already be normalised."""
-        return ou.bilateral_denoiser_raw(rgb, nrm_unit, zdz, self.sigma)
+        into the buffer assembly).  `nrm_unit` must already be normalised.  `mask` > 0 marks the pixels whose value the caller uses."""
+        return ou.bilateral_denoiser_raw(rgb, nrm_unit, zdz, self.sigma, mask)
 
     def forward(self, input):
         rgb, nrm, zdz = input[..., :3], input[..., 3:6], input[..., 6:8]

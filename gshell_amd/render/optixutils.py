@@ -166,32 +166,35 @@ def optix_env_shade(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, 
 
 class _bilateral_denoiser_func(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, col, nrm, zdz, sigma):
+    def forward(ctx, col, nrm, zdz, sigma, mask=None):
         col_c, nrm_c, zdz_c = (x.detach().contiguous().float() for x in (col, nrm, zdz))
+        m_c = None if mask is None else mask.detach().reshape(col_c.shape[:3]).contiguous().float()
         B, H, W, _ = col_c.shape
         out = torch.empty((B, H, W, 4), dtype=torch.float32, device=col_c.device)
         with torch.cuda.device(col_c.device):
-            check(_lib.lib().gs_bilateral_fwd(ptr(col_c, torch.float32, "col"), ptr(nrm_c), ptr(zdz_c), c_int64(B), c_int64(H), c_int64(W),
-                                              c_float(sigma), ptr(out), stream()), "gs_bilateral_fwd")
-        ctx.save_for_backward(nrm_c, zdz_c)
+            check(_lib.lib().gs_bilateral_fwd_masked(ptr(col_c, torch.float32, "col"), ptr(nrm_c), ptr(zdz_c), ptr(m_c), c_int64(B), c_int64(H), c_int64(W),
+                                                     c_float(sigma), ptr(out), stream()), "gs_bilateral_fwd_masked")
+        ctx.save_for_backward(nrm_c, zdz_c, m_c)
         ctx.sigma = sigma
         return out
 
     @staticmethod
     def backward(ctx, out_grad):
-        nrm_c, zdz_c = ctx.saved_tensors
+        nrm_c, zdz_c, m_c = ctx.saved_tensors
         B, H, W, _ = nrm_c.shape
         g = out_grad.contiguous().float()
         g_col = torch.empty((B, H, W, 3), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            check(_lib.lib().gs_bilateral_bwd(ptr(nrm_c), ptr(zdz_c), c_int64(B), c_int64(H), c_int64(W), c_float(ctx.sigma), ptr(g), ptr(g_col),
-                                              stream()), "gs_bilateral_bwd")
-        return g_col, None, None, None
+            check(_lib.lib().gs_bilateral_bwd_masked(ptr(nrm_c), ptr(zdz_c), ptr(m_c), c_int64(B), c_int64(H), c_int64(W), c_float(ctx.sigma), ptr(g),
+                                                     ptr(g_col), stream()), "gs_bilateral_bwd_masked")
+        return g_col, None, None, None, None
 
 
-def bilateral_denoiser_raw(col, nrm, zdz, sigma):
-    """[B,H,W,4] = (sum w c, max(sum w, 1e-4)): the kernel's own output (denoising.cu:66-70), before the reference's division."""
-    return _bilateral_denoiser_func.apply(col, nrm, zdz, sigma)
+def bilateral_denoiser_raw(col, nrm, zdz, sigma, mask=None):
+    """[B,H,W,4] = (sum w c, max(sum w, 1e-4)): the kernel's own output (denoising.cu:66-70), before the reference's division.
+    `mask` [B,H,W(,1)]: only pixels with mask > 0 are consumed by the caller (covered pixels); the others are written as
+    (0,0,0,1e-4) without being filtered."""
+    return _bilateral_denoiser_func.apply(col, nrm, zdz, sigma, mask)
 
 
 def bilateral_denoiser(col, nrm, zdz, sigma):

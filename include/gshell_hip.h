@@ -321,6 +321,15 @@ int gs_bilateral_fwd(const float* col, const float* nrm, const float* zdz, int64
                      int64_t W, float sigma, float* out, gs_stream_t stream);
 int gs_bilateral_bwd(const float* nrm, const float* zdz, int64_t B, int64_t H, int64_t W, float sigma,
                      const float* g_out, float* g_col, gs_stream_t stream);
+/* the same filter when only the pixels with mask [B,H,W] > 0 are consumed downstream (covered pixels: the composite
+ * multiplies the others by alpha = 0): unwanted pixels still act as taps, their own outputs are written as
+ * (0, 0, 0, 1e-4) / zero gradient without running their tap loops.  mask = NULL: identical to the functions above. */
+int gs_bilateral_fwd_masked(const float* col, const float* nrm, const float* zdz, const float* mask,
+                            int64_t B, int64_t H, int64_t W, float sigma, float* out,
+                            gs_stream_t stream);
+int gs_bilateral_bwd_masked(const float* nrm, const float* zdz, const float* mask, int64_t B, int64_t H,
+                            int64_t W, float sigma, const float* g_out, float* g_col,
+                            gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Multiresolution hash-grid encoding   (replaces tinycudann.Encoding(3, HashGrid cfg) as configured by

@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 def test_fused_assembly_equals_the_torch_formulation(denoise):
     from gshell_amd import workload
     from gshell_amd.render import render
+    torch.manual_seed(0)       # the texture MLP is initialised from the global generator: same scene whatever ran before this test
     tr = workload.build(res=16, n_samples=2, batch=2, train_res=(48, 56), fit_steps=40, denoiser='bilateral' if denoise else 'none')
     target = workload.make_targets(tr, [0, 5], (48, 56))
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -28,7 +29,8 @@ def test_fused_assembly_equals_the_torch_formulation(denoise):
         results.append((st.detach().clone(), keys, sizes, [None if p.grad is None else p.grad.clone() for p in tr.all_params()]))
     (a, ka, sa, ga), (b, kb, sb, gb) = results
     assert ka == kb and sa == sb and a.shape[-1] == 45
-    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    # same arithmetic up to fma contraction / division order: a few ulp of O(1) radiance values (measured max |diff| 1.1e-6)
+    assert torch.allclose(a, b, rtol=1e-5, atol=5e-6)
     assert float((a[..., 3] > 0).float().mean()) > 0.02          # something is covered
     for x, y in zip(ga, gb):
         assert (x is None) == (y is None)

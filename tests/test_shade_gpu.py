@@ -158,3 +158,33 @@ def test_bilateral_golden_and_oracle():
     (o * wgt.to(DEV)).sum().backward()
     assert torch.allclose(o.cpu(), o_ref.detach(), rtol=1e-4, atol=1e-6)
     assert torch.allclose(c.grad.cpu(), c_ref.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("sigma", [2.0, 0.6, 4.5])      # LDS tile at radius 11 / 5, direct kernel at radius 25
+def test_bilateral_mask_only_skips_pixels_nobody_reads(sigma):
+    """gs_bilateral_*_masked: pixels with mask > 0 get bit-identical values (fwd) and gradients (bwd, with the upstream gradient
+    zero outside the mask, as the composite makes it) to the unmasked filter; the others get (0,0,0,1e-4) / zero gradient."""
+    from gshell_amd.render import optixutils as ou
+    gen = torch.Generator().manual_seed(9)
+    B, H, W = 3, 70, 101
+    col = torch.rand(B, H, W, 3, generator=gen).to(DEV)
+    nrm = torch.nn.functional.normalize(torch.randn(B, H, W, 3, generator=gen) * 0.3 + torch.tensor([0, 0, 1.0]), dim=-1).to(DEV)
+    zdz = torch.stack([torch.rand(B, H, W, generator=gen) * 0.2 + 0.5, torch.rand(B, H, W, generator=gen) * 0.02], -1).to(DEV)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    mask = (((yy - 30) ** 2 + (xx - 40) ** 2) < 20 ** 2).float()[None].repeat(B, 1, 1)
+    mask[1] = 0                    # a view without any covered pixel
+    mask[2, :, 64:] = 1            # whole 32x16 tiles wanted, whole tiles unwanted
+    mask = mask.to(DEV)
+    wgt = torch.randn(B, H, W, 4, generator=gen).to(DEV) * mask[..., None]
+    res = []
+    for m in (None, mask):
+        c = col.clone().requires_grad_(True)
+        o = ou.bilateral_denoiser_raw(c, nrm, zdz, sigma, m)
+        (o * wgt).sum().backward()
+        res.append((o.detach(), c.grad.clone()))
+    sel = mask > 0
+    assert torch.equal(res[1][0][sel], res[0][0][sel])
+    assert torch.equal(res[1][1][sel], res[0][1][sel])
+    assert torch.equal(res[1][0][~sel], torch.tensor([0, 0, 0, 1e-4], device=DEV).expand(int((~sel).sum()), 4))
+    assert float(res[1][1][~sel].abs().max()) == 0.0
+    assert float(res[0][1][~sel].abs().max()) > 0.0      # (the unmasked filter does send gradient to those colours)
