@@ -490,12 +490,23 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
     }
     if (need_x) __syncthreads();
 
+    // the saved outputs of a layer are fetched one layer AHEAD (issued before the GEMM of the layer above, consumed after its
+    // closing barrier): per-lane 16-byte pieces at a 1 KB row stride are latency, not bandwidth
+    float4 an[2][4];
+    auto fetch_plane = [&](int l) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            an[0][g] = *reinterpret_cast<const float4*>(B.A + ((int64_t)l * B.Rpad + r0 + m_lane) * D + n_base + 8 * g);
+            an[1][g] = *reinterpret_cast<const float4*>(B.A + ((int64_t)l * B.Rpad + r0 + 32 + m_lane) * D + n_base + 8 * g);
+        }
+    };
+    fetch_plane(B.n_layers - 1);
     for (int l = B.n_layers - 1; l >= 0; --l) {
         // ---- dL/dz_l from G (adjoint of the layer's OUTPUT) and the saved outputs
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 a0 = *reinterpret_cast<const float4*>(B.A + ((int64_t)l * B.Rpad + r0 + m_lane) * D + n_base + 8 * g);
-            const float4 a1 = *reinterpret_cast<const float4*>(B.A + ((int64_t)l * B.Rpad + r0 + 32 + m_lane) * D + n_base + 8 * g);
+            const float4 a0 = an[0][g];
+            const float4 a1 = an[1][g];
             const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
             float d0[4], d1[4];
 #pragma unroll
@@ -538,6 +549,11 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
             }
         }
         if (l == 0 && !need_x) break;
+#ifndef GS_H2_BWD_PREFETCH
+#define GS_H2_BWD_PREFETCH 0     // 1: issue the next plane's loads BEFORE the GEMM (spills: 71 / 22 VGPRs), 0: after it, before the closing
+#endif                           //    barrier; 2: before for <EIK>, after for <ROWS>.  Measured (both calls, ms): HEAD 1.78, 1 -> 1.67, 0 -> 1.47
+        constexpr bool EARLY = GS_H2_BWD_PREFETCH == 1 || (GS_H2_BWD_PREFETCH == 2 && MODE == MODE_EIK);
+        if (EARLY && l > 0) fetch_plane(l - 1);
         __syncthreads();
         // ---- G = W_l^T D_l
         v16f hi[2], lo[2];
@@ -560,6 +576,7 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
                     if (f < EK) GE[(32 * s + m_lane) * LDG + f] += __builtin_fmaf(lo[s][r], LO_INV, hi[s][r]);
                 }
         }
+        if (!EARLY && l > 0) fetch_plane(l - 1);
         __syncthreads();
     }
     if (need_x) {
