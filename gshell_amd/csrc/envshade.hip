@@ -365,7 +365,7 @@ struct ShadeArgs {
     int64_t view_offset, view_stride;  // RNG pixel index uses the GLOBAL view id b*view_stride + view_offset (view-sharded jobs)
     float shadow_scale;
     // ray buffers, slot r = k*2S + which*S + i  (which: 0 light sample, 1 BSDF sample)
-    float* ray_dir;            // [n_cov*2S, 3]
+    float4* ray_dk;            // [n_cov*2S]  (direction, k = MIS weight x sample weight): kept for the backward pass
     float* ray_contrib;        // [n_cov*2S, 6]  unshadowed (diff rgb, spec rgb) contribution
     uint64_t* vis_bits;        // [ceil(n_cov*2S / 64)]  bit = 1 -> unoccluded
     float *diff, *spec;                                  // fwd outputs [B,H,W,3]
@@ -380,22 +380,23 @@ struct PixelCtx {
 
 // BSDF * light * MIS * weight of one sample, WITHOUT the visibility factor (which is linear and applied later).
 // BWD: accumulates the gradient terms, already multiplied by `vis` (= V of this ray, cached by the forward pass).
+// `k_saved` >= 0: the forward pass's k of this sample (backward from saved samples) instead of pdf_sum / weight; `k_out` = k.
 template <bool BWD>
 __device__ __forceinline__ void eval_sample(const ShadeArgs& A, const PixelCtx& c, v3 dir, float pdf_sum, float weight, float vis, v3 g_diff, v3 g_spec,
-                                            v3& out_d, v3& out_s, v3& a_pos, v3& a_nrm, v3& a_kd, v3& a_ks) {
+                                            v3& out_d, v3& out_s, v3& a_pos, v3& a_nrm, v3& a_kd, v3& a_ks, float k_saved, float& k_out) {
     float u, v;
     dir_to_tc(dir, u, v);
     int lx = min(max((int)(u * (float)A.probe.Wl), 0), A.probe.Wl - 1);
     int ly = min(max((int)(v * (float)A.probe.Hl), 0), A.probe.Hl - 1);
     v3 light_col = ld3(A.probe.light + ((int64_t)ly * A.probe.Wl + lx) * 3);
-    float mis = 1.0f / fmaxf(pdf_sum, 0.0001f);
     v3 d_ = V3(fwd_lambert(c.nrm, dir)), s_ = V3(0.f);
     v3 spec_col = V3(0.f);
     if (A.bsdf == 0) {
         spec_col = (V3(0.04f) * (1.0f - c.ks.z) + c.kd * c.ks.z) * (1.0f - c.ks.x);
         s_ = fwd_pbr_specular(spec_col, c.nrm, c.wo, dir, c.alpha, MIN_ROUGHNESS);
     }
-    float k = mis * weight;
+    float k = k_saved >= 0.0f ? k_saved : (1.0f / fmaxf(pdf_sum, 0.0001f)) * weight;
+    k_out = k;
     if (!BWD) {
         out_d = d_ * light_col * k;
         out_s = s_ * light_col * k;
@@ -506,10 +507,10 @@ __global__ void __launch_bounds__(256) k_shade_samples(ShadeArgs A) {
         v3 dir = light_sample(A.probe, sx, sy, pdf_light);
         pdf_b = bsdf_pdf(c.pD, c.pS, c.nrm, c.wo, dir, c.alpha);
         int64_t r = r0 + i;
-        eval_sample<BWD>(A, c, dir, pdf_light + pdf_b, sample_frac, BWD ? vis_of(A, r) : 0.f, g_diff, g_spec, od, os, a_pos, a_nrm, a_kd, a_ks);
+        float kk;
+        eval_sample<BWD>(A, c, dir, pdf_light + pdf_b, sample_frac, BWD ? vis_of(A, r) : 0.f, g_diff, g_spec, od, os, a_pos, a_nrm, a_kd, a_ks, -1.0f, kk);
         if (!BWD) {
-            float* rd = A.ray_dir + 3 * r;
-            rd[0] = dir.x; rd[1] = dir.y; rd[2] = dir.z;
+            A.ray_dk[r] = make_float4(dir.x, dir.y, dir.z, kk);
             float* rc = A.ray_contrib + 6 * r;
             rc[0] = od.x; rc[1] = od.y; rc[2] = od.z; rc[3] = os.x; rc[4] = os.y; rc[5] = os.z;
         }
@@ -520,10 +521,9 @@ __global__ void __launch_bounds__(256) k_shade_samples(ShadeArgs A) {
         dir = bsdf_sample(c.pD, c.pS, c.nrm, c.wo, sx, sy, r4, c.alpha, pdf_b);
         pdf_light = light_pdf(A.probe, dir);
         r = r0 + S + i;
-        eval_sample<BWD>(A, c, dir, pdf_light + pdf_b, sample_frac, BWD ? vis_of(A, r) : 0.f, g_diff, g_spec, od, os, a_pos, a_nrm, a_kd, a_ks);
+        eval_sample<BWD>(A, c, dir, pdf_light + pdf_b, sample_frac, BWD ? vis_of(A, r) : 0.f, g_diff, g_spec, od, os, a_pos, a_nrm, a_kd, a_ks, -1.0f, kk);
         if (!BWD) {
-            float* rd = A.ray_dir + 3 * r;
-            rd[0] = dir.x; rd[1] = dir.y; rd[2] = dir.z;
+            A.ray_dk[r] = make_float4(dir.x, dir.y, dir.z, kk);
             float* rc = A.ray_contrib + 6 * r;
             rc[0] = od.x; rc[1] = od.y; rc[2] = od.z; rc[3] = os.x; rc[4] = os.y; rc[5] = os.z;
         }
@@ -540,6 +540,59 @@ __global__ void __launch_bounds__(256) k_shade_samples(ShadeArgs A) {
             p = A.g_kd + 3 * gid;  p[0] = a_kd.x;  p[1] = a_kd.y;  p[2] = a_kd.z;
             p = A.g_ks + 3 * gid;  p[0] = a_ks.x;  p[1] = a_ks.y;  p[2] = a_ks.z;
         }
+    }
+}
+
+// Backward from the SAVED samples: the forward pass's ray buffer holds every sample's direction and k (MIS x sample weight; the
+// reference treats both as constants in its backward pass too), so the gradient pass is a stream over 16 bytes per ray + the
+// visibility bit -- no RNG replay, no CDF searches (17 dependent loads per light sample), no BSDF sampling: 233 -> ~100 VGPRs.
+// Same arithmetic on the same k in the same order as k_shade_samples<true>: bit-identical per-pixel gradients.
+#ifndef GS_GRAD_WAVES
+#define GS_GRAD_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, GS_GRAD_WAVES) k_shade_grad(ShadeArgs A) {
+    const int tid = threadIdx.x;
+    const int G = A.G;
+    int64_t k = ((int64_t)blockIdx.x * 256 + tid) / G;   // covered-pixel slot
+    int j = tid & (G - 1);
+    if (k >= A.n_cov) return;
+    int64_t gid = A.pix[k];
+    PixelCtx c;
+    int64_t b = gid / A.HW;
+    c.pos = ld3(A.pos + 3 * gid);
+    c.nrm = ld3(A.nrm + 3 * gid);
+    c.view = ld3(A.view_pos + 3 * b);
+    c.kd = ld3(A.kd + 3 * gid);
+    c.ks = ld3(A.ks + 3 * gid);
+    const v3 g_diff = ld3(A.g_diff + 3 * gid), g_spec = ld3(A.g_spec + 3 * gid);
+    const int S = A.n * A.n;
+    c.alpha = c.ks.y * c.ks.y;
+    c.wo = safe_normalize(c.view - c.pos);
+    c.pD = c.pS = 0.f;
+    v3 a_pos = V3(0.f), a_nrm = V3(0.f), a_kd = V3(0.f), a_ks = V3(0.f);
+    const int64_t r0 = k * 2 * S;
+    for (int i = j; i < S; i += G) {
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {
+            const int64_t r = r0 + which * S + i;
+            const float4 dk = A.ray_dk[r];
+            const float vis = vis_of(A, r);
+            if (dk.w * vis == 0.f) continue;
+            v3 od, os;
+            float kk;
+            eval_sample<true>(A, c, V3(dk.x, dk.y, dk.z), 0.f, 0.f, vis, g_diff, g_spec, od, os, a_pos, a_nrm, a_kd, a_ks, dk.w, kk);
+        }
+    }
+    a_pos = group_sum(a_pos, G);
+    a_nrm = group_sum(a_nrm, G);
+    a_kd = group_sum(a_kd, G);
+    a_ks = group_sum(a_ks, G);
+    if (j == 0) {
+        float* p;
+        p = A.g_pos + 3 * gid; p[0] = a_pos.x; p[1] = a_pos.y; p[2] = a_pos.z;
+        p = A.g_nrm + 3 * gid; p[0] = a_nrm.x; p[1] = a_nrm.y; p[2] = a_nrm.z;
+        p = A.g_kd + 3 * gid;  p[0] = a_kd.x;  p[1] = a_kd.y;  p[2] = a_kd.z;
+        p = A.g_ks + 3 * gid;  p[0] = a_ks.x;  p[1] = a_ks.y;  p[2] = a_ks.z;
     }
 }
 
@@ -587,8 +640,8 @@ __global__ void __launch_bounds__(256) k_shade_trace(ShadeArgs A, int64_t n_rays
                 if (live) {
                     const int64_t gid = A.pix[r / rays_per_pixel];
                     const float* o = A.ro + 3 * gid;
-                    const float* d = A.ray_dir + 3 * r;
-                    o0 = o[0]; o1 = o[1]; o2 = o[2]; d0 = d[0]; d1 = d[1]; d2 = d[2];
+                    const float4 d = A.ray_dk[r];
+                    o0 = o[0]; o1 = o[1]; o2 = o[2]; d0 = d.x; d1 = d.y; d2 = d.z;
                     live = (d0 == d0 && d1 == d1 && d2 == d2) && !(d0 == 0.f && d1 == 0.f && d2 == 0.f);
                 }
             }
@@ -886,7 +939,7 @@ extern "C" int64_t gs_env_shade_vis_words(int64_t n_cov, int n_samples_x) {
 }
 
 extern "C" int64_t gs_env_shade_scratch_bytes(int64_t n_cov, int n_samples_x) {
-    return n_cov * 2 * n_samples_x * n_samples_x * (int64_t)(3 + 6) * 4 + 256;
+    return n_cov * 2 * n_samples_x * n_samples_x * (int64_t)(4 + 6) * 4 + 256;
 }
 
 extern "C" int gs_env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* ro, const float* gb_pos, const float* gb_normal,
@@ -905,8 +958,8 @@ extern "C" int gs_env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n
                        view_stride, bsdf, n_samples_x, rnd_seed, shadow_scale, vis_bits);
     if (rc) return rc;
     const int64_t S2 = 2ll * n_samples_x * n_samples_x, n_rays = n_cov * S2;
-    A.ray_dir = (float*)scratch;
-    A.ray_contrib = A.ray_dir + 3 * n_rays;
+    A.ray_dk = (float4*)scratch;
+    A.ray_contrib = (float*)(A.ray_dk + n_rays);
     A.diff = diff;
     A.spec = spec;
     int64_t lanes = n_cov * A.G;
@@ -917,12 +970,12 @@ extern "C" int gs_env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n
     return 0;
 }
 
-extern "C" int gs_env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* gb_pos, const float* gb_normal,
-                                const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
-                                const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
-                                int64_t H, int64_t W, int64_t view_offset, int64_t view_stride, int bsdf, int n_samples_x, uint32_t rnd_seed,
-                                float shadow_scale, const uint64_t* vis_bits, const float* g_diff, const float* g_spec, float* g_pos, float* g_normal, float* g_kd, float* g_ks, float* g_light,
-                                gs_stream_t stream_) {
+static int env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* gb_pos, const float* gb_normal,
+                         const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
+                         const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
+                         int64_t H, int64_t W, int64_t view_offset, int64_t view_stride, int bsdf, int n_samples_x, uint32_t rnd_seed,
+                         float shadow_scale, const uint64_t* vis_bits, const void* saved_rays, const float* g_diff, const float* g_spec, float* g_pos,
+                         float* g_normal, float* g_kd, float* g_ks, float* g_light, gs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (B * H * W == 0) return 0;
     GS_REQUIRE(g_diff && g_spec && g_pos && g_normal && g_kd && g_ks && g_light, "gs_env_shade_bwd: null pointer");
@@ -937,9 +990,37 @@ extern "C" int gs_env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n
                        perms, P, B, H, W, view_offset, view_stride, bsdf, n_samples_x, rnd_seed, shadow_scale, const_cast<uint64_t*>(vis_bits));
     if (rc) return rc;
     A.g_diff = g_diff; A.g_spec = g_spec; A.g_pos = g_pos; A.g_nrm = g_normal; A.g_kd = g_kd; A.g_ks = g_ks; A.g_light = g_light;
-    hipLaunchKernelGGL(k_shade_samples<true>, dim3((unsigned)gs::cdiv(n_cov * A.G, 256)), dim3(256), 0, stream, A);
+    if (saved_rays) {
+        A.ray_dk = (float4*)const_cast<void*>(saved_rays);
+        hipLaunchKernelGGL(k_shade_grad, dim3((unsigned)gs::cdiv(n_cov * A.G, 256)), dim3(256), 0, stream, A);
+    } else {
+        hipLaunchKernelGGL(k_shade_samples<true>, dim3((unsigned)gs::cdiv(n_cov * A.G, 256)), dim3(256), 0, stream, A);
+    }
     GS_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gs_env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* gb_pos, const float* gb_normal,
+                                const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
+                                const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
+                                int64_t H, int64_t W, int64_t view_offset, int64_t view_stride, int bsdf, int n_samples_x, uint32_t rnd_seed,
+                                float shadow_scale, const uint64_t* vis_bits, const float* g_diff, const float* g_spec, float* g_pos, float* g_normal, float* g_kd, float* g_ks, float* g_light,
+                                gs_stream_t stream_) {
+    return env_shade_bwd(bvh, pix, n_cov, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl, perms, P, B, H, W, view_offset,
+                         view_stride, bsdf, n_samples_x, rnd_seed, shadow_scale, vis_bits, nullptr, g_diff, g_spec, g_pos, g_normal, g_kd, g_ks, g_light,
+                         stream_);
+}
+
+extern "C" int gs_env_shade_bwd_saved(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* gb_pos, const float* gb_normal,
+                                      const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
+                                      const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
+                                      int64_t H, int64_t W, int64_t view_offset, int64_t view_stride, int bsdf, int n_samples_x, uint32_t rnd_seed,
+                                      float shadow_scale, const uint64_t* vis_bits, const void* fwd_scratch, const float* g_diff, const float* g_spec,
+                                      float* g_pos, float* g_normal, float* g_kd, float* g_ks, float* g_light, gs_stream_t stream_) {
+    GS_REQUIRE(fwd_scratch != nullptr, "gs_env_shade_bwd_saved: the forward pass's scratch buffer is required");
+    return env_shade_bwd(bvh, pix, n_cov, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl, perms, P, B, H, W, view_offset,
+                         view_stride, bsdf, n_samples_x, rnd_seed, shadow_scale, vis_bits, fwd_scratch, g_diff, g_spec, g_pos, g_normal, g_kd, g_ks, g_light,
+                         stream_);
 }
 
 extern "C" int gs_bilateral_fwd(const float* col, const float* nrm, const float* zdz, int64_t B, int64_t H, int64_t W, float sigma, float* out,

@@ -80,6 +80,9 @@ def set_random_perm(n_samples_x, table):
     _random_perm[(n_samples_x, str(table.device))] = table.int().contiguous()
 
 
+SAVED_SAMPLES = True      # backward from the forward pass's saved ray buffer (gs_env_shade_bwd_saved) instead of replaying the sampler
+
+
 class _optix_env_shade_func(torch.autograd.Function):
     @staticmethod
     def _launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n, seed, shadow_scale, dims, vis, diff, spec, view_map=(0, 1)):
@@ -92,6 +95,7 @@ class _optix_env_shade_func(torch.autograd.Function):
                                  ptr(perms, torch.int32), c_int64(perms.shape[0]), c_int64(B), c_int64(H), c_int64(W), c_int64(view_map[0]), c_int64(view_map[1]),
                                  c_int(BSDF), c_int(n), c_uint32(seed & 0xFFFFFFFF), c_float(shadow_scale), ptr(scratch), ptr(vis), ptr(diff), ptr(spec), stream()),
               "gs_env_shade_fwd")
+        return scratch
 
     @staticmethod
     def forward(ctx, optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, BSDF, n_samples_x, rnd_seed,
@@ -116,8 +120,11 @@ class _optix_env_shade_func(torch.autograd.Function):
         spec = torch.empty(full, dtype=torch.float32, device=dev)
         vis = torch.empty((int(L.gs_env_shade_vis_words(c_int64(pix.shape[0]), c_int(n_samples_x))),), dtype=torch.int64, device=dev)
         with torch.cuda.device(dev):
-            _optix_env_shade_func._launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, _rnd_seed, shadow_scale,
-                                              (B, H, W), vis, diff, spec, view_map)
+            scratch = _optix_env_shade_func._launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, _rnd_seed,
+                                                        shadow_scale, (B, H, W), vis, diff, spec, view_map)
+        # the ray buffer (direction + MIS weight per sample, 40 B / ray) stays alive for the backward pass, which then needs no
+        # RNG replay (SAVED_SAMPLES = False: regenerate the samples, the round-1 path; same gradients)
+        ctx.scratch = scratch if (SAVED_SAMPLES and any(ctx.needs_input_grad)) else None
         ctx.args = (optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, rnd_seed, _rnd_seed, shadow_scale, vis)
         ctx.view_map = view_map
         ctx.shapes = (gb_pos.shape, gb_normal.shape, gb_kd.shape, gb_ks.shape, light.shape)
@@ -136,16 +143,21 @@ class _optix_env_shade_func(torch.autograd.Function):
                 # "decorrelated" mode (ops.py:100): the backward pass draws a fresh seed -> new rays: trace them (no shading outputs)
                 _rnd_seed = int(np.random.randint(2 ** 31))
                 vis = torch.empty_like(vis)
-                _optix_env_shade_func._launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, _rnd_seed,
-                                                  shadow_scale, (B, H, W), vis, None, None, ctx.view_map)
+                scratch = _optix_env_shade_func._launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, _rnd_seed,
+                                                            shadow_scale, (B, H, W), vis, None, None, ctx.view_map)
+                if not SAVED_SAMPLES:
+                    scratch = None
             else:
                 _rnd_seed = _fwd_seed      # same seed -> same rays -> the cached visibility bits are exact
-            check(_lib.lib().gs_env_shade_bwd(optix_ctx.handle, ptr(pix), c_int64(pix.shape[0]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view), ptr(t["kd"]),
+                scratch = ctx.scratch
+            fn, extra = ((_lib.lib().gs_env_shade_bwd_saved, (ptr(scratch),)) if scratch is not None else (_lib.lib().gs_env_shade_bwd, ()))
+            check(fn(optix_ctx.handle, ptr(pix), c_int64(pix.shape[0]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view), ptr(t["kd"]),
                                               ptr(t["ks"]), ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]),
                                               c_int64(lgt.shape[1]), ptr(perms), c_int64(perms.shape[0]), c_int64(B), c_int64(H), c_int64(W),
                                               c_int64(ctx.view_map[0]), c_int64(ctx.view_map[1]), c_int(BSDF), c_int(n_samples_x), c_uint32(_rnd_seed & 0xFFFFFFFF), c_float(shadow_scale), ptr(vis),
-                                              ptr(gd), ptr(gs), ptr(g_pos), ptr(g_nrm), ptr(g_kd), ptr(g_ks), ptr(g_light), stream()),
+                                              *extra, ptr(gd), ptr(gs), ptr(g_pos), ptr(g_nrm), ptr(g_kd), ptr(g_ks), ptr(g_light), stream()),
                   "gs_env_shade_bwd")
+        ctx.scratch = None
         s = ctx.shapes
 
         def red(g, shape):

@@ -311,6 +311,18 @@ int gs_env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const
                      float shadow_scale, const uint64_t* vis_bits, const float* g_diff,
                      const float* g_spec, float* g_pos, float* g_normal, float* g_kd, float* g_ks,
                      float* g_light, gs_stream_t stream);
+/* The same gradients from the forward pass's SAVED samples: fwd_scratch = the scratch buffer of the gs_env_shade_fwd call
+ * (kept alive by the caller; it holds every ray's direction and MIS weight, which the reference's backward treats as
+ * constants too).  No RNG replay / CDF searches / BSDF sampling; bit-identical per-pixel gradients. */
+int gs_env_shade_bwd_saved(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* gb_pos,
+                           const float* gb_normal, const float* view_pos, const float* gb_kd,
+                           const float* gb_ks, const float* light, const float* pdf, const float* rows,
+                           const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P,
+                           int64_t B, int64_t H, int64_t W, int64_t view_offset, int64_t view_stride,
+                           int bsdf, int n_samples_x, uint32_t rnd_seed, float shadow_scale,
+                           const uint64_t* vis_bits, const void* fwd_scratch, const float* g_diff,
+                           const float* g_spec, float* g_pos, float* g_normal, float* g_kd, float* g_ks,
+                           float* g_light, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Bilateral denoiser   (replaces ou.bilateral_denoiser, render/optixutils/ops.py:110-123, :145-147;

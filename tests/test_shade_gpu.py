@@ -188,3 +188,35 @@ def test_bilateral_mask_only_skips_pixels_nobody_reads(sigma):
     assert torch.equal(res[1][0][~sel], torch.tensor([0, 0, 0, 1e-4], device=DEV).expand(int((~sel).sum()), 4))
     assert float(res[1][1][~sel].abs().max()) == 0.0
     assert float(res[0][1][~sel].abs().max()) > 0.0      # (the unmasked filter does send gradient to those colours)
+
+
+@pytest.mark.parametrize("bsdf,n,shadow", [("pbr", 4, 0.6), ("diffuse", 3, 1.0), ("pbr", 8, 1.0)])
+def test_env_shade_backward_from_saved_samples_equals_the_replayed_sampler(bsdf, n, shadow, monkeypatch):
+    """gs_env_shade_bwd_saved (directions + MIS weights kept from the forward pass) vs gs_env_shade_bwd (RNG replay, the path
+    pinned to the oracle above): per-pixel gradients bit-identical, the light gradient equal up to float-atomic order."""
+    from gshell_amd.render import optixutils as ou
+    B, H, W = 2, 40, 36
+    verts, tri, mask, gb_pos, gb_nrm, view, kd, ks = _gbuffer(B, H, W, 5)
+    gen = torch.Generator().manual_seed(3)
+    light = torch.rand(32, 64, 3, generator=gen) * 2 + 0.05
+    pdf, rows, cols = po.update_pdf(light)
+    wd, ws = torch.rand(B, H, W, 3, generator=gen).to(DEV), torch.rand(B, H, W, 3, generator=gen).to(DEV)
+    ctx = ou.OptiXContext()
+    ou.optix_build_bvh(ctx, torch.tensor(verts, device=DEV), torch.tensor(tri, device=DEV), rebuild=1)
+    ro_ = (gb_pos + gb_nrm * 0.001).to(DEV)
+    res = []
+    for saved in (True, False):
+        monkeypatch.setattr(ou, "SAVED_SAMPLES", saved)
+        dl = [t.to(DEV).requires_grad_(True) for t in (gb_pos, gb_nrm, kd, ks, light)]
+        d, s = ou.optix_env_shade(ctx, mask.to(DEV), ro_, dl[0], dl[1], view.to(DEV), dl[2], dl[3], dl[4], pdf.to(DEV), rows[:, 0].to(DEV),
+                                  cols.to(DEV), BSDF=bsdf, n_samples_x=n, rnd_seed=77, shadow_scale=shadow)
+        ((d * wd).sum() + (s * ws).sum()).backward()
+        res.append([d.detach(), s.detach()] + [None if t.grad is None else t.grad.clone() for t in dl])
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for x, y, name in zip(a[2:6], b[2:6], ("g_pos", "g_nrm", "g_kd", "g_ks")):
+        assert (x is None) == (y is None), name
+        if x is not None:
+            assert torch.equal(x, y), (name, float((x - y).abs().max()))
+    assert float(b[6].abs().max()) > 0
+    assert float((a[6] - b[6]).abs().max()) <= 1e-5 * float(b[6].abs().max())
