@@ -373,7 +373,8 @@ struct ShadeArgs {
     float *g_pos, *g_nrm, *g_kd, *g_ks, *g_light;        // bwd outputs
     // light gradient by binning instead of atomics (backward from saved samples, see k_light_*):
     float4* rec;               // [n_rays] (d loss / d light texel rgb, texel id as bits) per sample, LG_NONE = nothing to add
-    uint32_t* hist;            // [workgroups of k_shade_grad][nbins]
+    uint32_t* hist;            // [nbins][workgroups of k_shade_grad]
+    int64_t n_wg;
     int nbins;
 };
 constexpr int LG_TEXELS = 1024;            // probe texels per bin: 12 KB of LDS accumulators
@@ -622,7 +623,7 @@ __global__ void __launch_bounds__(256, GS_GRAD_WAVES) k_shade_grad(ShadeArgs A) 
     }
     if (binned) {
         __syncthreads();
-        for (int b = tid; b < A.nbins; b += 256) A.hist[(int64_t)blockIdx.x * A.nbins + b] = s_hist[b];
+        for (int b = tid; b < A.nbins; b += 256) A.hist[(int64_t)b * A.n_wg + blockIdx.x] = s_hist[b];
     }
 }
 
@@ -635,29 +636,30 @@ __global__ void __launch_bounds__(256, GS_GRAD_WAVES) k_shade_grad(ShadeArgs A) 
 //   k_light_base  : exclusive scan of the bin totals                 k_light_scatter: records -> bin-sorted order
 //   k_light_reduce: LDS accumulation per (bin, slice), a few float atomics per texel and slice to finish
 __global__ void __launch_bounds__(256) k_light_scan(uint32_t* __restrict__ hist, int64_t n_wg, int nbins, uint32_t* __restrict__ totals) {
-    __shared__ uint32_t s_part[256];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int64_t per = (n_wg + 255) / 256, lo = tid * per, hi = min(n_wg, lo + per);
-    uint32_t sum = 0;
-    for (int64_t w = lo; w < hi; ++w) sum += hist[w * nbins + b];
-    s_part[tid] = sum;
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* h = hist + (int64_t)blockIdx.x * n_wg;
+    if (tid == 0) s_carry = 0u;
     __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int t = 0; t < 256; ++t) {
-            const uint32_t v = s_part[t];
-            s_part[t] = run;
-            run += v;
+    for (int64_t base = 0; base < n_wg; base += 256) {
+        const int64_t w = base + tid;
+        const uint32_t v = w < n_wg ? h[w] : 0u;
+        uint32_t inc = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
         }
-        totals[b] = run;
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (int q = 0; q < wave; ++q) before += s_wave[q];
+        if (w < n_wg) h[w] = before + inc - v;          // in place: count -> offset inside the bin
+        __syncthreads();
+        if (tid == 255) s_carry = before + inc;
+        __syncthreads();
     }
-    __syncthreads();
-    uint32_t run = s_part[tid];
-    for (int64_t w = lo; w < hi; ++w) {
-        const uint32_t v = hist[w * nbins + b];
-        hist[w * nbins + b] = run;          // in place: count -> offset inside the bin
-        run += v;
-    }
+    if (tid == 0) totals[blockIdx.x] = s_carry;
 }
 
 __global__ void k_light_base(const uint32_t* __restrict__ totals, int nbins, uint32_t* __restrict__ base) {
@@ -675,7 +677,7 @@ __global__ void __launch_bounds__(256) k_light_scatter(const float4* __restrict_
                                                        const uint32_t* __restrict__ base, int nbins, float4* __restrict__ sorted) {
     __shared__ uint32_t s_cur[1024];
     const int tid = threadIdx.x;
-    for (int b = tid; b < nbins; b += 256) s_cur[b] = base[b] + hist[(int64_t)blockIdx.x * nbins + b];
+    for (int b = tid; b < nbins; b += 256) s_cur[b] = base[b] + hist[(int64_t)b * gridDim.x + blockIdx.x];
     __syncthreads();
     const int64_t r0 = (int64_t)blockIdx.x * rays_per_wg, r1 = min(n_rays, r0 + rays_per_wg);
     for (int64_t r = r0 + tid; r < r1; r += 256) {
@@ -685,8 +687,12 @@ __global__ void __launch_bounds__(256) k_light_scatter(const float4* __restrict_
     }
 }
 
-constexpr int LG_SLICES = 8;
-__global__ void __launch_bounds__(256) k_light_reduce(const float4* __restrict__ sorted, const uint32_t* __restrict__ base, int64_t n_texels,
+#ifndef GS_LG_SLICES
+#define GS_LG_SLICES 16
+#endif
+constexpr int LG_SLICES = GS_LG_SLICES;
+constexpr int LG_NT = 1024;
+__global__ void __launch_bounds__(LG_NT) k_light_reduce(const float4* __restrict__ sorted, const uint32_t* __restrict__ base, int64_t n_texels,
                                                       float* __restrict__ g_light) {
     __shared__ float s_acc[LG_TEXELS * 3];
     const int b = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x;
@@ -694,9 +700,9 @@ __global__ void __launch_bounds__(256) k_light_reduce(const float4* __restrict__
     const uint32_t n = hi - lo, per = (n + LG_SLICES - 1) / LG_SLICES;
     const uint32_t s0 = lo + min(n, slice * per), s1 = lo + min(n, (slice + 1) * per);
     if (s0 >= s1) return;
-    for (int t = tid; t < LG_TEXELS * 3; t += 256) s_acc[t] = 0.f;
+    for (int t = tid; t < LG_TEXELS * 3; t += LG_NT) s_acc[t] = 0.f;
     __syncthreads();
-    for (uint32_t q = s0 + tid; q < s1; q += 256) {
+    for (uint32_t q = s0 + tid; q < s1; q += LG_NT) {
         const float4 v = sorted[q];
         const uint32_t t = (__float_as_uint(v.w) - (uint32_t)b * LG_TEXELS) * 3;
         if (v.x != 0.f) atomicAdd(&s_acc[t], v.x);
@@ -705,7 +711,7 @@ __global__ void __launch_bounds__(256) k_light_reduce(const float4* __restrict__
     }
     __syncthreads();
     const int64_t f0 = (int64_t)b * LG_TEXELS * 3, f1 = min(n_texels * 3, f0 + LG_TEXELS * 3);
-    for (int t = tid; t < LG_TEXELS * 3; t += 256) {
+    for (int t = tid; t < LG_TEXELS * 3; t += LG_NT) {
         const float v = s_acc[t];
         if (v != 0.f && f0 + t < f1) atomicAdd(&g_light[f0 + t], v);
     }
@@ -1122,6 +1128,7 @@ static int env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, c
             A.rec = (float4*)(A.ray_dk + n_rays);
             A.hist = (uint32_t*)(A.rec + n_rays);
             A.nbins = (int)nbins;
+            A.n_wg = n_wg;
         }
         hipLaunchKernelGGL(k_shade_grad, dim3((unsigned)n_wg), dim3(256), 0, stream, A);
         if (binned) {
@@ -1130,7 +1137,7 @@ static int env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, c
             hipLaunchKernelGGL(k_light_scan, dim3((unsigned)nbins), dim3(256), 0, stream, A.hist, n_wg, (int)nbins, totals);
             hipLaunchKernelGGL(k_light_base, dim3(1), dim3(64), 0, stream, totals, (int)nbins, base);
             hipLaunchKernelGGL(k_light_scatter, dim3((unsigned)n_wg), dim3(256), 0, stream, A.rec, n_rays, rays_per_wg, A.hist, base, (int)nbins, A.ray_dk);
-            hipLaunchKernelGGL(k_light_reduce, dim3((unsigned)nbins, LG_SLICES), dim3(256), 0, stream, A.ray_dk, base, n_texels, A.g_light);
+            hipLaunchKernelGGL(k_light_reduce, dim3((unsigned)nbins, LG_SLICES), dim3(LG_NT), 0, stream, A.ray_dk, base, n_texels, A.g_light);
         }
     } else {
         hipLaunchKernelGGL(k_shade_samples<true>, dim3((unsigned)gs::cdiv(n_cov * A.G, 256)), dim3(256), 0, stream, A);
