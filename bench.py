@@ -204,10 +204,10 @@ def algorithmic_bytes(N, Ftets, V_aug, T, B, H, W):
         "gs_env_shade_fwd": npix * (4 + 6 * 12 + 24),
         "gs_env_shade_bwd": npix * (4 + 6 * 12 + 24 + 48),
         "gs_mtets_count": 16 * Ftets + 20 * N, "gs_mtets_fill": 16 * Ftets + 20 * N + 20 * V_aug + 12 * T,
-        "gs_bilateral_fwd": npix * (12 + 12 + 8 + 16), "gs_bilateral_bwd": npix * (12 + 8 + 16 + 12),
-        "gs_hashgrid_fwd": npix * (12 + 4 + 128), "gs_hashgrid_bwd": npix * (12 + 4 + 128 + 12 * 16),
+        "gs_bilateral_fwd_masked": npix * (12 + 12 + 8 + 16), "gs_bilateral_bwd_masked": npix * (12 + 8 + 16 + 12),
+        "gs_hashgrid_encode_fwd": 2 * npix * (12 + 4 + 128), "gs_hashgrid_encode_bwd": 2 * npix * (12 + 4 + 128 + 12),
         "gs_rasterize_fwd": B * (16 * V_aug + 12 * T) + npix * 40, "gs_aa_apply_fwd": npix * 8 * 45, "gs_aa_apply_bwd": npix * 12 * 45,
-        "gs_sdf_reg_fwd": 8 * int(1.19 * Ftets) + 4 * N, "gs_texmlp_fwd": npix * 152, "gs_texmlp_bwd": npix * (152 + 128 + 24),
+        "gs_sdf_reg_fwd": 8 * int(1.19 * Ftets) + 4 * N, "gs_texmlp_fwd_level_major": 2 * npix * 152, "gs_texmlp_bwd_level_major": 2 * npix * (152 + 128 + 24),
         "gs_frame_sums_fwd": npix * 4 * 49, "gs_frame_sums_bwd": npix * 8 * 49,
         "gs_interpolate_fwd": npix * (16 + 4 * 7), "gs_auto_normals_fwd": 36 * T + 24 * V_aug,
         "gs_shade_assemble_fwd": npix * 4 * (4 + 6 + 6 + 3 + 3 + 1 + 3 + 3 + 2 + 4 + 4 + 1 + 3 + 45),
@@ -220,7 +220,9 @@ def hbm_kernels(op_times, N, Ftets, V_aug, T, B, H, W):
     as a fraction of the 8 TB/s HBM3E peak.  Ray traversal, hash-grid gathers and the bilateral taps are latency / ALU /
     L2 bound: their fractions are reported, not targeted."""
     out = []
-    masked = ("gs_env_shade_fwd", "gs_env_shade_bwd", "gs_hashgrid_fwd", "gs_hashgrid_bwd", "gs_texmlp_fwd", "gs_texmlp_bwd")   # covered pixels only
+    # covered pixels only (their byte counts depend on the coverage) / ALU- and atomic-bound stages: not HBM rooflines
+    masked = ("gs_env_shade_fwd", "gs_env_shade_bwd", "gs_hashgrid_encode_fwd", "gs_hashgrid_encode_bwd", "gs_texmlp_fwd_level_major",
+              "gs_texmlp_bwd_level_major", "gs_bilateral_fwd_masked", "gs_bilateral_bwd_masked")
     for name, alg in algorithmic_bytes(N, Ftets, V_aug, T, B, H, W).items():
         if name in masked:
             continue
