@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(256) k_softplus(const float* __restrict__ x, c
 // (gshell_tets_geometry.py:280-285 of the reference), the monochrome-lighting prior (regularizer.py:34-41) and the
 // material / normal smoothness terms (regularizer.py:21-31).  As torch ops these are ~230 launches over 1 M pixels.
 // The scalar combination (means, the specular / diffuse ratio, lambdas) stays in torch on the nine numbers.
-enum { FS_ALPHA = 0, FS_MSDF0, FS_MSDF1, FS_ERR, FS_SPEC, FS_DIFF, FS_KD, FS_KS, FS_NRM, FS_COUNT };
+enum { FS_ALPHA = 0, FS_MSDF0, FS_MSDF1, FS_ERR, FS_SPEC, FS_DIFF, FS_KD, FS_KS, FS_NRM, FS_IMG, FS_COUNT };      // FS_IMG: the *_img entry points only
 
 struct FrameOffs {   // channel offset of each buffer inside a pixel record, -1 = absent
     int shaded, msdf, diff, spec, kdg, ksg, nrmg;
@@ -293,7 +293,8 @@ __device__ __forceinline__ float fl_logsrgb(float x, float* grad) {
 
 template <bool BWD>
 __global__ void __launch_bounds__(256) k_frame_sums(const float* __restrict__ st, const float* __restrict__ ref, int64_t n, int C, FrameOffs o,
-                                                    float* __restrict__ partial, const float* __restrict__ g9, float* __restrict__ g_st) {
+                                                    float* __restrict__ partial, const float* __restrict__ g9, float* __restrict__ g_st, int n_sums,
+                                                    int img_loss, int img_tm) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float acc[FS_COUNT];
 #pragma unroll
@@ -308,6 +309,21 @@ __global__ void __launch_bounds__(256) k_frame_sums(const float* __restrict__ st
             const float a = p[o.shaded + 3];
             acc[FS_ALPHA] = (a - m) * (a - m);
             if (BWD) g[o.shaded + 3] = g9[FS_ALPHA] * 2.0f * (a - m);
+            if (img_loss >= 0) {
+                // the colour term of the image loss (gshell_tets_geometry.py:277: loss_fn(shaded rgb * m, reference rgb * m), the
+                // element sum of renderutils' image_loss, loss.cu) -- so that the frame has ONE consumer and ONE gradient tensor
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float x = p[o.shaded + c] * m, y = ref[4 * i + c] * m;
+                    const float tx = tonemap(x, img_tm), ty = tonemap(y, img_tm);
+                    acc[FS_IMG] += loss_fwd(tx, ty, img_loss);
+                    if (BWD) {
+                        float da, db;
+                        loss_bwd(tx, ty, img_loss, g9[FS_IMG], da, db);
+                        g[o.shaded + c] = tonemap_bwd(x, img_tm, da) * m;
+                    }
+                }
+            }
         }
         if (o.msdf >= 0) {
             const float x = p[o.msdf];
@@ -369,7 +385,7 @@ __global__ void __launch_bounds__(256) k_frame_sums(const float* __restrict__ st
         if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6][k] = v;
     }
     __syncthreads();
-    if (threadIdx.x < FS_COUNT) partial[(int64_t)blockIdx.x * FS_COUNT + threadIdx.x] = (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]);
+    if (threadIdx.x < n_sums) partial[(int64_t)blockIdx.x * n_sums + threadIdx.x] = (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]);
 }
 
 // ---- auto normals -----------------------------------------------------------------------------------
@@ -739,7 +755,19 @@ extern "C" int gs_frame_sums_fwd(const float* stacked, const float* color_ref, i
     GS_REQUIRE(stacked && color_ref && offs_host && partials && C > 0, "gs_frame_sums_fwd: null pointer");
     for (int k = 0; k < 7; ++k) GS_REQUIRE(offs_host[k] < 0 || offs_host[k] + (k == 1 ? 1 : 4) <= C, "gs_frame_sums_fwd: channel offset out of range");
     hipLaunchKernelGGL(k_frame_sums<false>, dim3((unsigned)gs::cdiv(n_pixels, 256)), dim3(256), 0, (hipStream_t)stream, stacked, color_ref, n_pixels,
-                       (int)C, frame_offs(offs_host), partials, (const float*)nullptr, (float*)nullptr);
+                       (int)C, frame_offs(offs_host), partials, (const float*)nullptr, (float*)nullptr, 9, -1, 0);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_frame_sums_img_fwd(const float* stacked, const float* color_ref, int64_t n_pixels, int64_t C, const int32_t* offs_host, int loss,
+                                     int tonemapper, float* partials10, gs_stream_t stream) {
+    if (n_pixels == 0) return 0;
+    GS_REQUIRE(stacked && color_ref && offs_host && partials10 && C > 0, "gs_frame_sums_img_fwd: null pointer");
+    GS_REQUIRE(loss >= 0 && loss <= 3 && tonemapper >= 0 && tonemapper <= 1 && offs_host[0] >= 0, "gs_frame_sums_img_fwd: bad loss / tonemapper / no shaded buffer");
+    for (int k = 0; k < 7; ++k) GS_REQUIRE(offs_host[k] < 0 || offs_host[k] + (k == 1 ? 1 : 4) <= C, "gs_frame_sums_img_fwd: channel offset out of range");
+    hipLaunchKernelGGL(k_frame_sums<false>, dim3((unsigned)gs::cdiv(n_pixels, 256)), dim3(256), 0, (hipStream_t)stream, stacked, color_ref, n_pixels,
+                       (int)C, frame_offs(offs_host), partials10, (const float*)nullptr, (float*)nullptr, 10, loss, tonemapper);
     GS_LAUNCH_CHECK();
     return 0;
 }
@@ -750,7 +778,19 @@ extern "C" int gs_frame_sums_bwd(const float* stacked, const float* color_ref, i
     GS_REQUIRE(stacked && color_ref && offs_host && g_sums_dev && g_stacked && C > 0, "gs_frame_sums_bwd: null pointer");
     for (int k = 0; k < 7; ++k) GS_REQUIRE(offs_host[k] < 0 || offs_host[k] + (k == 1 ? 1 : 4) <= C, "gs_frame_sums_bwd: channel offset out of range");
     hipLaunchKernelGGL(k_frame_sums<true>, dim3((unsigned)gs::cdiv(n_pixels, 256)), dim3(256), 0, (hipStream_t)stream, stacked, color_ref, n_pixels,
-                       (int)C, frame_offs(offs_host), (float*)nullptr, g_sums_dev, g_stacked);
+                       (int)C, frame_offs(offs_host), (float*)nullptr, g_sums_dev, g_stacked, 9, -1, 0);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_frame_sums_img_bwd(const float* stacked, const float* color_ref, int64_t n_pixels, int64_t C, const int32_t* offs_host, int loss,
+                                     int tonemapper, const float* g_sums10_dev, float* g_stacked, gs_stream_t stream) {
+    if (n_pixels == 0) return 0;
+    GS_REQUIRE(stacked && color_ref && offs_host && g_sums10_dev && g_stacked && C > 0, "gs_frame_sums_img_bwd: null pointer");
+    GS_REQUIRE(loss >= 0 && loss <= 3 && tonemapper >= 0 && tonemapper <= 1 && offs_host[0] >= 0, "gs_frame_sums_img_bwd: bad loss / tonemapper / no shaded buffer");
+    for (int k = 0; k < 7; ++k) GS_REQUIRE(offs_host[k] < 0 || offs_host[k] + (k == 1 ? 1 : 4) <= C, "gs_frame_sums_img_bwd: channel offset out of range");
+    hipLaunchKernelGGL(k_frame_sums<true>, dim3((unsigned)gs::cdiv(n_pixels, 256)), dim3(256), 0, (hipStream_t)stream, stacked, color_ref, n_pixels,
+                       (int)C, frame_offs(offs_host), (float*)nullptr, g_sums10_dev, g_stacked, 10, loss, tonemapper);
     GS_LAUNCH_CHECK();
     return 0;
 }

@@ -310,15 +310,18 @@ class GShellTetsGeometry(torch.nn.Module):
                                                          shadow_scale=shadow_scale, extra_dict={'msdf': d['msdf']})
         return d
 
-    def _frame_sum_weights(self, dev, n_px, with_msdf, with_light):
+    def _frame_sum_weights(self, dev, n_px, with_msdf, with_light, with_img=False):
         """constant weight vectors over regularizer.frame_sums' nine sums: (image terms, regulariser terms); cached on the device"""
         FL = self.FLAGS
-        key = (str(dev), n_px, with_msdf, with_light, FL.lambda_diffuse, FL.lambda_kd, FL.lambda_ks, FL.lambda_nrm)
+        key = (str(dev), n_px, with_msdf, with_light, with_img, FL.lambda_diffuse, FL.lambda_kd, FL.lambda_ks, FL.lambda_nrm)
         cache = self.__dict__.setdefault('_fs_weights', {})
         if key not in cache:
             w_img = [1.0 / n_px, 0.5 / n_px if with_msdf else 0.0, 0.5 / n_px if with_msdf else 0.0, 0, 0, 0, 0, 0, 0]
             w_reg = [0, 0, 0, FL.lambda_diffuse / n_px if with_light else 0.0, 0, 0, FL.lambda_kd / n_px, FL.lambda_ks / (3 * n_px),
                      FL.lambda_nrm / (3 * n_px)]
+            if with_img:       # image_loss is the mean over B*H*W*3 elements
+                w_img.append(1.0 / (3 * n_px))
+                w_reg.append(0.0)
             cache[key] = (torch.tensor(w_img, dtype=torch.float32, device=dev), torch.tensor(w_reg, dtype=torch.float32, device=dev))
         return cache[key]
 
@@ -337,7 +340,13 @@ class GShellTetsGeometry(torch.nn.Module):
         gt_mask = color_ref[..., 3:]
         # pixel sums of the alpha MSE, the mSDF image terms and the image-space regularisers in one fused pass
         stacked = getattr(buffers, 'stacked', None)
-        fs = regularizer.frame_sums(stacked, color_ref) if (stacked is not None and getattr(FL, "fused_frame_sums", True)) else None
+        # a loss object of this package names its (loss, tonemapper): the colour term then rides the same pass (fs[9])
+        img_spec = getattr(loss_fn, 'gs_spec', None) if getattr(FL, "fused_image_loss", True) else None
+        if stacked is None or 'shaded' not in stacked[1]:
+            img_spec = None
+        fs = regularizer.frame_sums(stacked, color_ref, img_spec) if (stacked is not None and getattr(FL, "fused_frame_sums", True)) else None
+        if fs is None:
+            img_spec = None
         n_px = float(gt_mask.numel())
         shard = getattr(FL, "view_shard", None)
         world = shard.world if shard is not None else 1
@@ -346,11 +355,12 @@ class GShellTetsGeometry(torch.nn.Module):
         if fs is not None:
             # every term that is LINEAR in the nine frame sums comes out of two dot products with constant weight vectors (the scalar
             # algebra of the reference's tick is ~140 five-microsecond launches per iteration when written operator by operator)
-            w_img, w_reg = self._frame_sum_weights(dev, n_px, use_fs_msdf, 'diffuse_light' in buffers)
+            w_img, w_reg = self._frame_sum_weights(dev, n_px, use_fs_msdf, 'diffuse_light' in buffers, img_spec is not None)
             img_loss = torch.dot(fs, w_img)
         else:
             img_loss = F.mse_loss(buffers['shaded'][..., 3:], gt_mask)
-        img_loss = img_loss + loss_fn(buffers['shaded'][..., 0:3] * gt_mask, color_ref[..., 0:3] * gt_mask)
+        if img_spec is None:
+            img_loss = img_loss + loss_fn(buffers['shaded'][..., 0:3] * gt_mask, color_ref[..., 0:3] * gt_mask)
         if not use_fs_msdf:
             msdf_img = buffers['msdf_image']
             img_loss = img_loss + 5e-1 * F.l1_loss(msdf_img.clamp(min=0) * (gt_mask == 0).float(), torch.zeros_like(gt_mask))

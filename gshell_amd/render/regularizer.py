@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from .. import _lib
-from .._lib import c_int64, check, ptr, stream
+from .._lib import c_int, c_int64, check, ptr, stream
 from . import util
 
 FRAME_SUM_BUFFERS = ('shaded', 'msdf_image', 'diffuse_light', 'specular_light', 'kd_grad', 'ks_grad', 'normal_grad')
@@ -15,7 +15,7 @@ FRAME_SUM_BUFFERS = ('shaded', 'msdf_image', 'diffuse_light', 'specular_light', 
 
 class _FrameSumsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, stacked, color_ref, offs):
+    def forward(ctx, stacked, color_ref, offs, img=None):
         st, ref = stacked.detach().contiguous().float(), color_ref.detach().contiguous().float()
         C = st.shape[-1]
         n = st.numel() // C
@@ -23,12 +23,16 @@ class _FrameSumsFn(torch.autograd.Function):
             raise _lib.GShellHipError(f"frame_sums: color_ref {tuple(ref.shape)} does not match the frame {tuple(st.shape)}")
         c_offs = (ctypes.c_int32 * 7)(*offs)
         L = _lib.lib()
-        partial = torch.empty((int(L.gs_frame_sums_partials(c_int64(n))), 9), dtype=torch.float32, device=st.device)
+        partial = torch.empty((int(L.gs_frame_sums_partials(c_int64(n))), 9 if img is None else 10), dtype=torch.float32, device=st.device)
         with torch.cuda.device(st.device):
-            check(L.gs_frame_sums_fwd(ptr(st, torch.float32, "stacked"), ptr(ref, torch.float32, "color_ref"), c_int64(n), c_int64(C), c_offs,
-                                      ptr(partial), stream()), "gs_frame_sums_fwd")
+            if img is None:
+                check(L.gs_frame_sums_fwd(ptr(st, torch.float32, "stacked"), ptr(ref, torch.float32, "color_ref"), c_int64(n), c_int64(C), c_offs,
+                                          ptr(partial), stream()), "gs_frame_sums_fwd")
+            else:
+                check(L.gs_frame_sums_img_fwd(ptr(st, torch.float32, "stacked"), ptr(ref, torch.float32, "color_ref"), c_int64(n), c_int64(C), c_offs,
+                                              c_int(img[0]), c_int(img[1]), ptr(partial), stream()), "gs_frame_sums_img_fwd")
         ctx.save_for_backward(st, ref)
-        ctx.offs = tuple(offs)
+        ctx.offs, ctx.img = tuple(offs), img
         return partial.sum(0)
 
     @staticmethod
@@ -40,19 +44,27 @@ class _FrameSumsFn(torch.autograd.Function):
         g_st = torch.empty_like(st)
         c_offs = (ctypes.c_int32 * 7)(*ctx.offs)
         with torch.cuda.device(st.device):
-            check(_lib.lib().gs_frame_sums_bwd(ptr(st), ptr(ref), c_int64(n), c_int64(C), c_offs, ptr(g9), ptr(g_st), stream()), "gs_frame_sums_bwd")
-        return g_st, None, None
+            if ctx.img is None:
+                check(_lib.lib().gs_frame_sums_bwd(ptr(st), ptr(ref), c_int64(n), c_int64(C), c_offs, ptr(g9), ptr(g_st), stream()), "gs_frame_sums_bwd")
+            else:
+                check(_lib.lib().gs_frame_sums_img_bwd(ptr(st), ptr(ref), c_int64(n), c_int64(C), c_offs, c_int(ctx.img[0]), c_int(ctx.img[1]), ptr(g9),
+                                                       ptr(g_st), stream()), "gs_frame_sums_img_bwd")
+        return g_st, None, None, None
 
 
-def frame_sums(stacked_info, color_ref):
+def frame_sums(stacked_info, color_ref, img_loss=None):
     """stacked_info = (tensor [B,H,W,C], buffer names, channel counts) = render_mesh(...).stacked.
     Returns a [9] tensor: sum (a-m)^2, sum |msdf+[m=0]|, sum |msdf-[m=1]-1|, sum |logsrgb((d+s)m) - logsrgb(value(ref)m)|,
-    sum luma(spec), sum luma(diff), sum kd_grad term, sum ks_grad term, sum normal_grad term  (m = reference alpha)."""
+    sum luma(spec), sum luma(diff), sum kd_grad term, sum ks_grad term, sum normal_grad term  (m = reference alpha).
+    `img_loss` = (loss id, tonemapper id) of renderutils.image_loss: a TENTH entry, the element sum of
+    image_loss(shaded rgb * m, reference rgb * m) (the colour term of the training loss)."""
     stacked, keys, sizes = stacked_info
     offs = []
     for name in FRAME_SUM_BUFFERS:
         offs.append(sum(sizes[:keys.index(name)]) if name in keys else -1)
-    return _FrameSumsFn.apply(stacked, color_ref, tuple(offs))
+    if img_loss is not None and offs[0] < 0:
+        img_loss = None
+    return _FrameSumsFn.apply(stacked, color_ref, tuple(offs), None if img_loss is None else (int(img_loss[0]), int(img_loss[1])))
 
 
 _EPS = 1e-3

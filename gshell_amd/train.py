@@ -40,7 +40,19 @@ def default_flags(**overrides):
 def create_loss(FLAGS):
     table = {"smape": ('smape', 'none'), "mse": ('mse', 'none'), "logl1": ('l1', 'log_srgb'), "logl2": ('mse', 'log_srgb'), "relmse": ('relmse', 'none')}
     l, tm = table[FLAGS.loss]
-    return lambda img, ref: ru.image_loss(img, ref, loss=l, tonemapper=tm)
+    return ImageLoss(l, tm)
+
+
+class ImageLoss:
+    """The reference's createLoss closure (train script: ru.image_loss with a fixed loss / tonemapper) as an object: `gs_spec`
+    lets GShellTetsGeometry.tick fold the colour term into its one pass over the frame (regularizer.frame_sums)."""
+
+    def __init__(self, loss, tonemapper):
+        self.loss, self.tonemapper = loss, tonemapper
+        self.gs_spec = (ru._LOSS[loss], ru._TONEMAP[tonemapper])
+
+    def __call__(self, img, ref):
+        return ru.image_loss(img, ref, loss=self.loss, tonemapper=self.tonemapper)
 
 
 class ViewShard:

@@ -408,6 +408,16 @@ int gs_frame_sums_fwd(const float* stacked, const float* color_ref, int64_t n_pi
 int gs_frame_sums_bwd(const float* stacked, const float* color_ref, int64_t n_pixels, int64_t C,
                       const int32_t* offs_host, const float* g_sums_dev, float* g_stacked,
                       gs_stream_t stream);
+/* the same pass with a TENTH sum: the colour term of the image loss, sum over pixels and rgb of
+ * loss(tonemap(shaded * m), tonemap(reference * m))  (gshell_tets_geometry.py:277 through renderutils' image_loss,
+ * loss / tonemapper ids as gs_image_loss_fwd) -- the frame then has one consumer and one gradient tensor.
+ * partials10 [gs_frame_sums_partials(n_pixels), 10], g_sums10_dev [10]. */
+int gs_frame_sums_img_fwd(const float* stacked, const float* color_ref, int64_t n_pixels, int64_t C,
+                          const int32_t* offs_host, int loss, int tonemapper, float* partials10,
+                          gs_stream_t stream);
+int gs_frame_sums_img_bwd(const float* stacked, const float* color_ref, int64_t n_pixels, int64_t C,
+                          const int32_t* offs_host, int loss, int tonemapper,
+                          const float* g_sums10_dev, float* g_stacked, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Texture-field MLP   (replaces the torch `_MLP` + sigmoid range mapping of MLPTexture3D.sample,

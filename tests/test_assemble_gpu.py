@@ -36,3 +36,31 @@ def test_fused_assembly_equals_the_torch_formulation(denoise):
         assert (x is None) == (y is None)
         if x is not None:
             assert float((x - y).norm()) <= 1e-4 * float(y.norm()) + 1e-12
+
+
+def test_tick_with_the_colour_term_in_the_frame_pass_equals_the_separate_image_loss():
+    """FLAGS.fused_image_loss: tick folds loss_fn's colour term into regularizer.frame_sums (one consumer, one gradient tensor of
+    the frame) when the loss object names its (loss, tonemapper); same losses (1e-6) and parameter gradients (1e-5) as calling
+    loss_fn on the masked colours."""
+    from gshell_amd import workload
+    from gshell_amd.render import render
+    torch.manual_seed(0)
+    tr = workload.build(res=16, n_samples=2, batch=2, train_res=(48, 56), fit_steps=40)
+    target = workload.make_targets(tr, [1, 4], (48, 56))
+    res = []
+    for fused in (True, False):
+        tr.FLAGS.fused_image_loss = fused
+        render.rnd_seed = 5
+        tr.FLAGS.noise_stream.set_iteration(7)
+        for p in tr.all_params():
+            p.grad = None
+        tr.lgt.update_pdf()
+        img_loss, _, reg_loss = tr.geometry.tick(tr.glctx, target, tr.lgt, tr.mat, tr.loss_fn, 1200, denoiser=tr.denoiser)
+        (img_loss + reg_loss).backward()
+        res.append((float(img_loss), float(reg_loss), [None if p.grad is None else p.grad.clone() for p in tr.all_params()]))
+    (ia, ra, ga), (ib, rb, gb) = res
+    assert abs(ia - ib) <= 1e-6 * abs(ib) + 1e-9 and abs(ra - rb) <= 1e-6 * abs(rb) + 1e-9
+    for x, y in zip(ga, gb):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert float((x - y).norm()) <= 1e-5 * float(y.norm()) + 1e-12

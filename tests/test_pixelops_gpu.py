@@ -222,6 +222,37 @@ def test_frame_sums_match_the_torch_terms(with_light):
     assert float((got_g - stacked.grad).abs().max()) <= 1e-4 * scale
 
 
+@pytest.mark.parametrize("loss,tm", [("l1", "log_srgb"), ("mse", "log_srgb"), ("smape", "none"), ("relmse", "none"), ("mse", "none")])
+def test_frame_sums_colour_term_equals_image_loss(loss, tm):
+    """gs_frame_sums_img_*: the tenth sum is the element sum of renderutils.image_loss(shaded rgb * m, reference rgb * m) (pinned to
+    the reference's loss twins in test_image_loss_*), the other nine sums are unchanged, and the gradient of the frame is the sum of
+    the two separate gradients."""
+    from gshell_amd.render import regularizer as R, renderutils as ru
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B, H, W = 2, 29, 35
+    keys, sizes = ['shaded', 'kd_grad', 'ks_grad', 'normal_grad', 'diffuse_light', 'specular_light', 'msdf_image'], [4, 4, 4, 4, 4, 4, 1]
+    stacked = (torch.rand(B, H, W, sum(sizes), device="cuda", generator=g) * 1.5).requires_grad_(True)
+    with torch.no_grad():
+        stacked[0, 0, :6, 0:3] = 0.0                                     # tonemapper knee / clamp edge
+        stacked[0, 1, :6, 0:3] *= 40.0
+    ref = torch.rand(B, H, W, 4, device="cuda", generator=g)
+    ref[..., 3] = (ref[..., 3] > 0.4).float()
+    ref[1, 2, :9, 3] = 0.41
+    w = torch.rand(10, device="cuda", generator=g) + 0.5
+    spec = (ru._LOSS[loss], ru._TONEMAP[tm])
+    fs10 = R.frame_sums((stacked, keys, sizes), ref, spec)
+    (fs10 * w).sum().backward()
+    got = stacked.grad.clone()
+    stacked.grad = None
+    fs9 = R.frame_sums((stacked, keys, sizes), ref)
+    m = ref[..., 3:]
+    img = ru.image_loss(stacked[..., 0:3] * m, ref[..., 0:3] * m, loss=loss, tonemapper=tm) * (3.0 * m.numel())
+    assert torch.equal(fs10[:9], fs9)
+    assert abs(float(fs10[9]) - float(img)) <= 1e-5 * abs(float(img)) + 1e-6
+    ((fs9 * w[:9]).sum() + img * w[9]).backward()
+    assert float((got - stacked.grad).abs().max()) <= 1e-5 * float(stacked.grad.abs().max())
+
+
 def test_sdf_net_torch_formulation_fast_paths_match_plain_modules():
     """geometry/mlp.py swaps in a split-K Linear and HIP softplus kernels (value / gradient / gradient of the gradient) for
     large row counts.  Against the plain nn.Linear / nn.Softplus modules: outputs 1e-6, eikonal-style double-backward
