@@ -895,6 +895,31 @@ __global__ void __launch_bounds__(256) k_sdf_reg_bwd(const float* __restrict__ s
 }
 
 
+// ---- surface samples for the eikonal term (kaolin.ops.mesh.sample_points stand-in, gshell_tets_geometry.py:236) --------------------
+// area[t] = |(v1 - v0) x (v2 - v0)| (non-finite -> 0) + 1e-20: the weights of the face draw (torch.multinomial stays in torch: its
+// generator is part of the reproducibility contract); then p = (1-u) v0 + u (1-v) v1 + u v v2 with (u, v) = (sqrt(r0), r1).
+__global__ void __launch_bounds__(256) k_tri_area(const float* __restrict__ v, const int32_t* __restrict__ tri, int64_t T, float* __restrict__ area) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const f3 v0 = ld3(v + 3 * (int64_t)tri[3 * t]), v1 = ld3(v + 3 * (int64_t)tri[3 * t + 1]), v2 = ld3(v + 3 * (int64_t)tri[3 * t + 2]);
+    const f3 n = cross(v1 - v0, v2 - v0);
+    const float a = sqrtf(dot(n, n));
+    area[t] = (isfinite(a) ? a : 0.0f) + 1e-20f;
+}
+
+__global__ void __launch_bounds__(256) k_surface_points(const float* __restrict__ v, const int32_t* __restrict__ tri, const int64_t* __restrict__ fid,
+                                                        const float* __restrict__ r, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t t = fid[i];
+    const f3 v0 = ld3(v + 3 * (int64_t)tri[3 * t]), v1 = ld3(v + 3 * (int64_t)tri[3 * t + 1]), v2 = ld3(v + 3 * (int64_t)tri[3 * t + 2]);
+    const float u = sqrtf(r[2 * i]), w = r[2 * i + 1];
+    const float a = 1.0f - u, b = u * (1.0f - w), c = u * w;
+    out[3 * i] = a * v0.x + b * v1.x + c * v2.x;
+    out[3 * i + 1] = a * v0.y + b * v1.y + c * v2.y;
+    out[3 * i + 2] = a * v0.z + b * v1.z + c * v2.z;
+}
+
 // ---- mSDF open / close regularisers (gshell_tets_geometry.py:326-358) -----------------------------------------------
 // Huber (delta = 1) distance of the clamped mSDF values to -eps (all N grid values, "open") / +eps (the boundary vertices of
 // triangles some view saw, "close").  As ATen ops: clamp, expand, huber_loss, mul, sum per term plus the visibility mask
@@ -1013,6 +1038,23 @@ extern "C" int gs_msdf_reg_bwd(const float* msdf, int64_t N, const float* msdf_b
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_msdf_reg_bwd, dim3((unsigned)std::min<int64_t>(gs::cdiv(n, 256), 2048)), dim3(256), 0, (hipStream_t)stream, msdf, N, msdf_boundary,
                        weight, n_boundary, eps, open_w, close_w, g_out2_dev, g_msdf, g_boundary);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_tri_area(const float* v_pos, const int32_t* tri, int64_t T, float* area, gs_stream_t stream) {
+    if (T == 0) return 0;
+    GS_REQUIRE(v_pos && tri && area, "gs_tri_area: null pointer");
+    hipLaunchKernelGGL(k_tri_area, dim3((unsigned)gs::cdiv(T, 256)), dim3(256), 0, (hipStream_t)stream, v_pos, tri, T, area);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_surface_points(const float* v_pos, const int32_t* tri, const int64_t* face_id, const float* r01, int64_t n, float* out,
+                                 gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_REQUIRE(v_pos && tri && face_id && r01 && out, "gs_surface_points: null pointer");
+    hipLaunchKernelGGL(k_surface_points, dim3((unsigned)gs::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, v_pos, tri, face_id, r01, n, out);
     GS_LAUNCH_CHECK();
     return 0;
 }

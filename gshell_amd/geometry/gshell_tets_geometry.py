@@ -134,6 +134,22 @@ def sample_points(v_pos, faces, n, generator=None):
     return (1 - u) * v0[fid] + u * (1 - v) * v1[fid] + u * v * v2[fid], fid
 
 
+def sample_points_detached(v_pos, faces_i32, n, generator=None):
+    """sample_points without a graph (the reference detaches the samples before use, :303): two kernels around torch's
+    multinomial / rand (whose generator is the reproducibility contract of view-sharded jobs) instead of ~25 ATen launches."""
+    v = v_pos.detach().contiguous().float()
+    T = faces_i32.shape[0]
+    area = torch.empty(T, dtype=torch.float32, device=v.device)
+    out = torch.empty((n, 3), dtype=torch.float32, device=v.device)
+    with torch.cuda.device(v.device):
+        check(_lib.lib().gs_tri_area(ptr(v, torch.float32, "v_pos"), ptr(faces_i32, torch.int32, "faces"), c_int64(T), ptr(area), stream()), "gs_tri_area")
+        fid = torch.multinomial(area, n, replacement=True, generator=generator)
+        r = torch.rand(n, 2, device=v.device, generator=generator)
+        check(_lib.lib().gs_surface_points(ptr(v), ptr(faces_i32), ptr(fid, torch.int64, "face ids"), ptr(r), c_int64(n), ptr(out), stream()),
+              "gs_surface_points")
+    return out, fid
+
+
 class GShellTetsGeometry(torch.nn.Module):
     def __init__(self, grid_res, scale, FLAGS, offset=None, tet_init_file=None, extract_from_generative=False, tet_grid=None):
         super().__init__()
@@ -295,7 +311,10 @@ class GShellTetsGeometry(torch.nn.Module):
         if opt_mesh.v_pos.size(0) != 0 and opt_mesh.t_pos_idx.size(0) != 0:
             ns = getattr(self.FLAGS, 'noise_stream', None)       # seeded by (iteration) on every rank of a view-sharded job
             gen = ns.generator('eikonal', opt_mesh.v_pos.device) if ns is not None else None
-            d['sampled_pts'] = sample_points(opt_mesh.v_pos, opt_mesh.t_pos_idx, 50000, generator=gen)[0]
+            if opt_mesh.v_pos.is_cuda and hasattr(opt_mesh, 'faces_i32'):
+                d['sampled_pts'] = sample_points_detached(opt_mesh.v_pos, opt_mesh.faces_i32().contiguous(), 50000, generator=gen)[0]
+            else:
+                d['sampled_pts'] = sample_points(opt_mesh.v_pos, opt_mesh.t_pos_idx, 50000, generator=gen)[0]
         else:
             d['sampled_pts'] = None
         if _with_eikonal and self.FLAGS.use_sdf_mlp and self.FLAGS.use_eikonal and d['sampled_pts'] is not None:

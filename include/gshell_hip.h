@@ -444,6 +444,17 @@ int gs_texmlp_bwd_level_major(const float* x, const float* mask, int64_t N, cons
                               float* g_w2, float* g_w3, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Surface samples for the eikonal term   (stands in for kaolin.ops.mesh.sample_points, third party, called at
+ *   geometry/gshell_tets_geometry.py:236; the samples are detached at :303, so no gradient is needed)
+ *   gs_tri_area: area [T] WRITTEN = |(v1 - v0) x (v2 - v0)| (non-finite -> 0) + 1e-20 = the weights of the face draw;
+ *   gs_surface_points: out [n,3] = (1-u) v0 + u (1-v) v1 + u v v2 of face face_id[i] (int64, e.g. torch.multinomial),
+ *     (u, v) = (sqrt(r01[i,0]), r01[i,1]).
+ * ---------------------------------------------------------------------------------- */
+int gs_tri_area(const float* v_pos, const int32_t* tri, int64_t T, float* area, gs_stream_t stream);
+int gs_surface_points(const float* v_pos, const int32_t* tri, const int64_t* face_id, const float* r01,
+                      int64_t n, float* out, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * mSDF open / close regularisers   (replaces geometry/gshell_tets_geometry.py:326-358: Huber (delta 1) of
  *   clamp(msdf, min=-eps) to -eps over ALL grid values, and of clamp(msdf_boundary, max=eps) to +eps over the boundary
  *   vertices of the triangles some view saw)

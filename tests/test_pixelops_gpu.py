@@ -320,3 +320,35 @@ def test_msdf_regularisers_match_the_reference_formulation(N, nb, T):
     assert torch.allclose(md.grad.cpu().double(), m64.grad, rtol=1e-6, atol=1e-9)
     if nb:
         assert torch.allclose(bd.grad.cpu().double(), b64.grad, rtol=1e-6, atol=1e-9)
+
+
+def test_surface_sampling_kernels_match_the_torch_formulation():
+    """gs_tri_area / gs_surface_points vs geometry.sample_points' torch expressions: areas 1e-6 relative (degenerate and non-finite
+    triangles included), points 1e-6 for the same face ids and random numbers; and the product function draws from the generator
+    exactly like the torch formulation (same multinomial / rand calls), so ranks of a view-sharded job agree."""
+    from gshell_amd import _lib
+    from gshell_amd._lib import c_int64, check, ptr, stream
+    from gshell_amd.geometry.gshell_tets_geometry import sample_points, sample_points_detached
+    g = torch.Generator(device="cuda").manual_seed(21)
+    V, T, n = 5000, 9000, 20000
+    v = torch.randn(V, 3, device="cuda", generator=g)
+    tri = torch.randint(0, V, (T, 3), device="cuda", generator=g).int()
+    tri[5] = tri[5, 0]                                    # degenerate
+    v[tri[7, 1].long()] = float("inf")                    # non-finite area -> weight 1e-20
+    vf = v.clone()
+    v0, v1, v2 = vf[tri[:, 0].long()], vf[tri[:, 1].long()], vf[tri[:, 2].long()]
+    area_ref = torch.linalg.cross(v1 - v0, v2 - v0).norm(dim=-1)
+    area_ref = torch.where(torch.isfinite(area_ref), area_ref, torch.zeros_like(area_ref)) + 1e-20
+    area = torch.empty(T, device="cuda")
+    check(_lib.lib().gs_tri_area(ptr(vf), ptr(tri), c_int64(T), ptr(area), stream()), "gs_tri_area")
+    assert torch.allclose(area, area_ref, rtol=2e-6, atol=0)
+    finite = torch.isfinite(vf).all(dim=1)
+    ok_tri = finite[tri.long()].all(dim=1)
+    tri_ok = tri[ok_tri].contiguous()
+    gen_a, gen_b = torch.Generator(device="cuda").manual_seed(5), torch.Generator(device="cuda").manual_seed(5)
+    pts_a, fid_a = sample_points_detached(vf, tri_ok, n, generator=gen_a)
+    pts_b, fid_b = sample_points(vf, tri_ok.long(), n, generator=gen_b)
+    same = fid_a == fid_b                                  # an ulp in an area can move a draw to the neighbouring face
+    assert float(same.float().mean()) > 0.999
+    assert torch.allclose(pts_a[same], pts_b[same], rtol=1e-5, atol=1e-6)
+    assert torch.equal(torch.rand(3, device="cuda", generator=gen_a), torch.rand(3, device="cuda", generator=gen_b))    # same generator consumption
