@@ -11,7 +11,8 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgshell_hip.so")
+# GSHELL_HIP_LIB: an alternative build of the same library (tools/build_variant.sh: compile-time experiments built on the CPU box)
+LIB_PATH = os.environ.get("GSHELL_HIP_LIB") or os.path.join(_HERE, "lib", "libgshell_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gshell_hip.h")
 
 _lib = None

@@ -425,7 +425,8 @@ struct BwdArgs {
     const float* g_out;   // [Rpad] upstream gradient per (virtual) row; 0 on padding rows
     const float* A;       // [n_layers][Rpad][256]
     const float* EMB;     // [Rpad][EK]
-    float* Dsave;         // [n_layers][Rpad][256]  WRITTEN
+    float* Dsave;         // [n_layers][Rpad][256]  WRITTEN: the row-NORMALISED adjoints as fp16 pairs (hi | lo << 16), see decode_d
+    float* row_scale;     // [Rpad] WRITTEN: 1 / normalisation of the row (a power of two): d = decode_d(Dsave) * row_scale
     const int32_t* rows;  // ROWS: [R]
     float* g_x;           // ROWS: [N,3] scatter target (rows are unique), or null
     int64_t R, Rpad;
@@ -472,6 +473,10 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
     const float isc[2] = {1.0f / sc[0], 1.0f / sc[1]};       // exact (powers of two)
     go[0] *= sc[0];
     go[1] *= sc[1];
+    if (wave == 0 && lane < 32) {
+        B.row_scale[r0 + lane] = isc[0];
+        B.row_scale[r0 + 32 + lane] = isc[1];
+    }
     if (need_x) {
         for (int i = tid; i < TM * LDG; i += NT) GE[i] = 0.f;
         if (wave == 0 && lane < 32) { SC[lane] = isc[0]; SC[32 + lane] = isc[1]; }
@@ -492,8 +497,16 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
 
     // the saved outputs of a layer are fetched one layer AHEAD (issued before the GEMM of the layer above, consumed after its
     // closing barrier): per-lane 16-byte pieces at a 1 KB row stride are latency, not bandwidth
+#ifndef GS_H2_ABL
+#define GS_H2_ABL 0      // experiments (tools/build_variant.sh): 1 = no D-plane stores, 2 = no A-plane loads, 4 = no dgrad GEMM
+#endif
     float4 an[2][4];
     auto fetch_plane = [&](int l) {
+        if (GS_H2_ABL & 2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) an[0][g] = an[1][g] = make_float4(0.01f * (float)(l + g), 0.02f, 0.03f, 0.04f);
+            return;
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             an[0][g] = *reinterpret_cast<const float4*>(B.A + ((int64_t)l * B.Rpad + r0 + m_lane) * D + n_base + 8 * g);
@@ -530,11 +543,9 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
                     }
                 }
             }
-            *reinterpret_cast<float4*>(B.Dsave + ((int64_t)l * B.Rpad + r0 + m_lane) * D + n_base + 8 * g) =
-                make_float4(d0[0] * isc[0], d0[1] * isc[0], d0[2] * isc[0], d0[3] * isc[0]);
-            *reinterpret_cast<float4*>(B.Dsave + ((int64_t)l * B.Rpad + r0 + 32 + m_lane) * D + n_base + 8 * g) =
-                make_float4(d1[0] * isc[1], d1[1] * isc[1], d1[2] * isc[1], d1[3] * isc[1]);
-            if (l > 0 || need_x) {
+            // D_l goes to LDS as fp16 pairs (the dgrad GEMM's operands) and from THERE to HBM, whole rows at a time: the per-lane
+            // stores of the accumulator layout (16 bytes at a 1 KB stride) cost 0.3 of this kernel's 0.8 ms (tools/chain_time.py)
+            {
                 h2 p0, q0, p1, q1;
                 split_h2_pair(f2{d0[0], d0[1]}, p0, q0);
                 split_h2_pair(f2{d0[2], d0[3]}, p1, q1);
@@ -548,18 +559,28 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
                 *reinterpret_cast<h4*>(H2 + off) = h4{q0.x, q0.y, q1.x, q1.y};
             }
         }
-        if (l == 0 && !need_x) break;
 #ifndef GS_H2_BWD_PREFETCH
 #define GS_H2_BWD_PREFETCH 0     // 1: issue the next plane's loads BEFORE the GEMM (spills: 71 / 22 VGPRs), 0: after it, before the closing
 #endif                           //    barrier; 2: before for <EIK>, after for <ROWS>.  Measured (both calls, ms): HEAD 1.78, 1 -> 1.67, 0 -> 1.47
         constexpr bool EARLY = GS_H2_BWD_PREFETCH == 1 || (GS_H2_BWD_PREFETCH == 2 && MODE == MODE_EIK);
         if (EARLY && l > 0) fetch_plane(l - 1);
         __syncthreads();
+        if (!(GS_H2_ABL & 1)) {
+            // packed D plane: 512 threads x 16 bytes = two whole rows per pass, 32 passes
+            uint4* dst = reinterpret_cast<uint4*>(B.Dsave + ((int64_t)l * B.Rpad + r0) * D);
+            for (int q = tid; q < TM * (D / 4); q += NT) {
+                const int row = q >> 6, c4 = (q & 63) * 4;
+                const uint2 hh = *reinterpret_cast<const uint2*>(H1 + row * LDH + c4), ll = *reinterpret_cast<const uint2*>(H2 + row * LDH + c4);
+                dst[q] = make_uint4((hh.x & 0xffffu) | (ll.x << 16), (hh.x >> 16) | (ll.x & 0xffff0000u), (hh.y & 0xffffu) | (ll.y << 16),
+                                    (hh.y >> 16) | (ll.y & 0xffff0000u));
+            }
+        }
+        if (l == 0 && !need_x) break;
         // ---- G = W_l^T D_l
         v16f hi[2], lo[2];
         if (l > 0) {
             zero_acc(hi, lo);
-            gemm_seg<LDH, D / 16>(hi, lo, H1, H2, B.wfragT[l], wave, B.nblkT[l], lane);
+            if (!(GS_H2_ABL & 4)) gemm_seg<LDH, D / 16>(hi, lo, H1, H2, B.wfragT[l], wave, B.nblkT[l], lane);
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -608,10 +629,20 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
 // they lie -- no transposition).  Wave w owns features [32 w, 32 w + 32) x all K: up to 10 accumulator blocks.
 // The bias gradient is the column sum of the D slab, taken from the staging registers (each thread always holds the same four
 // features); partial results of the strips are combined with float atomics into the (zeroed) torch-layout gradient tensors.
+// one element of a D plane: bits = fp16 hi | fp16 lo << 16 of the row-normalised adjoint (exactly the operands the dgrad GEMM used)
+__device__ __forceinline__ float decode_d(float packed, float row_scale) {
+    const uint32_t u = __float_as_uint(packed);
+    union { uint16_t b; _Float16 h; } hi, lo;
+    hi.b = (uint16_t)(u & 0xffffu);
+    lo.b = (uint16_t)(u >> 16);
+    return __builtin_fmaf((float)lo.h, LO_INV, (float)hi.h) * row_scale;
+}
+
 struct WgradArgs {
     const float* A;       // [n_layers][Rpad][256]
     const float* EMB;     // [Rpad][EK]
-    const float* D;       // [n_layers][Rpad][256]
+    const float* D;       // [n_layers][Rpad][256]  packed fp16 pairs of the row-normalised adjoints (k_h2_bwd)
+    const float* row_scale;   // [Rpad]
     const float* g_out;   // [Rpad]
     int64_t Rpad, n;      // rows of the planes; rows in use (ROWS: the count or its capacity; EIK: all of Rpad)
     const int64_t* n_dev; // optional device-resident row count: only the tiles below it are reduced
@@ -655,7 +686,9 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs& W, int l, float* sm
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t row = rbase + (tid >> 6) + 8 * i;
-            dreg[i] = *reinterpret_cast<const float4*>(Dl + row * D + 4 * (tid & 63));
+            const float4 dp = *reinterpret_cast<const float4*>(Dl + row * D + 4 * (tid & 63));
+            const float rs = W.row_scale[row];
+            dreg[i] = make_float4(decode_d(dp.x, rs), decode_d(dp.y, rs), decode_d(dp.z, rs), decode_d(dp.w, rs));
             if (HAS_H) xreg[i] = *reinterpret_cast<const float4*>(Xh + row * D + 4 * (tid & 63));
         }
         if (HAS_E && tid < WS * (EK / 4)) ereg = *reinterpret_cast<const float4*>(W.EMB + (rbase + tid / (EK / 4)) * EK + 4 * (tid % (EK / 4)));
@@ -781,7 +814,7 @@ __device__ __forceinline__ void wgrad16_layer(const WgradArgs& W, int l, __bf16*
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                dreg[c][i] = Dl[(r0 + i) * D + lane + 64 * c];
+                dreg[c][i] = decode_d(Dl[(r0 + i) * D + lane + 64 * c], W.row_scale[r0 + i]);
                 if (HAS_H) xreg[c][i] = Xh[(r0 + i) * D + lane + 64 * c];
             }
         if (HAS_E)
@@ -1203,15 +1236,15 @@ extern "C" int gs_sdf_mlp_h2_save_fwd(int mode, const float* x, const int32_t* r
 // row); mode 1 with g_x != NULL: g_x[rows[r]] (of [N,3]) WRITTEN for r < n (dL/dx through the encoding).  g_out [Rpad]:
 // upstream gradient per virtual row, 0 on padding rows.
 extern "C" int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* rows, int64_t n, const int64_t* n_dev, const void* packed, int n_freq,
-                                 int n_hidden, int skip_layer, const float* A_save, const float* EMB_save, float* D_save, float* g_x,
-                                 gs_stream_t stream) {
+                                 int n_hidden, int skip_layer, const float* A_save, const float* EMB_save, float* D_save, float* row_scale,
+                                 float* g_x, gs_stream_t stream) {
     if (n == 0) return 0;
     GS_REQUIRE(mode == MODE_ROWS || mode == MODE_EIK, "gs_sdf_mlp_h2_bwd: mode must be 1 (rows) or 2 (eikonal)");
-    GS_REQUIRE(g_out && packed && A_save && EMB_save && D_save && (mode == MODE_EIK || rows != nullptr), "gs_sdf_mlp_h2_bwd: null pointer");
+    GS_REQUIRE(g_out && packed && A_save && EMB_save && D_save && row_scale && (mode == MODE_EIK || rows != nullptr), "gs_sdf_mlp_h2_bwd: null pointer");
     if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
     PackLayout L = make_layout(n_freq, n_hidden, skip_layer);
     BwdArgs B{};
-    B.g_out = g_out; B.A = A_save; B.EMB = EMB_save; B.Dsave = D_save; B.rows = rows; B.g_x = mode == MODE_ROWS ? g_x : nullptr;
+    B.g_out = g_out; B.A = A_save; B.EMB = EMB_save; B.Dsave = D_save; B.row_scale = row_scale; B.rows = rows; B.g_x = mode == MODE_ROWS ? g_x : nullptr;
     B.R = n; B.n_dev = mode == MODE_ROWS ? n_dev : nullptr; B.Rpad = gs_sdf_mlp_h2_rows_padded(mode, n); B.E = L.E; B.n_layers = L.n_layers; B.skip_layer = L.skip_layer;
     for (int l = 0; l < L.n_layers; ++l) {
         B.wfragT[l] = (const h8*)packed + L.fragT_off[l];
@@ -1234,14 +1267,14 @@ extern "C" int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* ro
 // dW, db = HOST arrays of n_hidden + 2 DEVICE pointers (Linear.weight.grad [out,in], Linear.bias.grad), output layer last;
 // db[n_hidden + 1] (the output bias, = sum of g_out over the value rows) is not touched.
 extern "C" int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, const int64_t* n_dev, int n_freq, int n_hidden, int skip_layer,
-                                   const float* A_save, const float* EMB_save, const float* D_save, float* const* dW, float* const* db, int exact_fp32,
-                                   gs_stream_t stream) {
+                                   const float* A_save, const float* EMB_save, const float* D_save, const float* row_scale, float* const* dW,
+                                   float* const* db, int exact_fp32, gs_stream_t stream) {
     if (n == 0) return 0;
     GS_REQUIRE(mode == MODE_ROWS || mode == MODE_EIK, "gs_sdf_mlp_h2_wgrad: mode must be 1 (rows) or 2 (eikonal)");
-    GS_REQUIRE(g_out && A_save && EMB_save && D_save && dW && db, "gs_sdf_mlp_h2_wgrad: null pointer");
+    GS_REQUIRE(g_out && A_save && EMB_save && D_save && row_scale && dW && db, "gs_sdf_mlp_h2_wgrad: null pointer");
     if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
     WgradArgs W{};
-    W.A = A_save; W.EMB = EMB_save; W.D = D_save; W.g_out = g_out; W.Rpad = gs_sdf_mlp_h2_rows_padded(mode, n);
+    W.A = A_save; W.EMB = EMB_save; W.D = D_save; W.row_scale = row_scale; W.g_out = g_out; W.Rpad = gs_sdf_mlp_h2_rows_padded(mode, n);
     W.n_dev = mode == MODE_ROWS ? n_dev : nullptr;
     W.n = mode == MODE_ROWS ? n : W.Rpad;
     W.E = 3 * (2 * n_freq + 1); W.n_layers = n_hidden + 1; W.skip_layer = skip_layer; W.mode = mode;
