@@ -41,6 +41,15 @@ constexpr int D = 256;            // hidden width
 constexpr int LDH = D + 8;        // activation plane row stride (halfs): 528 B = 33 sixteen-byte slots
 constexpr int EK = 48;            // embedding width padded to a multiple of the MFMA K (39 -> 48)
 constexpr int LDEH = EK + 8;      // 112 B = 7 slots
+
+// Saved planes (layer outputs A, layer adjoints D) of the gradient passes: [layer][32-row slab][256 features][32 rows] fp32.
+// Lanes of the MFMA accumulator layout hold (row m, a few features): with the ROW index fastest a store / load of one feature is
+// 32 lanes x 4 B = one full 128-byte line (the row-major [row][256] layout made every access 16 bytes at a 1 KB stride: 0.3 of the
+// reverse chain's 0.8 ms went into its stores), and the weight-gradient kernel reads 4 consecutive rows of a feature -- exactly
+// the 8-byte piece of its transposed LDS image -- with one 16-byte load, 1 KB per wave instruction.
+__device__ __forceinline__ int64_t plane_idx(int64_t Rpad, int l, int64_t r, int f) {
+    return ((int64_t)l * Rpad + (r & ~(int64_t)31)) * 256 + (int64_t)f * 32 + (r & 31);
+}
 constexpr int MAX_LAYERS = 16;
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
 constexpr float H_MIN_NORMAL = 6.103515625e-05f;   // 2^-14
@@ -363,9 +372,10 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                if (MODE != MODE_GRID)
-                    *reinterpret_cast<float4*>(A.A + ((int64_t)l * A.Rpad + r0 + 32 * s + m_lane) * D + n_base + 8 * g) =
-                        make_float4(v[s][0].x, v[s][0].y, v[s][1].x, v[s][1].y);
+                if (MODE != MODE_GRID) {
+                    float* ap = A.A + plane_idx(A.Rpad, l, r0 + 32 * s + m_lane, n_base + 8 * g);
+                    ap[0] = v[s][0].x; ap[32] = v[s][0].y; ap[64] = v[s][1].x; ap[96] = v[s][1].y;
+                }
                 if (last) {
                     part[s] = part[s] + v[s][0] * wj[0] + v[s][1] * wj[1];
                 } else {
@@ -423,10 +433,9 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
 // denormal range of the pair split) and unscaled on the way out (exact).
 struct BwdArgs {
     const float* g_out;   // [Rpad] upstream gradient per (virtual) row; 0 on padding rows
-    const float* A;       // [n_layers][Rpad][256]
+    const float* A;       // planes [n_layers][Rpad / 32][256][32] (plane_idx)
     const float* EMB;     // [Rpad][EK]
-    float* Dsave;         // [n_layers][Rpad][256]  WRITTEN: the row-NORMALISED adjoints as fp16 pairs (hi | lo << 16), see decode_d
-    float* row_scale;     // [Rpad] WRITTEN: 1 / normalisation of the row (a power of two): d = decode_d(Dsave) * row_scale
+    float* Dsave;         // planes [n_layers][Rpad / 32][256][32]  WRITTEN
     const int32_t* rows;  // ROWS: [R]
     float* g_x;           // ROWS: [N,3] scatter target (rows are unique), or null
     int64_t R, Rpad;
@@ -473,10 +482,6 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
     const float isc[2] = {1.0f / sc[0], 1.0f / sc[1]};       // exact (powers of two)
     go[0] *= sc[0];
     go[1] *= sc[1];
-    if (wave == 0 && lane < 32) {
-        B.row_scale[r0 + lane] = isc[0];
-        B.row_scale[r0 + 32 + lane] = isc[1];
-    }
     if (need_x) {
         for (int i = tid; i < TM * LDG; i += NT) GE[i] = 0.f;
         if (wave == 0 && lane < 32) { SC[lane] = isc[0]; SC[32 + lane] = isc[1]; }
@@ -509,8 +514,10 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            an[0][g] = *reinterpret_cast<const float4*>(B.A + ((int64_t)l * B.Rpad + r0 + m_lane) * D + n_base + 8 * g);
-            an[1][g] = *reinterpret_cast<const float4*>(B.A + ((int64_t)l * B.Rpad + r0 + 32 + m_lane) * D + n_base + 8 * g);
+            const float* p0 = B.A + plane_idx(B.Rpad, l, r0 + m_lane, n_base + 8 * g);
+            const float* p1 = B.A + plane_idx(B.Rpad, l, r0 + 32 + m_lane, n_base + 8 * g);
+            an[0][g] = make_float4(p0[0], p0[32], p0[64], p0[96]);
+            an[1][g] = make_float4(p1[0], p1[32], p1[64], p1[96]);
         }
     };
     fetch_plane(B.n_layers - 1);
@@ -543,9 +550,16 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
                     }
                 }
             }
-            // D_l goes to LDS as fp16 pairs (the dgrad GEMM's operands) and from THERE to HBM, whole rows at a time: the per-lane
-            // stores of the accumulator layout (16 bytes at a 1 KB stride) cost 0.3 of this kernel's 0.8 ms (tools/chain_time.py)
-            {
+            if (!(GS_H2_ABL & 1)) {
+                float* dp0 = B.Dsave + plane_idx(B.Rpad, l, r0 + m_lane, n_base + 8 * g);
+                float* dp1 = B.Dsave + plane_idx(B.Rpad, l, r0 + 32 + m_lane, n_base + 8 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dp0[32 * j] = d0[j] * isc[0];
+                    dp1[32 * j] = d1[j] * isc[1];
+                }
+            }
+            if (l > 0 || need_x) {
                 h2 p0, q0, p1, q1;
                 split_h2_pair(f2{d0[0], d0[1]}, p0, q0);
                 split_h2_pair(f2{d0[2], d0[3]}, p1, q1);
@@ -564,18 +578,8 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
 #endif                           //    barrier; 2: before for <EIK>, after for <ROWS>.  Measured (both calls, ms): HEAD 1.78, 1 -> 1.67, 0 -> 1.47
         constexpr bool EARLY = GS_H2_BWD_PREFETCH == 1 || (GS_H2_BWD_PREFETCH == 2 && MODE == MODE_EIK);
         if (EARLY && l > 0) fetch_plane(l - 1);
-        __syncthreads();
-        if (!(GS_H2_ABL & 1)) {
-            // packed D plane: 512 threads x 16 bytes = two whole rows per pass, 32 passes
-            uint4* dst = reinterpret_cast<uint4*>(B.Dsave + ((int64_t)l * B.Rpad + r0) * D);
-            for (int q = tid; q < TM * (D / 4); q += NT) {
-                const int row = q >> 6, c4 = (q & 63) * 4;
-                const uint2 hh = *reinterpret_cast<const uint2*>(H1 + row * LDH + c4), ll = *reinterpret_cast<const uint2*>(H2 + row * LDH + c4);
-                dst[q] = make_uint4((hh.x & 0xffffu) | (ll.x << 16), (hh.x >> 16) | (ll.x & 0xffff0000u), (hh.y & 0xffffu) | (ll.y << 16),
-                                    (hh.y >> 16) | (ll.y & 0xffff0000u));
-            }
-        }
         if (l == 0 && !need_x) break;
+        __syncthreads();
         // ---- G = W_l^T D_l
         v16f hi[2], lo[2];
         if (l > 0) {
@@ -629,20 +633,10 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
 // they lie -- no transposition).  Wave w owns features [32 w, 32 w + 32) x all K: up to 10 accumulator blocks.
 // The bias gradient is the column sum of the D slab, taken from the staging registers (each thread always holds the same four
 // features); partial results of the strips are combined with float atomics into the (zeroed) torch-layout gradient tensors.
-// one element of a D plane: bits = fp16 hi | fp16 lo << 16 of the row-normalised adjoint (exactly the operands the dgrad GEMM used)
-__device__ __forceinline__ float decode_d(float packed, float row_scale) {
-    const uint32_t u = __float_as_uint(packed);
-    union { uint16_t b; _Float16 h; } hi, lo;
-    hi.b = (uint16_t)(u & 0xffffu);
-    lo.b = (uint16_t)(u >> 16);
-    return __builtin_fmaf((float)lo.h, LO_INV, (float)hi.h) * row_scale;
-}
-
 struct WgradArgs {
-    const float* A;       // [n_layers][Rpad][256]
+    const float* A;       // planes [n_layers][Rpad / 32][256][32] (plane_idx)
     const float* EMB;     // [Rpad][EK]
-    const float* D;       // [n_layers][Rpad][256]  packed fp16 pairs of the row-normalised adjoints (k_h2_bwd)
-    const float* row_scale;   // [Rpad]
+    const float* D;       // planes, same layout
     const float* g_out;   // [Rpad]
     int64_t Rpad, n;      // rows of the planes; rows in use (ROWS: the count or its capacity; EIK: all of Rpad)
     const int64_t* n_dev; // optional device-resident row count: only the tiles below it are reduced
@@ -686,10 +680,9 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs& W, int l, float* sm
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t row = rbase + (tid >> 6) + 8 * i;
-            const float4 dp = *reinterpret_cast<const float4*>(Dl + row * D + 4 * (tid & 63));
-            const float rs = W.row_scale[row];
-            dreg[i] = make_float4(decode_d(dp.x, rs), decode_d(dp.y, rs), decode_d(dp.z, rs), decode_d(dp.w, rs));
-            if (HAS_H) xreg[i] = *reinterpret_cast<const float4*>(Xh + row * D + 4 * (tid & 63));
+            const int64_t pi = plane_idx(0, 0, row, 4 * (tid & 63));        // planes are [slab][feature][32 rows]
+            dreg[i] = make_float4(Dl[pi], Dl[pi + 32], Dl[pi + 64], Dl[pi + 96]);
+            if (HAS_H) xreg[i] = make_float4(Xh[pi], Xh[pi + 32], Xh[pi + 64], Xh[pi + 96]);
         }
         if (HAS_E && tid < WS * (EK / 4)) ereg = *reinterpret_cast<const float4*>(W.EMB + (rbase + tid / (EK / 4)) * EK + 4 * (tid % (EK / 4)));
     };
@@ -804,54 +797,72 @@ __device__ __forceinline__ void wgrad16_layer(const WgradArgs& W, int l, __bf16*
     for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-    // staging: this thread owns rows 4 wave .. 4 wave + 3 of the slab and features lane + 64 c (c = 0..3) of D and of X_h,
-    // feature `lane` of the encoding (lane < EK)
-    float dreg[4][4], xreg[4][4], ereg[4];
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    auto load_slab = [&](int64_t slab) {
-        const int64_t r0 = slab * WS + 4 * wave;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                dreg[c][i] = decode_d(Dl[(r0 + i) * D + lane + 64 * c], W.row_scale[r0 + i]);
-                if (HAS_H) xreg[c][i] = Xh[(r0 + i) * D + lane + 64 * c];
-            }
-        if (HAS_E)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ereg[i] = lane < EK ? W.EMB[(r0 + i) * EK + lane] : 0.0f;
+    // staging: the planes are [slab][feature][32 rows] (plane_idx), so FOUR consecutive rows of one feature -- the 8-byte piece of the
+    // transposed image -- are one 16-byte load: this thread owns rows 4 (lane & 7) .. + 3 of features 32 wave + 8 c + (lane >> 3),
+    // c = 0..3 (a wave instruction reads 8 features x 32 rows = 1 KB contiguous; the row-major planes needed 16 dword loads per
+    // plane and thread: 0.64 of this kernel's 1.65 ms were those loads).  Encoding: rows 4 wave .. + 3 of feature `lane` (< EK).
+    struct Staged {
+        float d[4][4], x[4][4], e[4];
     };
-    auto store_slab = [&](int64_t slab) {
-        const int roff = 4 * wave;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const int frow = 4 * (lane & 7), fsub = 32 * wave + (lane >> 3);
+    auto load_slab = [&](Staged& R, int64_t slab) {
+        const float* ds = Dl + slab * (int64_t)(WS * D) + frow;
+        const float* xs = HAS_H ? Xh + slab * (int64_t)(WS * D) + frow : nullptr;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            bf4 h, lw;
-            split_bf16_4(dreg[c], h, lw);
-            *reinterpret_cast<bf4*>(hi_img + (lane + 64 * c) * WB_RS + roff) = h;
-            *reinterpret_cast<bf4*>(lo_img + (lane + 64 * c) * WB_RS + roff) = lw;
+            const float4 dv = *reinterpret_cast<const float4*>(ds + (fsub + 8 * c) * WS);
+            R.d[c][0] = dv.x; R.d[c][1] = dv.y; R.d[c][2] = dv.z; R.d[c][3] = dv.w;
             if (HAS_H) {
-                split_bf16_4(xreg[c], h, lw);
-                *reinterpret_cast<bf4*>(hi_img + (D + lane + 64 * c) * WB_RS + roff) = h;
-                *reinterpret_cast<bf4*>(lo_img + (D + lane + 64 * c) * WB_RS + roff) = lw;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool value_row = W.mode != MODE_EIK || (((slab * WS + roff + i) & 63) < 16);
-                if (value_row) bsum[c] += dreg[c][i];
+                const float4 xv = *reinterpret_cast<const float4*>(xs + (fsub + 8 * c) * WS);
+                R.x[c][0] = xv.x; R.x[c][1] = xv.y; R.x[c][2] = xv.z; R.x[c][3] = xv.w;
             }
         }
         if (HAS_E) {
+            const int64_t r0 = slab * WS + 4 * wave;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) R.e[i] = lane < EK ? W.EMB[(r0 + i) * EK + lane] : 0.0f;
+        }
+    };
+    auto store_slab = [&](Staged& R, int64_t slab) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int f = fsub + 8 * c;
             bf4 h, lw;
-            split_bf16_4(ereg, h, lw);
+            split_bf16_4(R.d[c], h, lw);
+            *reinterpret_cast<bf4*>(hi_img + f * WB_RS + frow) = h;
+            *reinterpret_cast<bf4*>(lo_img + f * WB_RS + frow) = lw;
+            if (HAS_H) {
+                split_bf16_4(R.x[c], h, lw);
+                *reinterpret_cast<bf4*>(hi_img + (D + f) * WB_RS + frow) = h;
+                *reinterpret_cast<bf4*>(lo_img + (D + f) * WB_RS + frow) = lw;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool value_row = W.mode != MODE_EIK || (((slab * WS + frow + i) & 63) < 16);
+                if (value_row) bsum[c] += R.d[c][i];
+            }
+        }
+        if (HAS_E) {
+            const int roff = 4 * wave;
+            bf4 h, lw;
+            split_bf16_4(R.e, h, lw);
             *reinterpret_cast<bf4*>(hi_img + (2 * D + lane) * WB_RS + roff) = h;
             *reinterpret_cast<bf4*>(lo_img + (2 * D + lane) * WB_RS + roff) = lw;
         }
     };
-    load_slab(slab0);
-    for (int64_t s = 0; s < nslab; ++s) {
-        store_slab(slab0 + s * stride);
+#ifndef GS_WG_ABL
+#define GS_WG_ABL 0      // experiments: 1 = no MFMAs, 2 = LDS image written once, 4 = slab loaded once
+#endif
+#ifndef GS_WG_DEPTH
+#define GS_WG_DEPTH 1    // slabs in flight ahead of the one being reduced (two register sets; one workgroup per CU: 92 KB image)
+#endif
+    // one slab: registers -> transposed bf16-pair image, then the next-but-one slab's loads go out and fly during TWO slabs of MFMAs
+    // (a load issued one slab ahead arrived after the 0.7 us of MFMAs: the loop ran at the HBM latency, 6.4 us per slab)
+    auto reduce_slab = [&](Staged& R, int64_t s) {
+        if (!(GS_WG_ABL & 2) || s == 0) store_slab(R, slab0 + s * stride);
         __syncthreads();
-        if (s + 1 < nslab) load_slab(slab0 + (s + 1) * stride);        // in flight during the MFMAs below
+        if (s + GS_WG_DEPTH < nslab && !(GS_WG_ABL & 4)) load_slab(R, slab0 + (s + GS_WG_DEPTH) * stride);
         const int roff = 8 * (lane >> 5);
         const __bf16* ah = hi_img + (wave * 32 + (lane & 31)) * WB_RS + roff;
         const __bf16* al = lo_img + (wave * 32 + (lane & 31)) * WB_RS + roff;
@@ -863,12 +874,24 @@ __device__ __forceinline__ void wgrad16_layer(const WgradArgs& W, int l, __bf16*
                 const int feat = (HAS_H ? (b < 8 ? D + 32 * b : 2 * D + 32 * (b - 8)) : 2 * D + 32 * b) + (lane & 31);
                 const bf8 xh = *reinterpret_cast<const bf8*>(hi_img + feat * WB_RS + roff + 16 * ks);
                 const bf8 xl = *reinterpret_cast<const bf8*>(lo_img + feat * WB_RS + roff + 16 * ks);
+                if (GS_WG_ABL & 1) continue;
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, xh, acc[b], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, xl, acc[b], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl, xh, acc[b], 0, 0, 0);
             }
         }
         __syncthreads();
+    };
+    Staged R0, R1;
+    load_slab(R0, slab0);
+    if (GS_WG_DEPTH == 2 && nslab > 1) load_slab(R1, slab0 + stride);
+    if (GS_WG_DEPTH == 2) {
+        for (int64_t s = 0; s < nslab; s += 2) {
+            reduce_slab(R0, s);
+            if (s + 1 < nslab) reduce_slab(R1, s + 1);
+        }
+    } else {
+        for (int64_t s = 0; s < nslab; ++s) reduce_slab(R0, s);
     }
     const int Kreal = (HAS_H ? D : 0) + (HAS_E ? W.E : 0);
 #pragma unroll
@@ -887,16 +910,18 @@ __device__ __forceinline__ void wgrad16_layer(const WgradArgs& W, int l, __bf16*
                 atomicAdd(W.dW[l] + (int64_t)n * Kreal + k, acc[b][r]);
             }
     }
-    // bias gradient: thread (wave, lane) holds the partial column sums of features lane + 64 c over its rows
-    float* red = reinterpret_cast<float*>(img);       // [8 waves][256]
+    // bias gradient: the 8 lanes that share lane >> 3 hold the partial column sums of feature 32 wave + 8 c + (lane >> 3)
+    float* red = reinterpret_cast<float*>(img);       // [256]
 #pragma unroll
-    for (int c = 0; c < 4; ++c) red[wave * D + lane + 64 * c] = bsum[c];
-    __syncthreads();
-    if (tid < D) {
-        float t = 0.f;
-        for (int w = 0; w < 8; ++w) t += red[w * D + tid];
-        atomicAdd(W.db[l] + tid, t);
+    for (int c = 0; c < 4; ++c) {
+        float v = bsum[c];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        if ((lane & 7) == 0) red[fsub + 8 * c] = v;
     }
+    __syncthreads();
+    if (tid < D) atomicAdd(W.db[l] + tid, red[tid]);
 }
 
 __global__ void __launch_bounds__(NT, 2) k_h2_wgrad16(WgradArgs W) {
@@ -914,26 +939,20 @@ __global__ void __launch_bounds__(NT, 2) k_h2_wgrad(WgradArgs W) {
         // output layer: dw_out[n] = sum_rows g_out[row] a_{L-1}[row][n]  (tangent rows included: their g_out is dL/d(df/dx_d))
         const int64_t nslabs_total = wgrad_rows(W) / WS;
         const float* X = W.A + (int64_t)(W.n_layers - 1) * W.Rpad * D;
-        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t s = blockIdx.x; s < nslabs_total; s += gridDim.x)
+        // planes are [slab][feature][32 rows]: thread = (feature tid >> 1, rows 16 (tid & 1) .. + 15 of the slab), four 16-byte loads
+        const int f = tid >> 1, rb = 16 * (tid & 1);
+        float acc = 0.f;
+        for (int64_t s = blockIdx.x; s < nslabs_total; s += gridDim.x) {
+            const float* xp = X + s * (int64_t)(WS * D) + f * WS + rb;
+            const float* gp = W.g_out + s * WS + rb;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int64_t row = s * WS + (tid >> 6) + 8 * i;
-                const float g = W.g_out[row];
-                const float4 x = *reinterpret_cast<const float4*>(X + row * D + 4 * (tid & 63));
-                s4.x += g * x.x; s4.y += g * x.y; s4.z += g * x.z; s4.w += g * x.w;
+                const float4 x = *reinterpret_cast<const float4*>(xp + 4 * i), g = *reinterpret_cast<const float4*>(gp + 4 * i);
+                acc += g.x * x.x + g.y * x.y + g.z * x.z + g.w * x.w;
             }
-        float4* red = reinterpret_cast<float4*>(smem_f);
-        red[tid] = s4;
-        __syncthreads();
-        if (tid < 64) {
-            float4 t = red[tid];
-            for (int w = 1; w < 8; ++w) { const float4 o = red[w * 64 + tid]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
-            atomicAdd(W.dW[l] + 4 * tid, t.x);
-            atomicAdd(W.dW[l] + 4 * tid + 1, t.y);
-            atomicAdd(W.dW[l] + 4 * tid + 2, t.z);
-            atomicAdd(W.dW[l] + 4 * tid + 3, t.w);
         }
+        acc += __shfl_xor(acc, 1, 64);
+        if ((tid & 1) == 0 && acc != 0.f) atomicAdd(W.dW[l] + f, acc);
         return;
     }
     if (l == 0) wgrad_layer<2, false, true>(W, l, smem_f, tid);
@@ -1236,15 +1255,15 @@ extern "C" int gs_sdf_mlp_h2_save_fwd(int mode, const float* x, const int32_t* r
 // row); mode 1 with g_x != NULL: g_x[rows[r]] (of [N,3]) WRITTEN for r < n (dL/dx through the encoding).  g_out [Rpad]:
 // upstream gradient per virtual row, 0 on padding rows.
 extern "C" int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* rows, int64_t n, const int64_t* n_dev, const void* packed, int n_freq,
-                                 int n_hidden, int skip_layer, const float* A_save, const float* EMB_save, float* D_save, float* row_scale,
-                                 float* g_x, gs_stream_t stream) {
+                                 int n_hidden, int skip_layer, const float* A_save, const float* EMB_save, float* D_save, float* g_x,
+                                 gs_stream_t stream) {
     if (n == 0) return 0;
     GS_REQUIRE(mode == MODE_ROWS || mode == MODE_EIK, "gs_sdf_mlp_h2_bwd: mode must be 1 (rows) or 2 (eikonal)");
-    GS_REQUIRE(g_out && packed && A_save && EMB_save && D_save && row_scale && (mode == MODE_EIK || rows != nullptr), "gs_sdf_mlp_h2_bwd: null pointer");
+    GS_REQUIRE(g_out && packed && A_save && EMB_save && D_save && (mode == MODE_EIK || rows != nullptr), "gs_sdf_mlp_h2_bwd: null pointer");
     if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
     PackLayout L = make_layout(n_freq, n_hidden, skip_layer);
     BwdArgs B{};
-    B.g_out = g_out; B.A = A_save; B.EMB = EMB_save; B.Dsave = D_save; B.row_scale = row_scale; B.rows = rows; B.g_x = mode == MODE_ROWS ? g_x : nullptr;
+    B.g_out = g_out; B.A = A_save; B.EMB = EMB_save; B.Dsave = D_save; B.rows = rows; B.g_x = mode == MODE_ROWS ? g_x : nullptr;
     B.R = n; B.n_dev = mode == MODE_ROWS ? n_dev : nullptr; B.Rpad = gs_sdf_mlp_h2_rows_padded(mode, n); B.E = L.E; B.n_layers = L.n_layers; B.skip_layer = L.skip_layer;
     for (int l = 0; l < L.n_layers; ++l) {
         B.wfragT[l] = (const h8*)packed + L.fragT_off[l];
@@ -1267,14 +1286,14 @@ extern "C" int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* ro
 // dW, db = HOST arrays of n_hidden + 2 DEVICE pointers (Linear.weight.grad [out,in], Linear.bias.grad), output layer last;
 // db[n_hidden + 1] (the output bias, = sum of g_out over the value rows) is not touched.
 extern "C" int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, const int64_t* n_dev, int n_freq, int n_hidden, int skip_layer,
-                                   const float* A_save, const float* EMB_save, const float* D_save, const float* row_scale, float* const* dW,
-                                   float* const* db, int exact_fp32, gs_stream_t stream) {
+                                   const float* A_save, const float* EMB_save, const float* D_save, float* const* dW, float* const* db,
+                                   int exact_fp32, gs_stream_t stream) {
     if (n == 0) return 0;
     GS_REQUIRE(mode == MODE_ROWS || mode == MODE_EIK, "gs_sdf_mlp_h2_wgrad: mode must be 1 (rows) or 2 (eikonal)");
-    GS_REQUIRE(g_out && A_save && EMB_save && D_save && row_scale && dW && db, "gs_sdf_mlp_h2_wgrad: null pointer");
+    GS_REQUIRE(g_out && A_save && EMB_save && D_save && dW && db, "gs_sdf_mlp_h2_wgrad: null pointer");
     if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
     WgradArgs W{};
-    W.A = A_save; W.EMB = EMB_save; W.D = D_save; W.row_scale = row_scale; W.g_out = g_out; W.Rpad = gs_sdf_mlp_h2_rows_padded(mode, n);
+    W.A = A_save; W.EMB = EMB_save; W.D = D_save; W.g_out = g_out; W.Rpad = gs_sdf_mlp_h2_rows_padded(mode, n);
     W.n_dev = mode == MODE_ROWS ? n_dev : nullptr;
     W.n = mode == MODE_ROWS ? n : W.Rpad;
     W.E = 3 * (2 * n_freq + 1); W.n_layers = n_hidden + 1; W.skip_layer = skip_layer; W.mode = mode;

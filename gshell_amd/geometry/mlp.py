@@ -379,8 +379,7 @@ class _SavedChain:
         filled in place (mode 1)."""
         L = _lib.lib()
         dev = g_out.device
-        D = torch.empty_like(self.A)                # row-normalised adjoints as fp16 pairs + the rows' scales (see gshell_hip.h)
-        row_scale = torch.empty((self.Rpad,), dtype=torch.float32, device=dev)
+        D = torch.empty_like(self.A)
         params = list(self.net.parameters())
         # one zero-filled buffer, one view per parameter (16 fills -> 1)
         flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
@@ -393,12 +392,11 @@ class _SavedChain:
         with torch.cuda.device(dev):
             check(L.gs_sdf_mlp_h2_bwd(c_int(self.mode), ptr(g_out, torch.float32, "g_out"), ptr(self.rows, torch.int32, "rows"), c_int64(self.n), ptr(self.n_dev),
                                       ptr(self.packed),
-                                      c_int(self.nf), c_int(self.n_hidden), c_int(self.skip), ptr(self.A), ptr(self.EMB), ptr(D), ptr(row_scale), ptr(g_x),
-                                      stream()),
+                                      c_int(self.nf), c_int(self.n_hidden), c_int(self.skip), ptr(self.A), ptr(self.EMB), ptr(D), ptr(g_x), stream()),
                   "gs_sdf_mlp_h2_bwd")
             check(L.gs_sdf_mlp_h2_wgrad(c_int(self.mode), ptr(g_out), c_int64(self.n), ptr(self.n_dev), c_int(self.nf), c_int(self.n_hidden), c_int(self.skip),
                                         ptr(self.A),
-                                        ptr(self.EMB), ptr(D), ptr(row_scale), _ptr_array(dW), _ptr_array(db), c_int(1 if SDF_MLP_WGRAD_FP32 else 0), stream()),
+                                        ptr(self.EMB), ptr(D), _ptr_array(dW), _ptr_array(db), c_int(1 if SDF_MLP_WGRAD_FP32 else 0), stream()),
                   "gs_sdf_mlp_h2_wgrad")
         if self.mode == 1:      # output bias: sum of the upstream gradient over the (value) rows
             db[-1].copy_(g_out.sum().reshape(db[-1].shape))

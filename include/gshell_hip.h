@@ -575,14 +575,13 @@ int gs_compact_rows(const float* g, int64_t N, int64_t cap, void* scratch, int32
 int gs_sdf_mlp_h2_save_fwd(int mode, const float* x, const int32_t* rows, int64_t n, const int64_t* n_dev,
                            const void* packed, int n_freq, int n_hidden, int skip_layer, float* A_save,
                            float* EMB_save, float* out, gs_stream_t stream);
-/* D_save [layers, Rpad, 256] holds the row-NORMALISED layer adjoints as fp16 pairs (hi | lo << 16: the operands of the
- * dgrad GEMM, written from LDS in whole rows), row_scale [Rpad] the power of two that undoes the normalisation; both are
- * written by _bwd and read by _wgrad. */
+/* A_save / D_save are opaque scratch planes of layers * Rpad * 256 floats each, laid out [layer][32-row slab][256][32 rows]
+ * (row index fastest: every access of the three kernels is a whole line); written by _save_fwd / _bwd, read by _bwd / _wgrad. */
 int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* rows, int64_t n, const int64_t* n_dev,
                       const void* packed, int n_freq, int n_hidden, int skip_layer, const float* A_save,
-                      const float* EMB_save, float* D_save, float* row_scale, float* g_x, gs_stream_t stream);
+                      const float* EMB_save, float* D_save, float* g_x, gs_stream_t stream);
 int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, const int64_t* n_dev, int n_freq, int n_hidden, int skip_layer,
-                        const float* A_save, const float* EMB_save, const float* D_save, const float* row_scale,
+                        const float* A_save, const float* EMB_save, const float* D_save,
                         float* const* dW, float* const* db,
                         int exact_fp32 /* 0: bf16-pair operands on the bf16 matrix path (default); 1: fp32 MFMA */,
                         gs_stream_t stream);
