@@ -217,11 +217,28 @@ __global__ void __launch_bounds__(256) k_encode_fwd(GridMeta M, EncArgs A) {
 #define GS_HG_ALTERNATE 1       // odd workgroups walk the levels fine -> coarse
 #endif
 __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, EncArgs A, int tiled) {
-    __shared__ uint32_t s_key[CMB_SLOTS];
-    __shared__ float2 s_val[CMB_SLOTS];
-    __shared__ uint16_t s_list[CMB_SLOTS];   // the slots claimed at the current level (flush + clear walk this list, not the table)
-    __shared__ int s_claimed[2];             // bank = level step & 1
+#ifndef GS_HG_WAVETAB
+#define GS_HG_WAVETAB 0      // 1: every wave (4 rows x 16 pixels) combines in its OWN quarter of the table: no workgroup barriers
+#endif
+    __shared__ uint32_t s_key_all[CMB_SLOTS];
+    __shared__ float2 s_val_all[CMB_SLOTS];
+    __shared__ uint16_t s_list_all[CMB_SLOTS];   // the slots claimed at the current level (flush + clear walk this list, not the table)
+    __shared__ int s_claimed_all[4][2];          // bank = level step & 1
     const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int TSLOTS = GS_HG_WAVETAB ? CMB_SLOTS / 4 : CMB_SLOTS, TLOG = GS_HG_WAVETAB ? CMB_LOG_SLOTS - 2 : CMB_LOG_SLOTS;
+    const int tw = GS_HG_WAVETAB ? (tid >> 6) : 0, tn = GS_HG_WAVETAB ? 64 : 256, tl = GS_HG_WAVETAB ? lane : tid;   // table owner, its threads
+    uint32_t* const s_key = s_key_all + tw * TSLOTS;
+    float2* const s_val = s_val_all + tw * TSLOTS;
+    uint16_t* const s_list = s_list_all + tw * TSLOTS;
+    int* const s_claimed = s_claimed_all[tw];
+    auto table_sync = [&]() {
+        if (GS_HG_WAVETAB) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();
+        }
+    };
     int64_t i;
     int wg_linear;
     if (tiled) {                         // 16 x 16 pixel tile of image blockIdx.z
@@ -242,12 +259,12 @@ __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, Enc
     float t[3] = {0.f, 0.f, 0.f};
     bool inside[3] = {false, false, false};
     if (active) enc_coord(A, i, t, inside);
-    for (int s = tid; s < CMB_SLOTS; s += 256) {
+    for (int s = tl; s < TSLOTS; s += tn) {
         s_key[s] = CMB_EMPTY;
         s_val[s] = make_float2(0.f, 0.f);
     }
-    if (tid < 2) s_claimed[tid] = 0;
-    __syncthreads();
+    if (tl < 2) s_claimed[tl] = 0;
+    table_sync();
     float gx[3] = {0.f, 0.f, 0.f};
     const float2* gf = reinterpret_cast<const float2*>(A.g_feat);
     const int n_active8 = 8 * __popcll(__ballot(active));
@@ -331,7 +348,7 @@ __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, Enc
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 if (!((todo >> c) & 1u)) continue;
-                uint32_t slot = (idx[c] * 2654435761u) >> (32 - CMB_LOG_SLOTS);
+                uint32_t slot = (idx[c] * 2654435761u) >> (32 - TLOG);
                 bool done = false;
                 for (int pr = 0; pr < 8 && !done; ++pr) {
                     const uint32_t old = atomicCAS(&s_key[slot], CMB_EMPTY, idx[c]);
@@ -341,7 +358,7 @@ __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, Enc
                         atomicAdd(&s_val[slot].y, v1[c]);
                         done = true;
                     } else {
-                        slot = (slot + 1) & (CMB_SLOTS - 1);
+                        slot = (slot + 1) & (TSLOTS - 1);
                     }
                 }
                 if (done) todo &= ~(1u << c);
@@ -389,9 +406,9 @@ __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, Enc
                     }
                 }
         }
-        if (__syncthreads_or(combine)) {           // workgroup-uniform; the barrier also orders the inserts before the flush
+        if (GS_HG_WAVETAB ? (table_sync(), combine) : (bool)__syncthreads_or(combine)) {   // uniform over the table's owner; orders inserts before the flush
             const int n = *claimed;
-            for (int j = tid; j < n; j += 256) {
+            for (int j = tl; j < n; j += tn) {
                 const int s = s_list[j];
                 const uint32_t k = s_key[s];
                 const float2 v = s_val[s];
@@ -401,8 +418,8 @@ __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, Enc
                 s_key[s] = CMB_EMPTY;
                 s_val[s] = make_float2(0.f, 0.f);
             }
-            __syncthreads();
-            if (tid == 0) *claimed = 0;      // this bank is next used two steps on, behind the next step's barrier
+            table_sync();
+            if (tl == 0) *claimed = 0;      // this bank is next used two steps on, behind the next step's barrier
         }
     }
     if (active && A.g_pos) {
