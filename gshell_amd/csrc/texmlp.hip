@@ -31,6 +31,12 @@ constexpr int TP = D + 1;     // padded row stride of the LDS tiles
 constexpr int TILE = 64 * TP;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef GS_TEX_ABL
+#define GS_TEX_ABL 0      // experiments: 1 = no weight-gradient MFMAs, 2 = no matrix-vector products, 4 = no final atomics
+#endif
+#ifndef GS_TEX_MFMA
+#define GS_TEX_MFMA 1     // layer products of a 64-row tile on v_mfma_f32_32x32x2_f32 (0: one lane per row, 1024 FMAs per layer and lane)
+#endif
 
 struct TexArgs {
     const float* x; const float* mask; int64_t N;
@@ -62,6 +68,10 @@ __device__ __forceinline__ void load_weights(const TexArgs& A, float* s_w1, floa
 __device__ __forceinline__ void matvec(const float* __restrict__ rows, const float* __restrict__ vec, int n, float (&y)[D]) {
 #pragma unroll
     for (int j = 0; j < D; ++j) y[j] = 0.0f;
+    if (GS_TEX_ABL & 2) {
+        for (int j = 0; j < D; ++j) y[j] = vec[j & 7] * rows[j];
+        return;
+    }
 #pragma unroll 2
     for (int k = 0; k < n; ++k) {
         const float vk = vec[k];
@@ -115,6 +125,39 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Y[64][32] = X[64][0..K) . B[K][32] on the matrix core, tiles [64][TP] in LDS, B row-major [k][32] in LDS:
+// v_mfma_f32_32x32x2_f32 with the tile rows as M (two 32-row halves), operands read straight from LDS
+// (A: lane = row, k = 2 s + (lane >> 5); B: lane = column).  Both halves are accumulated before anything is written, so `out` may
+// alias `in`.  MODE 0: plain, 1: ReLU, 2: masked by gate > 0 (the ReLU derivative of the layer whose output tile is `gate`).
+// The one-lane-per-row product it replaces cost 0.27 of the backward kernel's 0.54 ms (tools/build_variant.sh -DGS_TEX_ABL=2).
+template <int MODE>
+__device__ __forceinline__ void mfma_layer(const float* __restrict__ in, const float* __restrict__ B, int K, float* __restrict__ out,
+                                           const float* __restrict__ gate, int lane) {
+    const int m = lane & 31, kh = lane >> 5;
+    f32x16 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][r] = 0.0f;
+        const float* ap = in + (32 * h + m) * TP + kh;
+        const float* bp = B + kh * D + m;
+#pragma unroll 4
+        for (int s = 0; s < K / 2; ++s) acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s * D], acc[h], 0, 0, 0);
+    }
+    wave_sync();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pos = (32 * h + (r & 3) + 8 * (r >> 2) + 4 * kh) * TP + m;
+            float v = acc[h][r];
+            if (MODE == 1) v = fmaxf(v, 0.0f);
+            if (MODE == 2) v = gate[pos] > 0.0f ? v : 0.0f;
+            out[pos] = v;
+        }
+    wave_sync();
+}
+
 __global__ void __launch_bounds__(256) k_texmlp_fwd(TexArgs A) {
     __shared__ __attribute__((aligned(16))) float s_w1t[D * D], s_w2t[D * D], s_w3[CMAX * D];
     __shared__ float s_lo[CMAX], s_hi[CMAX];
@@ -132,11 +175,19 @@ __global__ void __launch_bounds__(256) k_texmlp_fwd(TexArgs A) {
     float y[D];
     if (A.level_major) load_row_lm(A.x, A.N, r, on, vec);
     else load_row(A.x, r, on, vec);
-    matvec(s_w1t, vec, D, y);
-    relu_inplace(y);
-    put_row(vec, y);
-    matvec(s_w2t, vec, D, y);
-    relu_inplace(y);
+    if (GS_TEX_MFMA) {
+        wave_sync();
+        mfma_layer<1>(s_tile[wave], s_w1t, D, s_tile[wave], nullptr, lane);
+        mfma_layer<1>(s_tile[wave], s_w2t, D, s_tile[wave], nullptr, lane);
+#pragma unroll
+        for (int j = 0; j < D; ++j) y[j] = vec[j];
+    } else {
+        matvec(s_w1t, vec, D, y);
+        relu_inplace(y);
+        put_row(vec, y);
+        matvec(s_w2t, vec, D, y);
+        relu_inplace(y);
+    }
     if (r >= A.N) return;
     for (int c = 0; c < A.C; ++c) {
         float acc = 0.0f;
@@ -149,6 +200,7 @@ __global__ void __launch_bounds__(256) k_texmlp_fwd(TexArgs A) {
 
 // acc[32x32] += sum over the wave's 64 rows of G[row][i] * H[row][j]; tiles are [64][TP] in LDS
 __device__ __forceinline__ void outer_accumulate(const float* __restrict__ tg, const float* __restrict__ th, int lane, f32x16& acc) {
+    if (GS_TEX_ABL & 1) return;
     const int k = lane >> 5, c = lane & 31;
 #pragma unroll 8
     for (int s = 0; s < 32; ++s) {
@@ -184,12 +236,21 @@ __global__ void __launch_bounds__(64) k_texmlp_bwd(TexArgs A, int64_t n_chunks) 
         // forward, keeping x, h1, h2 in the tiles
         if (A.level_major) load_row_lm(A.x, A.N, r, on, tx + lane * TP);
         else load_row(A.x, r, on, tx + lane * TP);
-        matvec(s_w1t, tx + lane * TP, D, y);
-        const uint32_t m1 = relu_inplace(y);
-        put_row(t1 + lane * TP, y);
-        matvec(s_w2t, t1 + lane * TP, D, y);
-        const uint32_t m2 = relu_inplace(y);
-        put_row(t2 + lane * TP, y);
+        uint32_t m1 = 0u, m2 = 0u;
+        if (GS_TEX_MFMA) {
+            wave_sync();
+            mfma_layer<1>(tx, s_w1t, D, t1, nullptr, lane);
+            mfma_layer<1>(t1, s_w2t, D, t2, nullptr, lane);
+#pragma unroll
+            for (int j = 0; j < D; ++j) y[j] = t2[lane * TP + j];
+        } else {
+            matvec(s_w1t, tx + lane * TP, D, y);
+            m1 = relu_inplace(y);
+            put_row(t1 + lane * TP, y);
+            matvec(s_w2t, t1 + lane * TP, D, y);
+            m2 = relu_inplace(y);
+            put_row(t2 + lane * TP, y);
+        }
         // d loss / d logits
         for (int c = 0; c < CMAX; ++c) {
             float a = 0.0f;
@@ -203,24 +264,38 @@ __global__ void __launch_bounds__(64) k_texmlp_bwd(TexArgs A, int64_t n_chunks) 
         wave_sync();
         // layer 3:  dW3 += go (x) h2 ;  g2 = relu'(h2) * W3^T go
         outer_accumulate(tg, t2, lane, acc3);
-        matvec(s_w3, tg + lane * TP, CMAX, y);
+        if (GS_TEX_MFMA) {
+            mfma_layer<2>(tg, s_w3, CMAX, tg, t2, lane);           // in place: both halves are accumulated before the tile is rewritten
+        } else {
+            matvec(s_w3, tg + lane * TP, CMAX, y);
 #pragma unroll
-        for (int j = 0; j < D; ++j) y[j] = (m2 >> j) & 1u ? y[j] : 0.0f;
-        wave_sync();
-        put_row(tg + lane * TP, y);
-        wave_sync();
+            for (int j = 0; j < D; ++j) y[j] = (m2 >> j) & 1u ? y[j] : 0.0f;
+            wave_sync();
+            put_row(tg + lane * TP, y);
+            wave_sync();
+        }
         // layer 2:  dW2 += g2 (x) h1 ;  g1 = relu'(h1) * W2^T g2
         outer_accumulate(tg, t1, lane, acc2);
-        matvec(s_w2, tg + lane * TP, D, y);
+        if (GS_TEX_MFMA) {
+            mfma_layer<2>(tg, s_w2, D, tg, t1, lane);
+        } else {
+            matvec(s_w2, tg + lane * TP, D, y);
 #pragma unroll
-        for (int j = 0; j < D; ++j) y[j] = (m1 >> j) & 1u ? y[j] : 0.0f;
-        wave_sync();
-        put_row(tg + lane * TP, y);
-        wave_sync();
+            for (int j = 0; j < D; ++j) y[j] = (m1 >> j) & 1u ? y[j] : 0.0f;
+            wave_sync();
+            put_row(tg + lane * TP, y);
+            wave_sync();
+        }
         // layer 1:  dW1 += g1 (x) x ;  g_x = W1^T g1
         outer_accumulate(tg, tx, lane, acc1);
         if (A.g_x) {
-            matvec(s_w1, tg + lane * TP, D, y);
+            if (GS_TEX_MFMA) {
+                mfma_layer<0>(tg, s_w1, D, tx, nullptr, lane);     // x is dead after dW1: its tile takes g_x
+#pragma unroll
+                for (int j = 0; j < D; ++j) y[j] = tx[lane * TP + j];
+            } else {
+                matvec(s_w1, tg + lane * TP, D, y);
+            }
             if (r < A.N && A.level_major) {
                 if (on) {
                     float2* gx = reinterpret_cast<float2*>(A.g_x) + r;
@@ -236,6 +311,7 @@ __global__ void __launch_bounds__(64) k_texmlp_bwd(TexArgs A, int64_t n_chunks) 
         wave_sync();
     }
     // flush: D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31]
+    if (GS_TEX_ABL & 4) return;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31;
