@@ -45,6 +45,10 @@ struct TexArgs {
     float* out;
     const float* g_out; float* g_x; float* g_w1; float* g_w2; float* g_w3;
     int level_major;   // x / g_x are [16][N][2] (the hash-grid encoding's level-major feature tensor, hashgrid.hip) instead of [N][32]
+    // optional compact list of the rows to evaluate (ascending, count on the device): lane i takes row rows[i].  Image rows in scan
+    // order put a 64-row chunk on every crossing of the silhouette: a third of the lanes of the "active" chunks did work.
+    const int32_t* rows;
+    const int64_t* count_dev;
 };
 
 // weights into LDS: w1t / w2t are the transposes (forward products walk rows of W^T, backward products rows of W)
@@ -164,10 +168,18 @@ __global__ void __launch_bounds__(256) k_texmlp_fwd(TexArgs A) {
     __shared__ float s_tile[4][TILE];
     load_weights(A, nullptr, nullptr, s_w1t, s_w2t, s_w3, s_lo, s_hi);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool on = r < A.N && (!A.mask || A.mask[r] > 0.0f);
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t r = gi;
+    bool on, valid;
+    if (A.rows) {                 // compact rows: rows outside the list are the caller's (pre-filled with the zero-feature value)
+        on = valid = gi < A.count_dev[0];
+        r = on ? A.rows[gi] : 0;
+    } else {
+        valid = r < A.N;
+        on = valid && (!A.mask || A.mask[r] > 0.0f);
+    }
     if (__ballot(on) == 0ull) {   // zero features -> zero logits -> sigmoid = 1/2
-        if (r < A.N)
+        if (valid)
             for (int c = 0; c < A.C; ++c) A.out[r * A.C + c] = 0.5f * (s_hi[c] - s_lo[c]) + s_lo[c];
         return;
     }
@@ -188,7 +200,7 @@ __global__ void __launch_bounds__(256) k_texmlp_fwd(TexArgs A) {
         matvec(s_w2t, vec, D, y);
         relu_inplace(y);
     }
-    if (r >= A.N) return;
+    if (!valid) return;
     for (int c = 0; c < A.C; ++c) {
         float acc = 0.0f;
 #pragma unroll
@@ -211,7 +223,8 @@ __device__ __forceinline__ void outer_accumulate(const float* __restrict__ tg, c
 }
 
 // one wave per block: 4 tiles (x, h1, h2, gradient) = 33.8 KB + 17 KB of weights -> 3 blocks per CU
-__global__ void __launch_bounds__(64) k_texmlp_bwd(TexArgs A, int64_t n_chunks) {
+__global__ void __launch_bounds__(64) k_texmlp_bwd(TexArgs A, int64_t n_chunks_in) {
+    int64_t n_chunks = n_chunks_in;
     __shared__ __attribute__((aligned(16))) float s_w1[D * D], s_w2[D * D], s_w1t[D * D], s_w2t[D * D], s_w3[CMAX * D];
     __shared__ float s_lo[CMAX], s_hi[CMAX];
     __shared__ float s_tile[4][TILE];
@@ -222,9 +235,16 @@ __global__ void __launch_bounds__(64) k_texmlp_bwd(TexArgs A, int64_t n_chunks) 
     float* t2 = s_tile[2];
     float* tg = s_tile[3];
     f32x16 acc1 = {0}, acc2 = {0}, acc3 = {0};
+    if (A.rows) n_chunks = (A.count_dev[0] + 63) / 64;
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        const int64_t r = chunk * 64 + lane;
-        const bool on = r < A.N && (!A.mask || A.mask[r] > 0.0f);
+        int64_t r = chunk * 64 + lane;
+        bool on;
+        if (A.rows) {
+            on = r < A.count_dev[0];
+            r = on ? A.rows[r] : A.N;            // A.N = "no row": nothing below stores for it
+        } else {
+            on = r < A.N && (!A.mask || A.mask[r] > 0.0f);
+        }
         if (__ballot(on) == 0ull) {
             if (r < A.N && A.g_x && !A.level_major) {   // level major: rows with mask <= 0 are never read by the encoding's backward
                 float4* gx = reinterpret_cast<float4*>(A.g_x + r * D);
@@ -323,30 +343,37 @@ __global__ void __launch_bounds__(64) k_texmlp_bwd(TexArgs A, int64_t n_chunks) 
 
 }  // namespace
 
-static int texmlp_fwd(const float* x, int level_major, const float* mask, int64_t N, const float* w1, const float* w2, const float* w3, int C,
+static int texmlp_fwd(const float* x, int level_major, const int32_t* rows, const int64_t* count_dev, int64_t cap, const float* mask, int64_t N, const float* w1, const float* w2, const float* w3, int C,
                       const float* lo, const float* hi, float* out, gs_stream_t stream) {
     if (N == 0) return 0;
     GS_REQUIRE(x && w1 && w2 && w3 && lo && hi && out, "gs_texmlp_fwd: null pointer");
     GS_REQUIRE(C >= 1 && C <= CMAX, "gs_texmlp_fwd: 1..8 output channels");
     TexArgs A{};
     A.x = x; A.mask = mask; A.N = N; A.w1 = w1; A.w2 = w2; A.w3 = w3; A.C = C; A.lo = lo; A.hi = hi; A.out = out;
-    A.level_major = level_major;
-    hipLaunchKernelGGL(k_texmlp_fwd, dim3((unsigned)gs::cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    A.level_major = level_major; A.rows = rows; A.count_dev = count_dev;
+    hipLaunchKernelGGL(k_texmlp_fwd, dim3((unsigned)gs::cdiv(rows ? cap : N, 256)), dim3(256), 0, (hipStream_t)stream, A);
     GS_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int gs_texmlp_fwd(const float* x, const float* mask, int64_t N, const float* w1, const float* w2, const float* w3, int C,
                              const float* lo, const float* hi, float* out, gs_stream_t stream) {
-    return texmlp_fwd(x, 0, mask, N, w1, w2, w3, C, lo, hi, out, stream);
+    return texmlp_fwd(x, 0, nullptr, nullptr, 0, mask, N, w1, w2, w3, C, lo, hi, out, stream);
 }
 
 extern "C" int gs_texmlp_fwd_level_major(const float* x, const float* mask, int64_t N, const float* w1, const float* w2, const float* w3, int C,
                                          const float* lo, const float* hi, float* out, gs_stream_t stream) {
-    return texmlp_fwd(x, 1, mask, N, w1, w2, w3, C, lo, hi, out, stream);
+    return texmlp_fwd(x, 1, nullptr, nullptr, 0, mask, N, w1, w2, w3, C, lo, hi, out, stream);
 }
 
-static int texmlp_bwd(const float* x, int level_major, const float* mask, int64_t N, const float* w1, const float* w2, const float* w3, int C,
+extern "C" int gs_texmlp_fwd_rows(const float* x_level_major, const int32_t* rows, const int64_t* count_dev, int64_t cap, int64_t N, const float* w1,
+                                  const float* w2, const float* w3, int C, const float* lo, const float* hi, float* out, gs_stream_t stream) {
+    GS_REQUIRE(rows && count_dev && cap >= 0 && cap <= N, "gs_texmlp_fwd_rows: row list missing");
+    if (cap == 0) return 0;
+    return texmlp_fwd(x_level_major, 1, rows, count_dev, cap, nullptr, N, w1, w2, w3, C, lo, hi, out, stream);
+}
+
+static int texmlp_bwd(const float* x, int level_major, const int32_t* rows, const int64_t* count_dev, int64_t cap, const float* mask, int64_t N, const float* w1, const float* w2, const float* w3, int C,
                       const float* lo, const float* hi, const float* g_out, float* g_x, float* g_w1, float* g_w2, float* g_w3, gs_stream_t stream) {
     if (N == 0) return 0;
     GS_REQUIRE(x && w1 && w2 && w3 && lo && hi && g_out, "gs_texmlp_bwd: null pointer");
@@ -354,8 +381,8 @@ static int texmlp_bwd(const float* x, int level_major, const float* mask, int64_
     TexArgs A{};
     A.x = x; A.mask = mask; A.N = N; A.w1 = w1; A.w2 = w2; A.w3 = w3; A.C = C; A.lo = lo; A.hi = hi;
     A.g_out = g_out; A.g_x = g_x; A.g_w1 = g_w1; A.g_w2 = g_w2; A.g_w3 = g_w3;
-    A.level_major = level_major;
-    const int64_t n_chunks = gs::cdiv(N, 64);
+    A.level_major = level_major; A.rows = rows; A.count_dev = count_dev;
+    const int64_t n_chunks = gs::cdiv(rows ? cap : N, 64);
     const int64_t blocks = std::min<int64_t>(n_chunks, 768);
     hipLaunchKernelGGL(k_texmlp_bwd, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, A, n_chunks);
     GS_LAUNCH_CHECK();
@@ -365,11 +392,19 @@ static int texmlp_bwd(const float* x, int level_major, const float* mask, int64_
 extern "C" int gs_texmlp_bwd(const float* x, const float* mask, int64_t N, const float* w1, const float* w2, const float* w3, int C,
                              const float* lo, const float* hi, const float* g_out, float* g_x, float* g_w1, float* g_w2, float* g_w3,
                              gs_stream_t stream) {
-    return texmlp_bwd(x, 0, mask, N, w1, w2, w3, C, lo, hi, g_out, g_x, g_w1, g_w2, g_w3, stream);
+    return texmlp_bwd(x, 0, nullptr, nullptr, 0, mask, N, w1, w2, w3, C, lo, hi, g_out, g_x, g_w1, g_w2, g_w3, stream);
 }
 
 extern "C" int gs_texmlp_bwd_level_major(const float* x, const float* mask, int64_t N, const float* w1, const float* w2, const float* w3, int C,
                                          const float* lo, const float* hi, const float* g_out, float* g_x, float* g_w1, float* g_w2, float* g_w3,
                                          gs_stream_t stream) {
-    return texmlp_bwd(x, 1, mask, N, w1, w2, w3, C, lo, hi, g_out, g_x, g_w1, g_w2, g_w3, stream);
+    return texmlp_bwd(x, 1, nullptr, nullptr, 0, mask, N, w1, w2, w3, C, lo, hi, g_out, g_x, g_w1, g_w2, g_w3, stream);
+}
+
+extern "C" int gs_texmlp_bwd_rows(const float* x_level_major, const int32_t* rows, const int64_t* count_dev, int64_t cap, int64_t N, const float* w1,
+                                  const float* w2, const float* w3, int C, const float* lo, const float* hi, const float* g_out, float* g_x_level_major,
+                                  float* g_w1, float* g_w2, float* g_w3, gs_stream_t stream) {
+    GS_REQUIRE(rows && count_dev && cap >= 0 && cap <= N, "gs_texmlp_bwd_rows: row list missing");
+    if (cap == 0) return 0;
+    return texmlp_bwd(x_level_major, 1, rows, count_dev, cap, nullptr, N, w1, w2, w3, C, lo, hi, g_out, g_x_level_major, g_w1, g_w2, g_w3, stream);
 }

@@ -82,6 +82,9 @@ class _TexMlpFn(torch.autograd.Function):
         return g_x, None, g_w1, g_w2, g_w3, None, None
 
 
+COMPACT_ROWS = True      # _FieldFn: texture MLP over a device-compacted list of the masked rows (False: masked waves over all rows)
+
+
 class _FieldFn(torch.autograd.Function):
     """MLPTexture3D.sample as two kernels each way: AABB normalisation + clamp + hash-grid encoding
     (gs_hashgrid_encode_*), texture MLP + range mapping (gs_texmlp_*_level_major), with the [L, N, 2] LEVEL-MAJOR
@@ -99,13 +102,26 @@ class _FieldFn(torch.autograd.Function):
         ab = f(aabb)
         N, C = pos_c.shape[0], ws[2].shape[0]
         feat = torch.empty((cfg[0], N, cfg[1]), dtype=torch.float32, device=pos_c.device)
-        out = torch.empty((N, C), dtype=torch.float32, device=pos_c.device)
+        rows = count = None
         with torch.cuda.device(pos_c.device):
             check(L.gs_hashgrid_encode_fwd(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4]), ptr(pos_c, torch.float32, "pos"),
                                            ptr(ab), ptr(m_c), c_int64(N), ptr(p_c, torch.float32, "params"), ptr(feat), stream()),
                   "gs_hashgrid_encode_fwd")
-            check(L.gs_texmlp_fwd_level_major(ptr(feat), ptr(m_c), c_int64(N), ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), c_int(C), ptr(ws[3]), ptr(ws[4]),
-                                              ptr(out), stream()), "gs_texmlp_fwd_level_major")
+            if m_c is not None and N > 0 and COMPACT_ROWS:
+                # the texture MLP walks a compact list of the rows with mask > 0 (compacted on the device, no host sync): image rows
+                # in scan order put a 64-row chunk on every crossing of the silhouette, two thirds of its lanes idle
+                rows = torch.empty(N, dtype=torch.int32, device=pos_c.device)
+                count = torch.empty(2, dtype=torch.int64, device=pos_c.device)
+                scratch = torch.empty((int(L.gs_compact_rows_scratch_bytes(c_int64(N))) + 7) // 8, dtype=torch.int64, device=pos_c.device)
+                check(L.gs_compact_rows(ptr(m_c), c_int64(N), c_int64(N), ptr(scratch), ptr(rows), ptr(None), ptr(count), stream()), "gs_compact_rows")
+                out = (0.5 * (ws[4] - ws[3]) + ws[3]).expand(N, C).contiguous()         # rows outside the list: all-zero feature row
+                check(L.gs_texmlp_fwd_rows(ptr(feat), ptr(rows), ptr(count), c_int64(N), c_int64(N), ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), c_int(C),
+                                           ptr(ws[3]), ptr(ws[4]), ptr(out), stream()), "gs_texmlp_fwd_rows")
+            else:
+                out = torch.empty((N, C), dtype=torch.float32, device=pos_c.device)
+                check(L.gs_texmlp_fwd_level_major(ptr(feat), ptr(m_c), c_int64(N), ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), c_int(C), ptr(ws[3]), ptr(ws[4]),
+                                                  ptr(out), stream()), "gs_texmlp_fwd_level_major")
+        ctx.rows = (rows, count)
         ctx.save_for_backward(pos_c, p_c, m_c, feat, ab, *ws)
         ctx.cfg, ctx.scales, ctx.img = cfg, (float(mlp_scale), float(enc_scale)), img
         return out
@@ -125,8 +141,13 @@ class _FieldFn(torch.autograd.Function):
         g_pos = torch.empty_like(pos_c) if need_pos else None
         H, W = img if img is not None else (0, 0)
         with torch.cuda.device(g.device):
-            check(L.gs_texmlp_bwd_level_major(ptr(feat), ptr(m_c), c_int64(N), ptr(w1), ptr(w2), ptr(w3), c_int(C), ptr(lo), ptr(hi), ptr(g),
-                                              ptr(g_feat), ptr(g_w1), ptr(g_w2), ptr(g_w3), stream()), "gs_texmlp_bwd_level_major")
+            rows, count = ctx.rows
+            if rows is not None:
+                check(L.gs_texmlp_bwd_rows(ptr(feat), ptr(rows), ptr(count), c_int64(N), c_int64(N), ptr(w1), ptr(w2), ptr(w3), c_int(C), ptr(lo), ptr(hi),
+                                           ptr(g), ptr(g_feat), ptr(g_w1), ptr(g_w2), ptr(g_w3), stream()), "gs_texmlp_bwd_rows")
+            else:
+                check(L.gs_texmlp_bwd_level_major(ptr(feat), ptr(m_c), c_int64(N), ptr(w1), ptr(w2), ptr(w3), c_int(C), ptr(lo), ptr(hi), ptr(g),
+                                                  ptr(g_feat), ptr(g_w1), ptr(g_w2), ptr(g_w3), stream()), "gs_texmlp_bwd_level_major")
             if g_feat is not None:
                 # d/d feat of the MLP carries the x128 hook; the table gradient takes it as is, the position gradient takes x128 / 128
                 check(L.gs_hashgrid_encode_bwd(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4]), ptr(pos_c), ptr(ab), ptr(m_c),

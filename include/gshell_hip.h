@@ -442,6 +442,16 @@ int gs_texmlp_bwd_level_major(const float* x, const float* mask, int64_t N, cons
                               const float* w2, const float* w3, int C, const float* lo,
                               const float* hi, const float* g_out, float* g_x, float* g_w1,
                               float* g_w2, float* g_w3, gs_stream_t stream);
+/* ... over a COMPACT list of rows (rows [cap] i32 ascending, count_dev [2] i64 on the device, e.g. gs_compact_rows of the mask:
+ * no host sync): only listed rows are read / written -- out rows outside the list keep what the caller put there (the value
+ * of an all-zero feature row, 0.5 (hi - lo) + lo); image rows in scan order leave two thirds of the lanes of a masked pass idle. */
+int gs_texmlp_fwd_rows(const float* x_level_major, const int32_t* rows, const int64_t* count_dev,
+                       int64_t cap, int64_t N, const float* w1, const float* w2, const float* w3, int C,
+                       const float* lo, const float* hi, float* out, gs_stream_t stream);
+int gs_texmlp_bwd_rows(const float* x_level_major, const int32_t* rows, const int64_t* count_dev,
+                       int64_t cap, int64_t N, const float* w1, const float* w2, const float* w3, int C,
+                       const float* lo, const float* hi, const float* g_out, float* g_x_level_major,
+                       float* g_w1, float* g_w2, float* g_w3, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Surface samples for the eikonal term   (stands in for kaolin.ops.mesh.sample_points, third party, called at
@@ -570,7 +580,7 @@ int64_t gs_sdf_mlp_h2_rows_padded(int mode, int64_t n);
  *   n is then a CAPACITY (an upper bound on the rows with gradient, e.g. 2 x crossing edges) and n_dev -> count_dev[0];
  *   tiles past the device-side count exit.  n_dev = NULL: n is the exact count (the caller synchronised). */
 int64_t gs_compact_rows_scratch_bytes(int64_t N);
-int gs_compact_rows(const float* g, int64_t N, int64_t cap, void* scratch, int32_t* rows, float* g_rows,
+int gs_compact_rows(const float* g, int64_t N, int64_t cap, void* scratch, int32_t* rows, float* g_rows /* may be NULL */,
                     int64_t* count_dev /* [2]: min(count, cap), overflow flag */, gs_stream_t stream);
 int gs_sdf_mlp_h2_save_fwd(int mode, const float* x, const int32_t* rows, int64_t n, const int64_t* n_dev,
                            const void* packed, int n_freq, int n_hidden, int skip_layer, float* A_save,
