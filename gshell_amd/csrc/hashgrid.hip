@@ -160,6 +160,7 @@ struct EncArgs {
     const float* params; float* feat;
     const float* g_feat; float* g_params; float* g_pos; float grad_scale, table_scale;
     int img_w, img_h;
+    const int32_t* rows; const int64_t* count_dev;     // forward: optional compact list of the points to encode (count on the device)
 };
 
 __device__ __forceinline__ bool enc_coord(const EncArgs& A, int64_t i, float (&t)[3], bool (&inside)[3]) {
@@ -175,9 +176,14 @@ __device__ __forceinline__ bool enc_coord(const EncArgs& A, int64_t i, float (&t
 }
 
 __global__ void __launch_bounds__(256) k_encode_fwd(GridMeta M, EncArgs A) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int l = blockIdx.y;
-    if (i >= A.N || (A.mask && !(A.mask[i] > 0.0f))) return;
+    if (A.rows) {
+        if (i >= A.count_dev[0]) return;
+        i = A.rows[i];
+    } else if (i >= A.N || (A.mask && !(A.mask[i] > 0.0f))) {
+        return;
+    }
     float t[3];
     bool inside[3];
     enc_coord(A, i, t, inside);
@@ -502,6 +508,22 @@ extern "C" int gs_hashgrid_encode_fwd(int n_levels, int F, int log2_T, int base_
     EncArgs A{};
     A.pos = pos; A.aabb = aabb; A.mask = mask; A.N = N; A.params = params; A.feat = feat_level_major;
     hipLaunchKernelGGL(k_encode_fwd, dim3((unsigned)gs::cdiv(N, 256), (unsigned)n_levels), dim3(256), 0, (hipStream_t)stream, M, A);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_hashgrid_encode_fwd_rows(int n_levels, int F, int log2_T, int base_res, float per_level_scale, const float* pos, const float* aabb,
+                                           const int32_t* rows, const int64_t* count_dev, int64_t cap, int64_t N, const float* params,
+                                           float* feat_level_major, gs_stream_t stream) {
+    GridMeta M;
+    int rc = make_meta(M, n_levels, F, log2_T, base_res, per_level_scale);
+    if (rc) return rc;
+    GS_REQUIRE(F == 2, "gs_hashgrid_encode_fwd_rows: the level-major path is built for 2 features per level");
+    if (N == 0 || cap == 0) return 0;
+    GS_REQUIRE(pos && params && feat_level_major && rows && count_dev && cap <= N, "gs_hashgrid_encode_fwd_rows: null pointer");
+    EncArgs A{};
+    A.pos = pos; A.aabb = aabb; A.N = N; A.params = params; A.feat = feat_level_major; A.rows = rows; A.count_dev = count_dev;
+    hipLaunchKernelGGL(k_encode_fwd, dim3((unsigned)gs::cdiv(cap, 256), (unsigned)n_levels), dim3(256), 0, (hipStream_t)stream, M, A);
     GS_LAUNCH_CHECK();
     return 0;
 }

@@ -104,17 +104,22 @@ class _FieldFn(torch.autograd.Function):
         feat = torch.empty((cfg[0], N, cfg[1]), dtype=torch.float32, device=pos_c.device)
         rows = count = None
         with torch.cuda.device(pos_c.device):
-            check(L.gs_hashgrid_encode_fwd(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4]), ptr(pos_c, torch.float32, "pos"),
-                                           ptr(ab), ptr(m_c), c_int64(N), ptr(p_c, torch.float32, "params"), ptr(feat), stream()),
-                  "gs_hashgrid_encode_fwd")
             if m_c is not None and N > 0 and COMPACT_ROWS:
-                # the texture MLP walks a compact list of the rows with mask > 0 (compacted on the device, no host sync): image rows
-                # in scan order put a 64-row chunk on every crossing of the silhouette, two thirds of its lanes idle
+                # encoder and texture MLP walk a compact list of the rows with mask > 0 (compacted on the device, no host sync): image
+                # rows in scan order put a 64-row chunk on every crossing of the silhouette, two thirds of its lanes idle
                 rows = torch.empty(N, dtype=torch.int32, device=pos_c.device)
                 count = torch.empty(2, dtype=torch.int64, device=pos_c.device)
                 scratch = torch.empty((int(L.gs_compact_rows_scratch_bytes(c_int64(N))) + 7) // 8, dtype=torch.int64, device=pos_c.device)
                 check(L.gs_compact_rows(ptr(m_c), c_int64(N), c_int64(N), ptr(scratch), ptr(rows), ptr(None), ptr(count), stream()), "gs_compact_rows")
-                out = (0.5 * (ws[4] - ws[3]) + ws[3]).expand(N, C).contiguous()         # rows outside the list: all-zero feature row
+                check(L.gs_hashgrid_encode_fwd_rows(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4]),
+                                                    ptr(pos_c, torch.float32, "pos"), ptr(ab), ptr(rows), ptr(count), c_int64(N), c_int64(N),
+                                                    ptr(p_c, torch.float32, "params"), ptr(feat), stream()), "gs_hashgrid_encode_fwd_rows")
+            else:
+                check(L.gs_hashgrid_encode_fwd(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4]),
+                                               ptr(pos_c, torch.float32, "pos"), ptr(ab), ptr(m_c), c_int64(N), ptr(p_c, torch.float32, "params"),
+                                               ptr(feat), stream()), "gs_hashgrid_encode_fwd")
+            if rows is not None:
+                out = ((ws[4] + ws[3]) * 0.5).expand(N, C).contiguous()         # rows outside the list: sigmoid(0) (hi - lo) + lo, the all-zero feature row
                 check(L.gs_texmlp_fwd_rows(ptr(feat), ptr(rows), ptr(count), c_int64(N), c_int64(N), ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), c_int(C),
                                            ptr(ws[3]), ptr(ws[4]), ptr(out), stream()), "gs_texmlp_fwd_rows")
             else:

@@ -371,6 +371,11 @@ int gs_hashgrid_bwd(int n_levels, int F, int log2_T, int base_res, float per_lev
 int gs_hashgrid_encode_fwd(int n_levels, int F, int log2_T, int base_res, float per_level_scale,
                            const float* pos, const float* aabb, const float* mask, int64_t N,
                            const float* params, float* feat_level_major, gs_stream_t stream);
+/* forward over a compact list of points (rows [cap] i32, count_dev on the device: gs_compact_rows of the mask) */
+int gs_hashgrid_encode_fwd_rows(int n_levels, int F, int log2_T, int base_res, float per_level_scale,
+                                const float* pos, const float* aabb, const int32_t* rows,
+                                const int64_t* count_dev, int64_t cap, int64_t N, const float* params,
+                                float* feat_level_major, gs_stream_t stream);
 int gs_hashgrid_encode_bwd(int n_levels, int F, int log2_T, int base_res, float per_level_scale,
                            const float* pos, const float* aabb, const float* mask, int64_t N,
                            const float* params, const float* g_feat_level_major, float* g_params,
