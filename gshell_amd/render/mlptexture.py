@@ -119,7 +119,7 @@ class _FieldFn(torch.autograd.Function):
                                                ptr(pos_c, torch.float32, "pos"), ptr(ab), ptr(m_c), c_int64(N), ptr(p_c, torch.float32, "params"),
                                                ptr(feat), stream()), "gs_hashgrid_encode_fwd")
             if rows is not None:
-                out = ((ws[4] + ws[3]) * 0.5).expand(N, C).contiguous()         # rows outside the list: sigmoid(0) (hi - lo) + lo, the all-zero feature row
+                out = (0.5 * (ws[4] - ws[3]) + ws[3]).expand(N, C).contiguous()         # rows outside the list: the all-zero feature row, same expression as the kernel
                 check(L.gs_texmlp_fwd_rows(ptr(feat), ptr(rows), ptr(count), c_int64(N), c_int64(N), ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), c_int(C),
                                            ptr(ws[3]), ptr(ws[4]), ptr(out), stream()), "gs_texmlp_fwd_rows")
             else:
