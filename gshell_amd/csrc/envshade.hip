@@ -878,6 +878,9 @@ int fill_args(ShadeArgs& A, const gs_bvh* bvh, const int32_t* pix, int64_t n_cov
 // two half-rows of a 16-lane service group land on different halves of the 256-byte bank row), x^128 as seven squarings, ONE
 // v_exp_f32 (the spatial Gaussian is folded into the exponent from a per-window-row LDS table) and ONE v_rcp_f32.
 // Pixels outside the image are staged with a zero normal: their weight is clamp(0)^128 = 0 exactly, as if skipped.
+#ifndef GS_BILATERAL_DUAL
+#define GS_BILATERAL_DUAL 1
+#endif
 constexpr float FLT_EPS_D = 0.0001f;
 constexpr int BIL_TX = 32, BIL_TY = 16, BIL_NT = BIL_TX * BIL_TY;
 constexpr float LOG2E = 1.4426950408889634f;
@@ -887,11 +890,16 @@ __host__ __device__ inline int bil_row_stride(int R) {   // pixels; >= 32 + 2R, 
     return w + ((8 - (w & 15)) & 15);
 }
 
-template <bool BWD>
+// DUAL: a SECOND colour image (the specular radiance next to the diffuse one) filtered with the same weights -- the weights depend
+// on the guides only, and they are 20 of the ~24 VALU operations of a tap.  Third LDS plane (102 KB at R = 11: one workgroup / CU).
+struct BilSecond {
+    const float* col; float* out; const float* g_out; float* g_col;
+};
+template <bool BWD, bool DUAL>
 __global__ void __launch_bounds__(BIL_NT, 2) k_bilateral_tile(const float* __restrict__ col, const float* __restrict__ nrm, const float* __restrict__ zdz,
                                                                int H, int W, float sigma, int R, float* __restrict__ out,
                                                                const float* __restrict__ g_out, float* __restrict__ g_col,
-                                                               const float* __restrict__ mask) {
+                                                               const float* __restrict__ mask, BilSecond S2) {
     extern __shared__ __attribute__((aligned(16))) float4 bil_smem[];
     // `mask` (optional): pixels with mask <= 0 are pixels whose filtered value nobody reads (no triangle covers them: the
     // composite multiplies their buffers by alpha = 0, the shader never looks at their gradient).  They still act as TAPS of
@@ -906,6 +914,10 @@ __global__ void __launch_bounds__(BIL_NT, 2) k_bilateral_tile(const float* __res
                 const int64_t ci = (int64_t)blockIdx.z * H * W + (int64_t)my * W + mx;
                 if (!BWD) *reinterpret_cast<float4*>(out + 4 * ci) = make_float4(0.f, 0.f, 0.f, 0.0001f);
                 else { g_col[3 * ci] = 0.f; g_col[3 * ci + 1] = 0.f; g_col[3 * ci + 2] = 0.f; }
+                if (DUAL) {
+                    if (!BWD) *reinterpret_cast<float4*>(S2.out + 4 * ci) = make_float4(0.f, 0.f, 0.f, 0.0001f);
+                    else { S2.g_col[3 * ci] = 0.f; S2.g_col[3 * ci + 1] = 0.f; S2.g_col[3 * ci + 2] = 0.f; }
+                }
             }
             return;
         }
@@ -913,7 +925,8 @@ __global__ void __launch_bounds__(BIL_NT, 2) k_bilateral_tile(const float* __res
     const int RS = bil_row_stride(R), TH = BIL_TY + 2 * R, TW = BIL_TX + 2 * R;
     float4* sA = bil_smem;                 // [TH][RS]  (nx, ny, nz, z)
     float4* sB = sA + TH * RS;             // [TH][RS]  (dz, c0, c1, c2)   c = colour (fwd) / upstream gradient (bwd)
-    float2* sT = reinterpret_cast<float2*>(sB + TH * RS);     // [(R+1)^2]  (log2e * d^2 / (2 sigma^2), d) for d^2 = fx^2 + fy^2
+    float4* sC = sB + TH * RS;             // DUAL: [TH][RS]  (c0, c1, c2, -) of the second image
+    float2* sT = reinterpret_cast<float2*>(sB + (DUAL ? 2 : 1) * TH * RS);     // [(R+1)^2]  (log2e * d^2 / (2 sigma^2), d) for d^2 = fx^2 + fy^2
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * BIL_TX, y0 = blockIdx.y * BIL_TY;
     const int64_t base = (int64_t)blockIdx.z * H * W;
@@ -925,7 +938,7 @@ __global__ void __launch_bounds__(BIL_NT, 2) k_bilateral_tile(const float* __res
     for (int i = tid; i < TH * TW; i += BIL_NT) {
         int ty = i / TW, tx = i - ty * TW;
         int x = x0 + tx - R, y = y0 + ty - R;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f), c2 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (x >= 0 && x < W && y >= 0 && y < H) {
             int64_t p = base + (int64_t)y * W + x;
             float2 zz = *reinterpret_cast<const float2*>(zdz + 2 * p);
@@ -933,22 +946,27 @@ __global__ void __launch_bounds__(BIL_NT, 2) k_bilateral_tile(const float* __res
             if (BWD) {
                 float4 g = *reinterpret_cast<const float4*>(g_out + 4 * p);
                 b = make_float4(zz.y, g.x, g.y, g.z);
-            } else
+                if (DUAL) c2 = *reinterpret_cast<const float4*>(S2.g_out + 4 * p);
+            } else {
                 b = make_float4(zz.y, col[3 * p], col[3 * p + 1], col[3 * p + 2]);
+                if (DUAL) c2 = make_float4(S2.col[3 * p], S2.col[3 * p + 1], S2.col[3 * p + 2], 0.f);
+            }
         }
         sA[ty * RS + tx] = a;
         sB[ty * RS + tx] = b;
+        if (DUAL) sC[ty * RS + tx] = c2;
     }
     __syncthreads();
     const int lx = tid & (BIL_TX - 1), ly = tid / BIL_TX;
     const int x = x0 + lx, y = y0 + ly;
     const float4 ca = sA[(ly + R) * RS + lx + R];
     const float cdz = sB[(ly + R) * RS + lx + R].x;
-    float acc_w = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    float acc_w = 0.f, ax = 0.f, ay = 0.f, az = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
     const int R_eff = (mask && __ballot(wanted) == 0ull) ? -1 : R;       // a wave (two tile rows) without a wanted pixel: no taps
     for (int fy = -R_eff; fy <= R_eff; ++fy) {
         const float4* rowA = sA + (ly + R + fy) * RS + lx + R;
         const float4* rowB = sB + (ly + R + fy) * RS + lx + R;
+        const float4* rowC = sC + (ly + R + fy) * RS + lx + R;
         const float2* rowT = sT + (fy < 0 ? -fy : fy) * (R + 1);
 #pragma unroll 2
         for (int fx = -R; fx <= R; ++fx) {
@@ -965,12 +983,27 @@ __global__ void __launch_bounds__(BIL_NT, 2) k_bilateral_tile(const float* __res
             ax = __builtin_fmaf(tb.y, w, ax);
             ay = __builtin_fmaf(tb.z, w, ay);
             az = __builtin_fmaf(tb.w, w, az);
+            if (DUAL) {
+                const float4 tc = rowC[fx];
+                bx = __builtin_fmaf(tc.x, w, bx);
+                by = __builtin_fmaf(tc.y, w, by);
+                bz = __builtin_fmaf(tc.z, w, bz);
+            }
             if (!BWD) acc_w += w;
         }
     }
     if (x >= W || y >= H) return;
     const int64_t ci = base + (int64_t)y * W + x;
-    if (!wanted) ax = ay = az = acc_w = 0.f;
+    if (!wanted) ax = ay = az = bx = by = bz = acc_w = 0.f;
+    if (DUAL) {
+        if (!BWD) {
+            *reinterpret_cast<float4*>(S2.out + 4 * ci) = make_float4(bx, by, bz, fmaxf(acc_w, 0.0001f));
+        } else {
+            S2.g_col[3 * ci] = bx;
+            S2.g_col[3 * ci + 1] = by;
+            S2.g_col[3 * ci + 2] = bz;
+        }
+    }
     if (!BWD) {
         *reinterpret_cast<float4*>(out + 4 * ci) = make_float4(ax, ay, az, fmaxf(acc_w, 0.0001f));
     } else {
@@ -1037,8 +1070,8 @@ __global__ void __launch_bounds__(256) k_bilateral_direct(const float* __restric
 
 int bilateral_radius(float sigma) { return 2 * (int)std::ceil(sigma * 2.5f) + 1; }
 
-size_t bilateral_smem_bytes(int R) {
-    return (size_t)2 * (BIL_TY + 2 * R) * bil_row_stride(R) * sizeof(float4) + (size_t)(R + 1) * (R + 1) * sizeof(float2);
+size_t bilateral_smem_bytes(int R, int planes = 2) {
+    return (size_t)planes * (BIL_TY + 2 * R) * bil_row_stride(R) * sizeof(float4) + (size_t)(R + 1) * (R + 1) * sizeof(float2);
 }
 
 template <bool BWD>
@@ -1048,13 +1081,33 @@ int launch_bilateral(const float* col, const float* nrm, const float* zdz, const
     const size_t smem = bilateral_smem_bytes(R);
     if (smem <= 80 * 1024) {      // two workgroups per CU (160 KB of LDS)
         // set on every launch: the attribute is per device / per function, and a per-process flag would be neither
-        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bilateral_tile<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bilateral_tile<BWD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         dim3 grid((unsigned)gs::cdiv(W, BIL_TX), (unsigned)gs::cdiv(H, BIL_TY), (unsigned)B);
-        hipLaunchKernelGGL(k_bilateral_tile<BWD>, grid, dim3(BIL_NT), smem, stream, col, nrm, zdz, (int)H, (int)W, sigma, R, out, g_out, g_col, mask);
+        hipLaunchKernelGGL((k_bilateral_tile<BWD, false>), grid, dim3(BIL_NT), smem, stream, col, nrm, zdz, (int)H, (int)W, sigma, R, out, g_out, g_col, mask,
+                           BilSecond{});
     } else {
         dim3 grid((unsigned)gs::cdiv(W, 16), (unsigned)gs::cdiv(H, 16), (unsigned)B);
         hipLaunchKernelGGL(k_bilateral_direct<BWD>, grid, dim3(256), 0, stream, col, nrm, zdz, B, (int)H, (int)W, sigma, R, out, g_out, g_col, mask);
     }
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+// two colour images with shared guides: one dual launch while the three LDS planes fit (sigma <= ~2.4), else two single passes
+template <bool BWD>
+int launch_bilateral2(const float* col_a, const float* col_b, const float* nrm, const float* zdz, const float* mask, int64_t B, int64_t H, int64_t W,
+                      float sigma, float* out_a, float* out_b, const float* g_out_a, const float* g_out_b, float* g_col_a, float* g_col_b,
+                      hipStream_t stream) {
+    const int R = bilateral_radius(sigma);
+    const size_t smem = bilateral_smem_bytes(R, 3);
+    if (smem > 160 * 1024 || !GS_BILATERAL_DUAL) {
+        if (int rc = launch_bilateral<BWD>(col_a, nrm, zdz, mask, B, H, W, sigma, out_a, g_out_a, g_col_a, stream)) return rc;
+        return launch_bilateral<BWD>(col_b, nrm, zdz, mask, B, H, W, sigma, out_b, g_out_b, g_col_b, stream);
+    }
+    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bilateral_tile<BWD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    dim3 grid((unsigned)gs::cdiv(W, BIL_TX), (unsigned)gs::cdiv(H, BIL_TY), (unsigned)B);
+    hipLaunchKernelGGL((k_bilateral_tile<BWD, true>), grid, dim3(BIL_NT), smem, stream, col_a, nrm, zdz, (int)H, (int)W, sigma, R, out_a, g_out_a, g_col_a,
+                       mask, BilSecond{col_b, out_b, g_out_b, g_col_b});
     GS_LAUNCH_CHECK();
     return 0;
 }
@@ -1184,6 +1237,21 @@ extern "C" int gs_bilateral_fwd_masked(const float* col, const float* nrm, const
     if (B * H * W == 0) return 0;
     GS_REQUIRE(col && nrm && zdz && out && sigma > 0.f, "gs_bilateral_fwd_masked: null pointer / sigma <= 0");
     return launch_bilateral<false>(col, nrm, zdz, mask, B, H, W, sigma, out, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int gs_bilateral_fwd_masked2(const float* col_a, const float* col_b, const float* nrm, const float* zdz, const float* mask, int64_t B,
+                                        int64_t H, int64_t W, float sigma, float* out_a, float* out_b, gs_stream_t stream) {
+    if (B * H * W == 0) return 0;
+    GS_REQUIRE(col_a && col_b && nrm && zdz && out_a && out_b && sigma > 0.f, "gs_bilateral_fwd_masked2: null pointer / sigma <= 0");
+    return launch_bilateral2<false>(col_a, col_b, nrm, zdz, mask, B, H, W, sigma, out_a, out_b, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int gs_bilateral_bwd_masked2(const float* nrm, const float* zdz, const float* mask, int64_t B, int64_t H, int64_t W, float sigma,
+                                        const float* g_out_a, const float* g_out_b, float* g_col_a, float* g_col_b, gs_stream_t stream) {
+    if (B * H * W == 0) return 0;
+    GS_REQUIRE(nrm && zdz && g_out_a && g_out_b && g_col_a && g_col_b && sigma > 0.f, "gs_bilateral_bwd_masked2: null pointer / sigma <= 0");
+    return launch_bilateral2<true>(nullptr, nullptr, nrm, zdz, mask, B, H, W, sigma, nullptr, nullptr, g_out_a, g_out_b, g_col_a, g_col_b,
+                                   (hipStream_t)stream);
 }
 
 extern "C" int gs_bilateral_bwd(const float* nrm, const float* zdz, int64_t B, int64_t H, int64_t W, float sigma, const float* g_out, float* g_col,

@@ -24,6 +24,10 @@ class BilateralDenoiser(torch.nn.Module):
         into the buffer assembly).  `nrm_unit` must already be normalised.  `mask` > 0 marks the pixels whose value the caller uses."""
         return ou.bilateral_denoiser_raw(rgb, nrm_unit, zdz, self.sigma, mask)
 
+    def filter_raw_pair(self, rgb_a, rgb_b, nrm_unit, zdz, mask=None):
+        """filter_raw of two images with the same guides (diffuse and specular radiance): the weights are computed once"""
+        return ou.bilateral_denoiser_raw_pair(rgb_a, rgb_b, nrm_unit, zdz, self.sigma, mask)
+
     def forward(self, input):
         rgb, nrm, zdz = input[..., :3], input[..., 3:6], input[..., 6:8]
         return ou.bilateral_denoiser(rgb, util.safe_normalize(nrm), zdz, self.sigma)   # bent normals are not unit length

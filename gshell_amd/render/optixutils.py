@@ -202,6 +202,42 @@ class _bilateral_denoiser_func(torch.autograd.Function):
         return g_col, None, None, None, None
 
 
+class _bilateral_denoiser_pair_func(torch.autograd.Function):
+    """two colour images, one set of guides, one kernel each way (gs_bilateral_*_masked2): the filter weights are shared"""
+
+    @staticmethod
+    def forward(ctx, col_a, col_b, nrm, zdz, sigma, mask=None):
+        ca, cb, nrm_c, zdz_c = (x.detach().contiguous().float() for x in (col_a, col_b, nrm, zdz))
+        m_c = None if mask is None else mask.detach().reshape(ca.shape[:3]).contiguous().float()
+        B, H, W, _ = ca.shape
+        out_a = torch.empty((B, H, W, 4), dtype=torch.float32, device=ca.device)
+        out_b = torch.empty_like(out_a)
+        with torch.cuda.device(ca.device):
+            check(_lib.lib().gs_bilateral_fwd_masked2(ptr(ca, torch.float32, "col_a"), ptr(cb, torch.float32, "col_b"), ptr(nrm_c), ptr(zdz_c), ptr(m_c),
+                                                      c_int64(B), c_int64(H), c_int64(W), c_float(sigma), ptr(out_a), ptr(out_b), stream()),
+                  "gs_bilateral_fwd_masked2")
+        ctx.save_for_backward(nrm_c, zdz_c, m_c)
+        ctx.sigma = sigma
+        return out_a, out_b
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        nrm_c, zdz_c, m_c = ctx.saved_tensors
+        B, H, W, _ = nrm_c.shape
+        ga, gb = ga.contiguous().float(), gb.contiguous().float()
+        g_a = torch.empty((B, H, W, 3), dtype=torch.float32, device=ga.device)
+        g_b = torch.empty_like(g_a)
+        with torch.cuda.device(ga.device):
+            check(_lib.lib().gs_bilateral_bwd_masked2(ptr(nrm_c), ptr(zdz_c), ptr(m_c), c_int64(B), c_int64(H), c_int64(W), c_float(ctx.sigma), ptr(ga),
+                                                      ptr(gb), ptr(g_a), ptr(g_b), stream()), "gs_bilateral_bwd_masked2")
+        return g_a, g_b, None, None, None, None
+
+
+def bilateral_denoiser_raw_pair(col_a, col_b, nrm, zdz, sigma, mask=None):
+    """bilateral_denoiser_raw of two images that share their guides (and the filter weights): one launch each way"""
+    return _bilateral_denoiser_pair_func.apply(col_a, col_b, nrm, zdz, sigma, mask)
+
+
 def bilateral_denoiser_raw(col, nrm, zdz, sigma, mask=None):
     """[B,H,W,4] = (sum w c, max(sum w, 1e-4)): the kernel's own output (denoising.cu:66-70), before the reference's division.
     `mask` [B,H,W(,1)]: only pixels with mask > 0 are consumed by the caller (covered pixels); the others are written as

@@ -224,8 +224,11 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
                 with torch.no_grad():
                     nrm_unit = util.safe_normalize(gb_normal)       # the filter's guides carry no gradient (optixutils.py backward)
                 # only covered pixels are read by gs_shade_assemble (alpha = 0 elsewhere): the others are taps, not centres
-                diffuse_accum = denoiser.filter_raw(diffuse_accum, nrm_unit, gb_depth, mask)        # [B,H,W,4] = (sum w c, sum w)
-                specular_accum = denoiser.filter_raw(specular_accum, nrm_unit, gb_depth, mask)
+                if hasattr(denoiser, "filter_raw_pair"):      # same guides, same weights: one pass for both images
+                    diffuse_accum, specular_accum = denoiser.filter_raw_pair(diffuse_accum, specular_accum, nrm_unit, gb_depth, mask)
+                else:
+                    diffuse_accum = denoiser.filter_raw(diffuse_accum, nrm_unit, gb_depth, mask)        # [B,H,W,4] = (sum w c, sum w)
+                    specular_accum = denoiser.filter_raw(specular_accum, nrm_unit, gb_depth, mask)
             return PendingFrame(tex=all_tex, texj=all_tex_jitter, n_in=gb_normal_interp, n_jit=nrm_jitter, mask_tap=grad_weight, n_shade=gb_normal,
                                 n_geo=gb_geometric_normal, depth=gb_depth, dif=diffuse_accum, spc=specular_accum)
         if denoiser is not None and FLAGS.denoiser_demodulate:

@@ -342,6 +342,14 @@ int gs_bilateral_fwd_masked(const float* col, const float* nrm, const float* zdz
 int gs_bilateral_bwd_masked(const float* nrm, const float* zdz, const float* mask, int64_t B, int64_t H,
                             int64_t W, float sigma, const float* g_out, float* g_col,
                             gs_stream_t stream);
+/* two colour images (diffuse and specular radiance, render.py:231-232) with the same guides in one pass: the filter weights
+ * depend on the guides only and are most of a tap's arithmetic.  Same values as two single calls. */
+int gs_bilateral_fwd_masked2(const float* col_a, const float* col_b, const float* nrm, const float* zdz,
+                             const float* mask, int64_t B, int64_t H, int64_t W, float sigma,
+                             float* out_a, float* out_b, gs_stream_t stream);
+int gs_bilateral_bwd_masked2(const float* nrm, const float* zdz, const float* mask, int64_t B, int64_t H,
+                             int64_t W, float sigma, const float* g_out_a, const float* g_out_b,
+                             float* g_col_a, float* g_col_b, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Multiresolution hash-grid encoding   (replaces tinycudann.Encoding(3, HashGrid cfg) as configured by

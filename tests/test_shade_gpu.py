@@ -220,3 +220,25 @@ def test_env_shade_backward_from_saved_samples_equals_the_replayed_sampler(bsdf,
             assert torch.equal(x, y), (name, float((x - y).abs().max()))
     assert float(b[6].abs().max()) > 0
     assert float((a[6] - b[6]).abs().max()) <= 1e-5 * float(b[6].abs().max())
+
+
+@pytest.mark.parametrize("sigma,masked", [(2.0, True), (2.0, False), (0.6, True), (4.5, True)])
+def test_bilateral_pair_equals_two_single_passes(sigma, masked):
+    """gs_bilateral_*_masked2 (two colour images, shared guides, weights computed once; falls back to two passes when three LDS
+    planes do not fit): bit-identical to two calls of the single-image filter, forward and backward."""
+    from gshell_amd.render import optixutils as ou
+    gen = torch.Generator().manual_seed(12)
+    B, H, W = 2, 50, 77
+    ca, cb = torch.rand(B, H, W, 3, generator=gen).to(DEV), torch.rand(B, H, W, 3, generator=gen).to(DEV)
+    nrm = torch.nn.functional.normalize(torch.randn(B, H, W, 3, generator=gen) * 0.3 + torch.tensor([0, 0, 1.0]), dim=-1).to(DEV)
+    zdz = torch.stack([torch.rand(B, H, W, generator=gen) * 0.2 + 0.5, torch.rand(B, H, W, generator=gen) * 0.02], -1).to(DEV)
+    mask = (torch.rand(B, H, W, generator=gen) > 0.5).float().to(DEV) if masked else None
+    wa, wb = torch.randn(B, H, W, 4, generator=gen).to(DEV), torch.randn(B, H, W, 4, generator=gen).to(DEV)
+    a1, b1 = ca.clone().requires_grad_(True), cb.clone().requires_grad_(True)
+    oa, ob = ou.bilateral_denoiser_raw_pair(a1, b1, nrm, zdz, sigma, mask)
+    ((oa * wa).sum() + (ob * wb).sum()).backward()
+    a2, b2 = ca.clone().requires_grad_(True), cb.clone().requires_grad_(True)
+    ra, rb = ou.bilateral_denoiser_raw(a2, nrm, zdz, sigma, mask), ou.bilateral_denoiser_raw(b2, nrm, zdz, sigma, mask)
+    ((ra * wa).sum() + (rb * wb).sum()).backward()
+    assert torch.equal(oa, ra) and torch.equal(ob, rb)
+    assert torch.equal(a1.grad, a2.grad) and torch.equal(b1.grad, b2.grad)
