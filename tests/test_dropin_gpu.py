@@ -65,6 +65,8 @@ def test_reference_style_training_loop(tmp_path):
             geometry.clamp_deform()
         losses.append(float(img_loss.detach()))
     assert all(np.isfinite(losses))
-    assert losses[-1] < losses[0] - 0.015 and all(b < a + 1e-3 for a, b in zip(losses, losses[1:])), losses     # steady descent
+    # descent: clearly lower at the end, no step up beyond the Monte-Carlo / float-atomic noise of a 2-sample, 64 x 64 render (a 1e-3
+    # bound failed once in ~10 runs of the unchanged code: summation order differs from run to run and 12 Adam steps amplify it)
+    assert losses[-1] < losses[0] - 0.015 and all(b < a + 5e-3 for a, b in zip(losses, losses[1:])), losses
     sd = geometry.state_dict()
     assert {"sdf", "msdf", "deform"} <= set(sd) and "sdf_net.net.0.weight" in sd
