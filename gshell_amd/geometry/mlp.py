@@ -280,10 +280,10 @@ def param_gate(net, reuse=False):
     """a token for this forward pass; `reuse` = take the one the grid pass of the same iteration left on the network"""
     if reuse:
         g = net.__dict__.pop("_gs_gate", None)
-        if g is not None:
+        if g is not None and (g.requires_grad or not torch.is_grad_enabled()):      # never a token made under no_grad for a pass that needs gradients
             return g
     g = _ParamGate.apply(*list(net.parameters()))
-    if not reuse:
+    if not reuse and g.requires_grad:
         net.__dict__["_gs_gate"] = g
     return g
 

@@ -78,3 +78,24 @@ def test_split_k_linear_matches_plain_linear_through_double_backward():
     b = grads(lambda m, h: m(h))
     for p, q in zip(a, b):
         assert torch.allclose(p, q, rtol=1e-12, atol=1e-14)
+
+
+def test_parameter_gate_token_is_not_reused_across_grad_modes():
+    """mlp.param_gate: the grid pass leaves its token on the network for the eikonal pass of the same iteration; a token created under
+    no_grad (validation render) must not be handed to a pass that needs parameter gradients."""
+    from gshell_amd.geometry import mlp as M
+    torch.manual_seed(0)
+    net = M.MLP(n_freq=2, d_hidden=16, n_hidden=2, skip_in=[])
+    with torch.no_grad():
+        g0 = M.param_gate(net)
+    assert not g0.requires_grad and "_gs_gate" not in net.__dict__
+    g1 = M.param_gate(net)
+    assert g1.requires_grad and net.__dict__["_gs_gate"] is g1
+    assert M.param_gate(net, reuse=True) is g1 and "_gs_gate" not in net.__dict__
+    g2 = M.param_gate(net, reuse=True)                     # nothing stashed: a fresh token
+    assert g2 is not g1 and g2.requires_grad
+    flat = torch.arange(float(g2.numel()))
+    g2.backward(flat)
+    got = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert torch.equal(got, flat)                          # the gate hands every parameter its slice of the flat gradient
+    assert all(torch.equal(a, b) for a, b in zip(M.split_param_grads(net, flat), [p.grad for p in net.parameters()]))
