@@ -524,7 +524,9 @@ __global__ void __launch_bounds__(256, BWD ? 1 : GS_SAMPLES_WAVES) k_shade_sampl
         float kk;
         eval_sample<BWD>(A, c, dir, pdf_light + pdf_b, sample_frac, BWD ? vis_of(A, r) : 0.f, g_diff, g_spec, od, os, a_pos, a_nrm, a_kd, a_ks, -1.0f, kk);
         if (!BWD) {
-            A.ray_dk[r] = make_float4(dir.x, dir.y, dir.z, kk);
+            // k >= 0: its sign bit tells the trace kernel that the ray is dead (contribution exactly zero) without the 24-byte record
+            const bool live = (od.x != 0.f) | (od.y != 0.f) | (od.z != 0.f) | (os.x != 0.f) | (os.y != 0.f) | (os.z != 0.f);
+            A.ray_dk[r] = make_float4(dir.x, dir.y, dir.z, live ? kk : -kk);
             float* rc = A.ray_contrib + 6 * r;
             rc[0] = od.x; rc[1] = od.y; rc[2] = od.z; rc[3] = os.x; rc[4] = os.y; rc[5] = os.z;
         }
@@ -537,7 +539,9 @@ __global__ void __launch_bounds__(256, BWD ? 1 : GS_SAMPLES_WAVES) k_shade_sampl
         r = r0 + S + i;
         eval_sample<BWD>(A, c, dir, pdf_light + pdf_b, sample_frac, BWD ? vis_of(A, r) : 0.f, g_diff, g_spec, od, os, a_pos, a_nrm, a_kd, a_ks, -1.0f, kk);
         if (!BWD) {
-            A.ray_dk[r] = make_float4(dir.x, dir.y, dir.z, kk);
+            // k >= 0: its sign bit tells the trace kernel that the ray is dead (contribution exactly zero) without the 24-byte record
+            const bool live = (od.x != 0.f) | (od.y != 0.f) | (od.z != 0.f) | (os.x != 0.f) | (os.y != 0.f) | (os.z != 0.f);
+            A.ray_dk[r] = make_float4(dir.x, dir.y, dir.z, live ? kk : -kk);
             float* rc = A.ray_contrib + 6 * r;
             rc[0] = od.x; rc[1] = od.y; rc[2] = od.z; rc[3] = os.x; rc[4] = os.y; rc[5] = os.z;
         }
@@ -595,7 +599,8 @@ __global__ void __launch_bounds__(256, GS_GRAD_WAVES) k_shade_grad(ShadeArgs A) 
 #pragma unroll 1
             for (int which = 0; which < 2; ++which) {
                 const int64_t r = r0 + which * S + i;
-                const float4 dk = A.ray_dk[r];
+                float4 dk = A.ray_dk[r];
+                dk.w = fabsf(dk.w);                                  // the sign bit is the trace kernel's "dead ray" flag
                 const float vis = vis_of(A, r);
                 float4 rec = make_float4(0.f, 0.f, 0.f, __uint_as_float(LG_NONE));
                 if (dk.w * vis != 0.f) {
@@ -762,12 +767,11 @@ __global__ void __launch_bounds__(256) k_shade_trace(ShadeArgs A, int64_t n_rays
             float o0 = 0.f, o1 = 0.f, o2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
             if (i < chunk_n && any_tris) {
                 const int64_t r = chunk0 + i;
-                const float* rc = A.ray_contrib + 6 * r;
-                live = (rc[0] != 0.f) | (rc[1] != 0.f) | (rc[2] != 0.f) | (rc[3] != 0.f) | (rc[4] != 0.f) | (rc[5] != 0.f);
+                const float4 d = A.ray_dk[r];
+                live = !(__float_as_uint(d.w) >> 31);              // sign bit of k = dead ray (k_shade_samples)
                 if (live) {
                     const int64_t gid = A.pix[r / rays_per_pixel];
                     const float* o = A.ro + 3 * gid;
-                    const float4 d = A.ray_dk[r];
                     o0 = o[0]; o1 = o[1]; o2 = o[2]; d0 = d.x; d1 = d.y; d2 = d.z;
                     live = (d0 == d0 && d1 == d1 && d2 == d2) && !(d0 == 0.f && d1 == 0.f && d2 == 0.f);
                 }
