@@ -165,14 +165,10 @@ __device__ __forceinline__ float tonemap(float x, int tm) {
     float c = fminf(fmaxf(x, 0.0f), 65535.0f);
     return tm == TM_LOG_SRGB ? fwd_srgb(logf(c + 1.0f)) : c;
 }
-// d tonemap(x) / dx * d   (torch semantics: the clamp passes gradient on the closed interval for 'none';
-// the reference CUDA kernel zeroes it outside the OPEN interval for log_srgb, loss.cu:50-66)
-__device__ __forceinline__ float tonemap_bwd(float x, int tm, float d) {
-    if (tm == TM_LOG_SRGB) {
-        if (!(x > 0.0f && x < 65535.0f)) return 0.0f;
-        return bwd_srgb(logf(x + 1.0f), d) * (1.0f / (x + 1.0f));
-    }
-    return (x >= 0.0f && x <= 65535.0f) ? d : 0.0f;
+// Chain rule through the log-sRGB tonemapper exactly as bwdTonemapLogSRGB does it (loss.cu:50-67): only on the OPEN interval.
+__device__ __forceinline__ float tonemap_log_srgb_bwd(float x, float d) {
+    if (!(x > 0.0f && x < 65535.0f)) return 0.0f;
+    return bwd_srgb(logf(x + 1.0f), d) * (1.0f / (x + 1.0f));
 }
 __device__ __forceinline__ float sgnf(float x) { return x == 0.0f ? 0.0f : (x < 0.0f ? -1.0f : 1.0f); }
 
@@ -208,6 +204,27 @@ __device__ __forceinline__ void loss_bwd(float a, float b, int loss, float d, fl
     }
 }
 
+// d loss / d (img, target) of one element as imgLossBwdKernel computes it (loss.cu:137-209) -- which is NOT the derivative of the
+// forward kernel outside (0, 65535): the loss derivative is re-evaluated on the UNCLAMPED inputs (tonemapped without the
+// forward's clamp, :157-163), the log-sRGB chain rule applies on the open interval only, and finally an input that is itself
+// <= 0 or >= 65535 gets a zero gradient (:197-202) while the OTHER input keeps the derivative formed from the unclamped pair.
+// Pinned by tests/golden/ref_image_loss.npz (the reference kernel compiled for the host).
+__device__ __forceinline__ void image_loss_bwd_elem(float x, float y, int loss, int tm, float d, float& gx, float& gy) {
+    float a = x, b = y;
+    if (tm == TM_LOG_SRGB) {
+        a = fwd_srgb(logf(x + 1.0f));
+        b = fwd_srgb(logf(y + 1.0f));
+    }
+    float da, db;
+    loss_bwd(a, b, loss, d, da, db);
+    if (tm == TM_LOG_SRGB) {
+        da = tonemap_log_srgb_bwd(x, da);
+        db = tonemap_log_srgb_bwd(y, db);
+    }
+    gx = (x <= 0.0f || x >= 65535.0f) ? 0.0f : da;
+    gy = (y <= 0.0f || y >= 65535.0f) ? 0.0f : db;
+}
+
 // partial[blockIdx] = sum over the block's elements (wave64 shuffle reduction, then 4 waves through LDS)
 __global__ void __launch_bounds__(256) k_image_loss_fwd(const float* __restrict__ img, const float* __restrict__ target, int64_t n, int loss,
                                                         int tm, float* __restrict__ partial) {
@@ -232,9 +249,9 @@ __global__ void __launch_bounds__(256) k_image_loss_bwd(const float* __restrict_
     float d = g_scalar[0] * scale;
     float x = img[i], y = target[i];
     float da, db;
-    loss_bwd(tonemap(x, tm), tonemap(y, tm), loss, d, da, db);
-    if (g_img) g_img[i] = tonemap_bwd(x, tm, da);
-    if (g_target) g_target[i] = tonemap_bwd(y, tm, db);
+    image_loss_bwd_elem(x, y, loss, tm, d, da, db);
+    if (g_img) g_img[i] = da;
+    if (g_target) g_target[i] = db;
 }
 
 // ---- softplus with first and second derivative -------------------------------------------------------------
@@ -330,8 +347,8 @@ __global__ void __launch_bounds__(256) k_frame_sums(const float* __restrict__ st
                     acc[FS_IMG] += loss_fwd(tx, ty, img_loss);
                     if (BWD) {
                         float da, db;
-                        loss_bwd(tx, ty, img_loss, g9[FS_IMG], da, db);
-                        g[o.shaded + c] = tonemap_bwd(x, img_tm, da) * m;
+                        image_loss_bwd_elem(x, y, img_loss, img_tm, g9[FS_IMG], da, db);
+                        g[o.shaded + c] = da * m;
                     }
                 }
             }

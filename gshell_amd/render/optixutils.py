@@ -176,6 +176,38 @@ def optix_env_shade(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, 
                                        n_samples_x, rnd_seed, shadow_scale, (int(view_offset), int(view_stride)))
 
 
+def optix_env_shade_samples(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, BSDF='pbr', n_samples_x=8,
+                            rnd_seed=0, shadow_scale=1.0, view_offset=0, view_stride=1):
+    """Diagnostics: the forward pass's per-sample records, for comparing sample by sample with the reference's raygen loop
+    (kernel.cu:488-529).  -> pix [n_cov] (linear index of the covered pixels), dirs [n_cov, 2, S, 3] (0: light samples, 1: BSDF
+    samples), k [n_cov, 2, S] (MIS weight x sample weight = 1 / max(pdf_light + pdf_bsdf, 1e-4) / n^2), live [n_cov, 2, S] (False:
+    the unshadowed contribution is exactly zero and the ray was not traced), visible [n_cov, 2, S] (the cached shadow-ray bit)."""
+    L = _lib.lib()
+    B, H, W, _ = gb_pos.shape
+    dev = gb_pos.device
+    full = (B, H, W, 3)
+
+    def c3(t):
+        return t.detach().expand(full).contiguous().float()
+    pix = torch.nonzero(mask.detach().expand(B, H, W).reshape(-1) > 0).reshape(-1).int()
+    t = dict(ro=c3(ro), pos=c3(gb_pos), nrm=c3(gb_normal), kd=c3(gb_kd), ks=c3(gb_ks))
+    view = gb_view_pos.detach().expand(B, 1, 1, 3).reshape(B, 3).contiguous().float()
+    lgt, t_pdf, t_rows, t_cols = (x.detach().contiguous().float() for x in (light, pdf, rows, cols))
+    perms = random_perm(n_samples_x, dev)
+    S = n_samples_x * n_samples_x
+    n_cov = int(pix.shape[0])
+    vis = torch.zeros((int(L.gs_env_shade_vis_words(c_int64(n_cov), c_int(n_samples_x))),), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        scratch = _optix_env_shade_func._launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, _BSDF_IDS.index(BSDF), n_samples_x,
+                                                    int(rnd_seed), shadow_scale, (B, H, W), vis, None, None, (int(view_offset), int(view_stride)))
+    dk = scratch.view(torch.float32)[: n_cov * 2 * S * 4].reshape(n_cov, 2, S, 4)
+    bits = (vis[:, None] >> torch.arange(64, device=dev)[None, :]) & 1
+    visible = bits.reshape(-1)[: n_cov * 2 * S].reshape(n_cov, 2, S).bool()
+    w = dk[..., 3]
+    live = ~torch.signbit(w)
+    return pix, dk[..., :3].clone(), w.abs(), live, visible
+
+
 class _bilateral_denoiser_func(torch.autograd.Function):
     @staticmethod
     def forward(ctx, col, nrm, zdz, sigma, mask=None):

@@ -132,3 +132,46 @@ def sdf_reg_loss(sdf, all_edges):
     pair = pair[mask]
     bce = torch.nn.functional.binary_cross_entropy_with_logits
     return bce(pair[..., 0], (pair[..., 1] > 0).float()) + bce(pair[..., 1], (pair[..., 0] > 0).float())
+
+
+def image_loss_kernel_backward(img, target, loss='l1', tonemapper='none', d_scalar=1.0):
+    """Gradient of `ru.image_loss` as the reference's CUDA backward kernel computes it (c_src/loss.cu:137-209), which is NOT
+    the autograd of its forward outside (0, 65535): the kernel re-evaluates the tonemap / loss derivative on the UNCLAMPED
+    inputs (:157-163), applies the log-sRGB chain rule only where 0 < x < 65535 (:50-67) and finally zeroes the gradient of an
+    input that is itself <= 0 or >= 65535 (:197-202) -- the OTHER input still receives the unclamped-value derivative.
+    d_out per pixel = d_scalar / (B*H*W) (renderutils/ops.py:497).  Pinned by tests/golden/ref_image_loss.npz."""
+    B, H, W, _ = img.shape
+    d_v = torch.full_like(img, d_scalar / (B * H * W)) / 3.0
+
+    def srgb(x):
+        return torch.where(x > 0.0031308, torch.pow(torch.clamp(x, min=0.0031308), 1.0 / 2.4) * 1.055 - 0.055, 12.92 * torch.clamp(x, min=0.0))
+
+    def d_srgb(x):   # bwdSRGB (:33-39)
+        return torch.where(x > 0.0031308, 0.439583 / torch.pow(torch.clamp(x, min=1e-30), 0.583333), torch.where(x > 0.0, torch.full_like(x, 12.92), torch.zeros_like(x)))
+    a, b = img, target
+    if tonemapper == 'log_srgb':
+        a, b = srgb(torch.log(img + 1.0)), srgb(torch.log(target + 1.0))      # NaN for x <= -1: masked out below like the kernel's `if`
+    if loss == 'mse':
+        d_a = d_v * 2 * (a - b)
+        d_b = -d_a
+    elif loss == 'relmse':
+        den = b * b + a * a + 0.1
+        d_a = d_v * 2 * (a - b) * (b * (b + a) + 0.1) / (den * den)
+        d_b = -(d_v * 2 * (a - b) * (a * (b + a) + 0.1) / (den * den))
+    elif loss == 'smape':
+        den = b + a + 0.01
+        sg = torch.sign(a - b)
+        d_a = d_v * sg * (2 * b + 0.01) / (den * den)
+        d_b = -(d_v * sg * (2 * a + 0.01) / (den * den))
+    else:
+        d_a = d_v * torch.sign(a - b)
+        d_b = -d_a
+    if tonemapper == 'log_srgb':
+        def chain(x, d):
+            ok = (x > 0) & (x < 65535)
+            xs = torch.where(ok, x, torch.ones_like(x))
+            return torch.where(ok, d * d_srgb(torch.log(xs + 1.0)) / (xs + 1.0), torch.zeros_like(x))
+        d_a, d_b = chain(img, d_a), chain(target, d_b)
+    d_a = torch.where((img <= 0) | (img >= 65535), torch.zeros_like(d_a), d_a)
+    d_b = torch.where((target <= 0) | (target >= 65535), torch.zeros_like(d_b), d_b)
+    return d_a, d_b

@@ -58,3 +58,26 @@ def grid_sheet(n, seed=0, amp=0.15, size=1.2):
     a, b, c, d = idx[:-1, :-1], idx[1:, :-1], idx[1:, 1:], idx[:-1, 1:]
     tri = np.concatenate([np.stack([a, b, c], -1).reshape(-1, 3), np.stack([a, c, d], -1).reshape(-1, 3)]).astype(np.int32)
     return verts, tri
+
+
+def sheet_gbuffer(B, H, W, seed, n_sheet=12):
+    """g-buffer of a wavy sheet seen by `B` orbit cameras, rendered with the CPU oracle rasteriser (independent of the HIP
+    rasteriser): -> verts, tri, mask [B,H,W], gb_pos, gb_nrm [B,H,W,3], view [B,1,1,3], kd, ks [B,H,W,3] (torch, float32)."""
+    import torch
+    from oracle import pixel_oracle as po
+    from oracle import raster_oracle as ro
+    verts, tri = grid_sheet(n_sheet, seed)
+    mvp, cam = orbit_views(B, first=seed)
+    pos_clip = ro.xfm_points(torch.tensor(verts)[None], torch.tensor(mvp))
+    tri_l = torch.tensor(tri).long()
+    ids = torch.tensor(ro.rasterize_ids(pos_clip.numpy(), tri, H, W))
+    rast, _ = ro.rast_from_ids(pos_clip, tri_l, ids)
+    gb_pos = ro.interpolate(torch.tensor(verts)[None], rast, tri_l)
+    nrm_v = po.auto_normals(torch.tensor(verts), tri_l)
+    gb_nrm = ro.interpolate(nrm_v[None], rast, tri_l)
+    gen = torch.Generator().manual_seed(seed)
+    kd = torch.rand(B, H, W, 3, generator=gen)
+    ks = torch.rand(B, H, W, 3, generator=gen) * torch.tensor([0.3, 1.0, 1.0])
+    mask = (ids >= 0).float()
+    view = torch.tensor(cam)[:, None, None, :]
+    return verts, tri, mask, gb_pos, gb_nrm, view, kd, ks
