@@ -7,9 +7,10 @@ return tuple (gshell_tets.py:245, :426-443) but runs as hand-written HIP kernels
     (verts_aug, faces_aug, None, None, v_tng_aug, extra)
 
 Differences that are deliberate (documented in DESIGN.md):
-  * v_tng_aug / extra['v_tng_watertight'] are computed (forward parity) but carry no
-    gradient; the reference's training path discards them
-    (gshell_tets_geometry.py:206-208, render.py:264-267).
+  * v_tng_aug / extra['v_tng_watertight'] are computed (forward parity); their gradient
+    (compute_tangents, gshell_tets.py:40-78) is NOT implemented and back-propagating through
+    them RAISES (_TangentGradGuard) instead of silently dropping it.  The reference's training
+    path discards the tangents (gshell_tets_geometry.py:206-208, render.py:264-267).
   * faces are additionally available as int32 (`extra['faces_i32']`) for the rasteriser.
 """
 import ctypes
@@ -142,6 +143,20 @@ class _MarchingTetsFn(torch.autograd.Function):
         return g_pos.reshape(ps), g_sdf.reshape(ss), g_msdf.reshape(ms), None, None, None
 
 
+class _TangentGradGuard(torch.autograd.Function):
+    """Identity on the tangents, with an autograd edge to the vertices they were computed from: a loss that consumes
+    v_tng_aug reaches this node in its backward pass and gets an error, not a silently missing term."""
+
+    @staticmethod
+    def forward(ctx, v_tng, verts_aug):
+        return v_tng.view_as(v_tng)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise _lib.GShellHipError("the gradient of v_tng_aug / v_tng_watertight (compute_tangents, reference geometry/gshell_tets.py:40-78) is not "
+                                  "implemented in the HIP path; the reference's training path never consumes it")
+
+
 class GShell_Tets:
     """Same call surface as the reference class (gshell_tets.py:80, :245)."""
 
@@ -171,6 +186,8 @@ class GShell_Tets:
         verts_aug, msdf_aug, verts_wt, faces_aug, faces_wt, faces_i32, v_tng_aug, tet_id = _MarchingTetsFn.apply(
             pos_nx3, sdf_n, msdf_n, topo, self.compute_tangents, presigned)
         V = verts_wt.shape[0]
+        if verts_aug.requires_grad:
+            v_tng_aug = _TangentGradGuard.apply(v_tng_aug, verts_aug)
         extra = {
             'n_verts_watertight': V,
             'vertices_watertight': verts_wt,

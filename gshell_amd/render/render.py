@@ -139,7 +139,6 @@ class _ShadeAssembleFn(torch.autograd.Function):
             check(_lib.lib().gs_shade_assemble_bwd(*[ptr(x) for x in t[:11]], c_int(cw), ptr(t[11]), c_int64(B), c_int64(H), c_int64(W), ptr(g), ptr(g_tex),
                                                    ptr(g_texj), ptr(g_nin), ptr(g_njit), ptr(g_nsh), ptr(g_ngeo), ptr(g_dif), ptr(g_spc), ptr(g_msdf), stream()),
                   "gs_shade_assemble_bwd")
-        ctx.t = None
         return None, g_tex, g_texj, g_nin, g_njit, None, g_nsh, g_ngeo, None, g_dif, g_spc, g_msdf, None
 
 

@@ -76,9 +76,10 @@ def extract(x, s, nu, cubes, res, beta=None, alpha=None, gamma=None, topo=None, 
     surf = (cnt > 0) & (cnt < 8)
     if int(surf.sum()) == 0:
         return torch.zeros((0, 3)), torch.zeros((0, 3), dtype=torch.long), torch.zeros((0,))
-    beta = torch.ones(F, 12) if beta is None else torch.tanh(beta) * weight_scale + 1
-    alpha = torch.ones(F, 8) if alpha is None else torch.tanh(alpha) * weight_scale + 1
-    gamma = torch.ones(F) if gamma is None else torch.sigmoid(gamma) * weight_scale + (1 - weight_scale) / 2
+    dt = x.dtype
+    beta = torch.ones(F, 12, dtype=dt) if beta is None else torch.tanh(beta) * weight_scale + 1
+    alpha = torch.ones(F, 8, dtype=dt) if alpha is None else torch.tanh(alpha) * weight_scale + 1
+    gamma = torch.ones(F, dtype=dt) if gamma is None else torch.sigmoid(gamma) * weight_scale + (1 - weight_scale) / 2
 
     # ---- case ids with the C16/C19 ambiguity fix-up (:266-306)
     case_raw = (occ8.long() * (2 ** torch.arange(8))).sum(-1)
@@ -125,17 +126,17 @@ def extract(x, s, nu, cubes, res, beta=None, alpha=None, gamma=None, topo=None, 
     nu_e = _interp(ca, cb, nu1[a_id, None], nu1[b_id, None])
     nu_e_sv = _interp(ca.detach(), cb.detach(), nu1[a_id, None], nu1[b_id, None])
     bt = beta[ent_cube, ent_e][:, None]
-    beta_sum = torch.zeros(n_vd, 1).index_add(0, ent_vd, bt)
-    vd = torch.zeros(n_vd, 3).index_add(0, ent_vd, ue * bt) / beta_sum
-    nu_d = torch.zeros(n_vd, 1).index_add(0, ent_vd, nu_e * bt) / beta_sum
+    beta_sum = torch.zeros(n_vd, 1, dtype=dt).index_add(0, ent_vd, bt)
+    vd = torch.zeros(n_vd, 3, dtype=dt).index_add(0, ent_vd, ue * bt) / beta_sum
+    nu_d = torch.zeros(n_vd, 1, dtype=dt).index_add(0, ent_vd, nu_e * bt) / beta_sum
     nu_d = nu_d.index_add(0, ent_vd, nu_e_sv * bt.detach())               # the reference's in-place quirk (:476-477)
     nu_d_sv = nu_d / beta_sum.detach()
     zc = _interp(s1[a_id, None], s1[b_id, None], x[a_id], x[b_id])        # un-weighted zero crossing of each entry's edge
     dist = (zc - vd[ent_vd]).norm(dim=-1)
-    n_edges = torch.zeros(n_vd).index_add(0, ent_vd, torch.ones_like(dist))
-    mean_l2 = torch.zeros(n_vd).index_add(0, ent_vd, dist) / n_edges
+    n_edges = torch.zeros(n_vd, dtype=dt).index_add(0, ent_vd, torch.ones_like(dist))
+    mean_l2 = torch.zeros(n_vd, dtype=dt).index_add(0, ent_vd, dist) / n_edges
     L_dev = (dist - mean_l2[ent_vd]).abs()
-    vd_gamma = torch.zeros(n_vd).index_put((ent_vd,), gamma[ent_cube])
+    vd_gamma = torch.zeros(n_vd, dtype=dt).index_put((ent_vd,), gamma[ent_cube])
     vd_idx_map = torch.full((F, 12), -1, dtype=torch.long)
     vd_idx_map[ent_cube, ent_e] = ent_vd
 
@@ -175,4 +176,17 @@ def extract(x, s, nu, cubes, res, beta=None, alpha=None, gamma=None, topo=None, 
     faces_open = torch.cat([uncut, torch.gather(idx_map[one], 1, CUT_CFG[cfg[one]][:, :3]).reshape(-1, 3),
                             torch.gather(idx_map[two], 1, CUT_CFG[cfg[two]][:, :6]).reshape(-1, 3)])
     extra.update(msdf=nus_open, msdf_boundary=bnu)
+    with torch.no_grad():
+        # Forward-error scale of each boundary vertex (a length; multiply by a few float32 eps).  x = x_a + w (x_b - x_a) with
+        # w = nu_a / (nu_a - nu_b); nu_d of a dual vertex is a sum over its <= 7 entries (twice: the index_add_ quirk), exact only
+        # to eps * A with A = sum |nu_e beta| (1 + 1 / sum beta) -- far more than eps |nu_d| when the terms cancel.  So
+        #   |dx| <~ eps |x_a - x_b| (|nu_b| A_a + |nu_a| A_b) / (nu_b - nu_a)^2.
+        # Large (i) on edges whose end points lie on the SAME side of the cut (every edge of a cut triangle gets a vertex; those
+        # extrapolate and no face references them) and (ii) where both values are noise around zero.
+        A = torch.zeros(n_vd, 1, dtype=dt).index_add(0, ent_vd, (nu_e_sv * bt).abs().detach())
+        A = (A * (1.0 + 1.0 / beta_sum.detach())).reshape(-1)
+        wa, wb = nu_d[pa].reshape(-1), nu_d[pb].reshape(-1)
+        den2 = (wb - wa) ** 2
+        amp = torch.where(den2 > 0, (wb.abs() * A[pa] + wa.abs() * A[pb]) / den2.clamp_min(1e-38), torch.zeros_like(den2))
+        extra["boundary_cond"] = amp * (vd[pa] - vd[pb]).norm(dim=-1)
     return verts_open, faces_open, L_dev, extra

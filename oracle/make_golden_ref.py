@@ -2,7 +2,8 @@
 
     make -C oracle && python -m oracle.make_golden_ref
 
-  tests/golden/ref_envshade_{pbr,diffuse,white}_n{1,4,8}.npz   kernel.cu raygen, forward + the five gradients of backward = 1,
+  tests/golden/ref_envshade_{pbr,diffuse,white}_n{1,4,8}.npz,  ref_envshade_pbr_n8_64x64.npz
+                                                                kernel.cu raygen, forward + the five gradients of backward = 1,
                                                                 + the per-sample record (direction, pdf_light, pdf_bsdf, visible)
                                                                 of every covered pixel (ref_env_shade_trace_pixel)
   tests/golden/ref_image_loss.npz                               loss.cu: {l1,mse,smape,relmse} x {none,log_srgb}, value + both gradients
@@ -27,11 +28,11 @@ ENVSHADE_CASES = [(b, n) for b in BSDFS for n in (1, 4, 8)]
 PERM_ROWS = 64
 
 
-def envshade_case(bsdf, n):
+def envshade_case(bsdf, n, frame=None, probe=None):
     """Inputs of one env-shade golden (deterministic).  -> dict of numpy arrays + scalars."""
     big = n == 8
-    B, H, W = (1, 20, 20) if big else (2, 20, 20)
-    probe = (32, 64) if big else (16, 32)
+    B, H, W = frame or ((1, 20, 20) if big else (2, 20, 20))
+    probe = probe or ((32, 64) if big else (16, 32))
     seed_scene = 3 + BSDFS.index(bsdf)
     verts, tri, mask, gb_pos, gb_nrm, view, kd, ks = scenes.sheet_gbuffer(B, H, W, seed_scene)
     gen = torch.Generator().manual_seed(9 + n)
@@ -152,6 +153,8 @@ def all_goldens():
     for bsdf, n in ENVSHADE_CASES:
         d = envshade_case(bsdf, n)
         files[f"ref_envshade_{bsdf}_n{n}.npz"] = {**d, **run_envshade(d)}
+    d = envshade_case("pbr", 8, frame=(1, 64, 64), probe=(64, 128))      # the benchmarked sample count on a larger frame and a finer probe
+    files["ref_envshade_pbr_n8_64x64.npz"] = {**d, **run_envshade(d)}
     img, tgt = image_loss_case()
     files["ref_image_loss.npz"] = dict(img=img, target=tgt, **run_image_loss(img, tgt))
     t = shading_normal_case()

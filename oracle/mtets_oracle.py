@@ -161,8 +161,12 @@ def extract(pos, sdf, msdf, tets, topo=None, with_tangents=True):
     }
 
 
-def _tangents(verts, faces, tet1, tet2, F):
+def _tangents(verts, faces, tet1, tet2, F, return_cond=False):
     """Smooth normals + uv tangents of the watertight mesh (ref :9-78, :210-239, :301-319).
+    return_cond: also the per-vertex condition number of the result w.r.t. the ORDER of the two scatter sums (the reference
+    accumulates them with scatter_add_, i.e. float atomics in arbitrary order on a GPU): (sum m(t_f) / |sum t_f| + sum m(n_f) /
+    |sum n_f|) / |t - (t.n) n|, m() = the magnitude of a term including its own rounding -- the factor by which float32 round-off
+    of the terms and of the partial sums is amplified in the unit tangent (infinite where every face at the vertex is degenerate).
 
     Reference quirk (ref :319): compute_tangents is called with t_tex_idx = faces, so
     the uv of mesh vertex v is entry v of the atlas table built by map_uv, i.e. corner
@@ -205,7 +209,25 @@ def _tangents(verts, faces, tet1, tet2, F):
     def nz(x):
         return x / torch.sqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=1e-20))
     t = nz(t)
-    return nz(t - (t * nrm).sum(-1, keepdim=True) * nrm)
+    out = nz(t - (t * nrm).sum(-1, keepdim=True) * nrm)
+    if not return_cond:
+        return out
+    with torch.no_grad():
+        # magnitudes of what is summed, INCLUDING the rounding of each term: a face normal e1 x e2 is exact only to eps |e1| |e2|
+        # (a degenerate face leaves a residue of that size whose sign depends on whether the products were contracted to fma --
+        # torch does on the CPU and on CUDA, numpy and -ffp-contract=off code do not), a face tangent to eps (|q1| |e2y| + |q2| |e1y|) / |den|
+        den_c = torch.where(den > 0.0, torch.clamp(den, min=1e-6), torch.clamp(den, max=-1e-6)).abs().reshape(-1)
+        m_t = (q1.norm(dim=-1) * e2[:, 1].abs() + q2.norm(dim=-1) * e1[:, 1].abs()) / den_c
+        m_n = q1.norm(dim=-1) * q2.norm(dim=-1)
+        a_t, a_n, s_n = torch.zeros(verts.shape[0]), torch.zeros(verts.shape[0]), torch.zeros_like(verts)
+        for idx in (i0, i1, i2):
+            a_t = a_t.index_add(0, idx, m_t)
+            a_n = a_n.index_add(0, idx, m_n)
+            s_n = s_n.index_add(0, idx, fn)
+        tiny = 1e-30
+        perp = (t - (t * nrm).sum(-1, keepdim=True) * nrm).norm(dim=-1)
+        cond = (a_t / tsum.norm(dim=-1).clamp_min(tiny) + a_n / s_n.norm(dim=-1).clamp_min(tiny)) / perp.clamp_min(tiny)
+    return out, cond
 
 
 def extract_from_auggrid(pos, sdf, tets, verts_disc, coeff_grid, msdf_grid, occgrid, topo=None, with_tangents=True):

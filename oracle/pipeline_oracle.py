@@ -45,7 +45,8 @@ def render_mesh(v_pos, faces, v_nrm, msdf, mvp, campos, light, background, noise
     B = mvp.shape[0]
     tri_np = faces.numpy().astype(np.int32)
     v_pos_clip = ro.xfm_points(v_pos[None], mvp)
-    ids = torch.tensor(ro.rasterize_ids(v_pos_clip.detach().numpy(), tri_np, H, W))
+    # discrete decisions (coverage, sample placement) are always made from float32 values, whatever dtype the floats run in
+    ids = torch.tensor(ro.rasterize_ids(ro.xfm_points(v_pos.detach().float()[None], mvp.float()).numpy(), tri_np, H, W))
     rast, rast_db = ro.rast_from_ids(v_pos_clip, faces, ids)
     visible = torch.unique(ids[ids >= 0])
     gb_pos = ro.interpolate(v_pos[None], rast, faces)
@@ -65,7 +66,7 @@ def render_mesh(v_pos, faces, v_nrm, msdf, mvp, campos, light, background, noise
     view_pos = campos[:, None, None, :]
     # ---- shade
     jitter = po.pixel_grid(W, H)[None] + noise['jitter']
-    mask = (rast[..., -1:] > 0).float()
+    mask = (rast[..., -1:] > 0).to(rast.dtype)
     grad_weight = mask * po.texture_linear_clamp(mask, jitter)
     all_jit = texture.sample(gb_pos + noise['texture'])
     all_tex = texture.sample(gb_pos)

@@ -121,6 +121,7 @@ def update_pdf(base):
 
 def texture_linear_clamp(tex, uv):
     """tex [B,H,W,C], uv [B,h,w,2] in [0,1] -> [B,h,w,C]."""
+    uv = uv.to(tex.dtype)
     out = torch.nn.functional.grid_sample(tex.permute(0, 3, 1, 2), uv * 2 - 1, mode='bilinear', padding_mode='border', align_corners=False)
     return out.permute(0, 2, 3, 1)
 

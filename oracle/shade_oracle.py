@@ -314,8 +314,9 @@ def env_shade(mask, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, r
     m = (mask.reshape(-1) > 0)
     pix = torch.nonzero(m).reshape(-1)
     P = pix.numel()
-    diff = torch.zeros(B * H * W, 3)
-    spec = torch.zeros(B * H * W, 3)
+    dt = gb_pos.dtype
+    diff = torch.zeros(B * H * W, 3, dtype=dt)
+    spec = torch.zeros(B * H * W, 3, dtype=dt)
     if P == 0:
         return diff.reshape(B, H, W, 3), spec.reshape(B, H, W, 3)
 
@@ -356,7 +357,7 @@ def env_shade(mask, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, r
     alpha_t = (ks[:, 1:2] * ks[:, 1:2])
     wo_t = t_safe_normalize(view - pos)
     Hl, Wl = npdf.shape
-    acc_d, acc_s = torch.zeros(P, 3), torch.zeros(P, 3)
+    acc_d, acc_s = torch.zeros(P, 3, dtype=dt), torch.zeros(P, 3, dtype=dt)
 
     def process(dirs, pdf_sum):
         u, v = _dir_to_tc(dirs)

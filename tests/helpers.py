@@ -31,3 +31,28 @@ def auggrid_inputs(g):
     G = int(vdisc.max()) + 1
     coeff, mgrid, occ = fields.make_aug_grids(G, seed, str(g["msdf_kind"]))
     return pos.astype(np.float32), tets.numpy(), sdf, vdisc, coeff, mgrid, occ
+
+
+def assert_tangents_match(out_tng, ref_tng, verts_wt, faces_wt, F, what="tangents"):
+    """v_tng_aug [V_aug,3] of the HIP path vs the reference's (compute_tangents, gshell_tets.py:40-78).  Both sides accumulate the
+    per-face tangents and normals with float atomics (the reference: scatter_add_ on CUDA), so the unit tangents agree up to the
+    summation order, amplified by each vertex's condition number.  No outlier quota:
+      * watertight vertex v: every component within 1e-4 + 2e-6 * cond(v)  (cond from oracle/mtets_oracle._tangents: ~2..5 for
+        ordinary vertices, 1e3+ where sliver triangles nearly cancel; 2e-6 = 32 ulp of float32),
+      * boundary vertices are convex combinations of two watertight tangents with bit-identical weights, so their worst error
+        cannot exceed the worst watertight error."""
+    import torch
+    from oracle import mtets_oracle
+    V = verts_wt.shape[0]
+    err = np.abs(np.asarray(out_tng, np.float64) - np.asarray(ref_tng, np.float64))
+    if V == 0:
+        assert err.size == 0 or err.max() == 0
+        return
+    _, cond = mtets_oracle._tangents(torch.tensor(np.asarray(verts_wt)), torch.tensor(np.asarray(faces_wt)).long(), None, None, F, return_cond=True)
+    tol = 1e-4 + 2e-6 * cond.numpy().astype(np.float64)
+    bad = err[:V].max(-1) > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {V} watertight vertices outside 1e-4 + 2e-6 cond; worst {float((err[:V].max(-1) / tol).max()):.2f} x its bound"
+    if err.shape[0] > V:
+        assert err[V:].max() <= err[:V].max() + 1e-6, f"{what}: boundary tangents differ by {err[V:].max():.3e} > watertight {err[:V].max():.3e}"
+    n_ill = int((tol > 2e-4).sum())
+    return dict(vertices=int(V), ill_conditioned=n_ill, outside_1e4=int((err[:V].max(-1) > 1e-4).sum()))

@@ -35,12 +35,12 @@ def test_goldens_are_what_the_reference_build_produces():
             np.testing.assert_array_equal(np.asarray(v), g[k], err_msg=f"{name}:{k}")
 
 
-@pytest.mark.parametrize("bsdf,n", mg.ENVSHADE_CASES)
-def test_env_shade_restatement_equals_the_reference_kernel(bsdf, n):
+@pytest.mark.parametrize("bsdf,n,suffix", [(b, n, "") for b, n in mg.ENVSHADE_CASES] + [("pbr", 8, "_64x64")])
+def test_env_shade_restatement_equals_the_reference_kernel(bsdf, n, suffix):
     """oracle/shade_oracle.env_shade (numpy sampling + torch autograd) vs kernel.cu compiled for the host: EVERY pixel of the
     forward outputs and of the five gradients within 1e-4 of the tensor's maximum.  The two sides share libm / numpy float
     arithmetic up to association, so no discrete decision flips on these inputs -- any outlier is a restatement bug."""
-    g = _load(f"ref_envshade_{bsdf}_n{n}.npz")
+    g = _load(f"ref_envshade_{bsdf}_n{n}{suffix}.npz")
     t = {k: torch.tensor(g[k]) for k in ("mask", "ro", "gb_pos", "gb_normal", "view_pos", "gb_kd", "gb_ks", "light", "pdf", "rows", "cols")}
     leaves = [t[k].clone().requires_grad_(True) for k in ("gb_pos", "gb_normal", "gb_kd", "gb_ks", "light")]
     d, s = so.env_shade(t["mask"], t["ro"], leaves[0], leaves[1], t["view_pos"], leaves[2], leaves[3], leaves[4], t["pdf"], t["rows"], t["cols"],

@@ -40,8 +40,17 @@ def _texel(d, Hl, Wl):
 
 @pytest.mark.parametrize("bsdf,n", [(b, n) for b in BSDFS for n in (1, 4, 8)])
 def test_env_shade_equals_the_reference_kernel_sample_by_sample(bsdf, n):
+    _compare_env_shade(_load(f"ref_envshade_{bsdf}_n{n}.npz"), f"{bsdf}_n{n}")
+
+
+def test_env_shade_equals_the_reference_kernel_at_64x64_n8():
+    """The benchmarked sample count (128 shadow rays per pixel and pass) on a 64 x 64 frame with a 64 x 128 probe."""
+    _compare_env_shade(_load("ref_envshade_pbr_n8_64x64.npz"), "pbr_n8_64x64")
+
+
+def _compare_env_shade(g, tag):
     from gshell_amd.render import optixutils as ou
-    g = _load(f"ref_envshade_{bsdf}_n{n}.npz")
+    bsdf, n = BSDFS[int(g["bsdf"])], int(g["n"])
     S = n * n
     t = {k: torch.tensor(g[k], device=DEV) for k in ("mask", "ro", "gb_pos", "gb_normal", "view_pos", "gb_kd", "gb_ks", "light", "pdf", "rows", "cols")}
     ctx = ou.OptiXContext()
@@ -114,7 +123,7 @@ def test_env_shade_equals_the_reference_kernel_sample_by_sample(bsdf, n):
         cause = "sample_moved" if moved[kk, w, i] else "pdf_branch_or_texel" if k_off[kk, w, i] else "shadow_ray" if vis_off[kk, w, i] else "probe_texel_border"
         listing.append(dict(pixel=int(pix[kk]), kind="light" if w == 0 else "bsdf", sample=int(i), cause=cause, dir_diff=float(dd[kk, w, i]),
                             k=float(k[kk, w, i]), k_ref=float(r_k[kk, w, i]), border_texels=float(border[kk, w, i])))
-    REPORT[f"{bsdf}_n{n}"] = dict(covered_pixels=int(len(pix)), samples=int(n_samples), flagged_samples=int(flagged.sum()), flagged_fraction=frac,
+    REPORT[tag] = dict(covered_pixels=int(len(pix)), samples=int(n_samples), flagged_samples=int(flagged.sum()), flagged_fraction=frac,
                                   pixels_with_flagged_sample=int(pix_flag.sum()), causes=causes, pixels_outside_tolerance=outside, flagged=listing)
     print(f"{bsdf} n={n}: {len(pix)} px, {n_samples} samples, flagged {int(flagged.sum())} ({frac:.2e}) {causes}; outside tol (all in flagged px): {outside}")
     assert frac <= 5e-3, (frac, causes)
@@ -183,3 +192,35 @@ def test_bilateral_equals_the_reference_kernel(sigma):
     np.testing.assert_allclose(out.detach().cpu().numpy(), r, rtol=1e-4, atol=1e-5 * np.abs(r).max())
     r = g[f"g_col_{sigma}"]
     np.testing.assert_allclose(col.grad.cpu().numpy(), r, rtol=1e-4, atol=1e-5 * np.abs(r).max())
+
+
+@pytest.mark.parametrize("sigma", [1.0, 2.0])
+def test_masked_and_paired_bilateral_equal_the_reference_kernel_where_consumed(sigma):
+    """the training path's entry points (gs_bilateral_*_masked2: two colour images, shared weights, tap loops only for consumed
+    pixels) against the reference kernels directly -- not against the product's own unmasked path"""
+    from gshell_amd.render import optixutils as ou
+    g = _load("ref_bilateral.npz")
+    B, H, W, _ = g["col"].shape
+    mask = torch.zeros(B, H, W, device=DEV)
+    mask[:, 2:-3, 3:-2] = 1.0
+    mask[0, 7, 9] = 0.0
+    col_a = torch.tensor(g["col"], device=DEV, requires_grad=True)
+    col_b = torch.tensor(g["col"], device=DEV, requires_grad=True)
+    nrm, zdz = torch.tensor(g["nrm"], device=DEV), torch.tensor(g["zdz"], device=DEV)
+    out_a, out_b = ou.bilateral_denoiser_raw_pair(col_a, col_b, nrm, zdz, sigma, mask)
+    m = mask.bool().cpu().numpy()
+    r = g[f"out_{sigma}"]
+    for o in (out_a, out_b):
+        np.testing.assert_allclose(o.detach().cpu().numpy()[m], r[m], rtol=1e-4, atol=1e-5 * np.abs(r).max())
+        assert (o.detach().cpu().numpy()[~m] == np.array([0, 0, 0, 1e-4], np.float32)).all()        # unconsumed pixels: not filtered
+    # backward: the gradient arrives only at consumed pixels (the composite multiplies the others by alpha = 0), so feed the
+    # reference kernel the same masked out_grad: its tap-dz adjoint (denoising.cu:74-130) is linear in out_grad
+    og = torch.tensor(g["out_grad"], device=DEV) * mask[..., None]
+    ((out_a * og).sum() + (out_b * og * 0.5).sum()).backward()
+    from oracle import refnative as rn
+    if rn.available("ref_denoise"):
+        ref_g = rn.bilateral_bwd(g["col"], g["nrm"], g["zdz"], sigma, og.cpu().numpy())
+        # ... and is produced only FOR consumed pixels: the radiance of an uncovered pixel has no producer to hand a gradient to
+        np.testing.assert_allclose(col_a.grad.cpu().numpy()[m], ref_g[m], rtol=1e-4, atol=1e-5 * np.abs(ref_g).max())
+        np.testing.assert_allclose(col_b.grad.cpu().numpy()[m], 0.5 * ref_g[m], rtol=1e-4, atol=1e-5 * np.abs(ref_g).max())
+        assert float(col_a.grad.cpu()[~torch.tensor(m)].abs().max()) == 0.0

@@ -10,13 +10,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _close_frac(a, b, rtol):
-    scale = b.abs().max().clamp(min=1e-12)
-    return float(((a - b).abs() <= rtol * b.abs() + rtol * scale).float().mean())
-
-
-@pytest.mark.parametrize("denoise", [False, True])
-def test_render_mesh_matches_pipeline_oracle(denoise):
+def render_both(denoise, tex_levels=16):
+    """-> product outputs (HIP), oracle outputs (CPU), and the leaf tensors of both sides (also used by tools/render_grad_diag.py).
+    tex_levels: hash-grid levels that carry texture (the finer ones are zeroed) -- see test_render_mesh_matches_pipeline_oracle."""
     from gshell_amd import grid
     from gshell_amd.denoiser.denoiser import BilateralDenoiser
     from gshell_amd.render import light, mesh, mlptexture, optixutils as ou, render
@@ -45,6 +41,10 @@ def test_render_mesh_matches_pipeline_oracle(denoise):
     tex = mlptexture.MLPTexture3D(aabb, channels=6, min_max=[mn, mx])
     with torch.no_grad():
         tex.encoder.params.mul_(3000.0)        # make the texture vary visibly over the object
+        from oracle import hashgrid_oracle as ho
+        metas, _ = ho.level_meta(*tex.encoder.cfg)
+        if tex_levels < len(metas):
+            tex.encoder.params[metas[tex_levels][2] * tex.encoder.cfg[1]:] = 0.0
     FLAGS = default_flags(n_samples=n)
     vd = v_pos.to(DEV).requires_grad_(True)
     md = msdf.to(DEV).requires_grad_(True)
@@ -72,15 +72,38 @@ def test_render_mesh_matches_pipeline_oracle(denoise):
     ref = pl.render_mesh(v_ref, faces, po.auto_normals(v_ref, faces), m_ref, torch.tensor(mvp), torch.tensor(cam), l_ref, bg, noise, tex_o, n, seed, shadow,
                          perms.numpy(), denoise_sigma=sigma if denoise else None, resolution=(H, W))
 
+    lin = [m for m in tex.net.net if isinstance(m, torch.nn.Linear)]
+    leaves = dict(v_pos=(vd, v_ref), msdf=(md, m_ref), light=(lgt.base, l_ref), hash_grid=(tex.encoder.params, params),
+                  **{f"mlp{i}": (m.weight, w) for i, (m, w) in enumerate(zip(lin, weights))})
+    return out, ref, leaves, (B, H, W)
+
+
+@pytest.mark.parametrize("denoise,tex_levels", [(False, 16), (True, 16), (False, 6), (True, 6)])
+def test_render_mesh_matches_pipeline_oracle(denoise, tex_levels):
+    """tex_levels = 16: all hash-grid levels carry texture (amplitude x 3000).  The texture is then piecewise trilinear with cells of
+    1/4096 of the box: d texture / d position JUMPS at every cell face, and a surface point within float32 round-off of a face takes
+    either side's slope -- the float32 and float64 runs of the CPU oracle itself differ by 4e-3 (relative L2) in the v_pos
+    gradient (measured), the HIP path by 1.3e-4 .. 1.7e-4 from the float32 oracle, concentrated in ~10 vertices
+    (tools/render_grad_diag.py).  tex_levels = 6: the fine levels are zeroed (cells >= 1/100 of the box, slope jumps 40 x
+    smaller): there the end-to-end position gradient must meet the north-star 1e-4."""
+    out, ref, leaves, (B, H, W) = render_both(denoise, tex_levels)
     assert set(out.keys()) == set(ref.keys())
     np.testing.assert_array_equal(out['visible_triangles'].cpu().numpy(), ref['visible_triangles'].numpy())    # integer: bit exact
+    n = 2                                                # n_samples of render_both: 2 n^2 = 8 Monte-Carlo samples per pixel
     for key in ref:
         if key == 'visible_triangles':
             continue
-        frac = _close_frac(out[key].detach().cpu(), ref[key].detach(), 1e-4)
-        floor = 0.999       # measured on MI355X (r02): 1.0000 for every buffer of every case (MC sample-placement flips: see test_shade_gpu)
-        print(f"  buffer {key}: pixels within 1e-4: {frac:.4f}")
-        assert frac >= floor, (key, frac)
+        a, b = out[key].detach().cpu(), ref[key].detach()
+        scale = b.abs().max().clamp(min=1e-12)
+        dev = ((a - b).abs() - 1e-4 * b.abs()).amax(dim=-1) / scale
+        bad = dev > 1e-4
+        # Every pixel within 1e-4 (measured on MI355X, r02 / r03: all of them, every buffer, every case).  The vertex normals that feed
+        # the sampler are float-atomic sums on the GPU (as in the reference), so an ulp of run-to-run noise can move ONE of a pixel's
+        # 2 n^2 samples across a CDF cell / probe texel (tests/test_ref_parity_gpu.py lists such samples against the reference
+        # kernel): tolerate at most two such pixels per buffer, each off by no more than two samples' weight -- not a percentage.
+        print(f"  buffer {key}: pixels outside 1e-4: {int(bad.sum())} of {bad.numel()}")
+        assert int(bad.sum()) <= 2, (key, int(bad.sum()))
+        assert float(dev.max()) <= 2.0 / (2 * n * n) * 4.0, (key, float(dev.max()))
 
     gen2 = torch.Generator().manual_seed(9)
     w_sh, w_ms = torch.rand(B, H, W, 4, generator=gen2), torch.rand(B, H, W, 1, generator=gen2)
@@ -89,15 +112,12 @@ def test_render_mesh_matches_pipeline_oracle(denoise):
         return (o['shaded'] * w_sh.to(dev)).sum() + (o['msdf_image'] * w_ms.to(dev)).sum() + o['kd_grad'].sum() * 0.1 + o['normal'].sum() * 0.05
     loss(out, DEV).backward()
     loss(ref, "cpu").backward()
-    pairs = [("v_pos", vd.grad.cpu(), v_ref.grad), ("msdf", md.grad.cpu(), m_ref.grad), ("light", lgt.base.grad.cpu(), l_ref.grad),
-             ("hash grid", tex.encoder.params.grad.cpu(), params.grad * 128.0)]       # product keeps the reference's x128 gradient hook
-    lin = [m for m in tex.net.net if isinstance(m, torch.nn.Linear)]
-    pairs += [(f"mlp{i}", m.weight.grad.cpu(), w.grad) for i, (m, w) in enumerate(zip(lin, weights))]
+    # the product keeps the reference's x128 gradient hook on the hash-grid parameters
+    pairs = [(name, a.grad.cpu(), b.grad * (128.0 if name == "hash_grid" else 1.0)) for name, (a, b) in leaves.items()]
     for name, a, b in pairs:
         assert torch.isfinite(a).all(), name
         assert b.abs().max() > 0, name
         # float atomics + a few MC placement flips: compare in aggregate (relative L2) and element-wise coverage
         rel = float((a - b).norm() / b.norm())
         print(f"  end-to-end gradient {name}: relative L2 error {rel:.2e}")
-        # measured (r02): v_pos 1.4e-4 .. 1.7e-4 (float atomics through the silhouette antialiasing), everything else <= 8e-5
-        assert rel < (5e-4 if name == "v_pos" else 2e-4), (name, rel)
+        assert rel < (5e-4 if (name == "v_pos" and tex_levels == 16) else 1e-4 if name == "v_pos" else 2e-4), (name, rel)

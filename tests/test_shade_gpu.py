@@ -40,80 +40,9 @@ def test_bvh_any_hit_matches_bruteforce(kind, ntri):
     assert int(ou.any_hit(ctx, torch.tensor(org, device=DEV), torch.tensor(d, device=DEV)).sum()) == 0
 
 
-def _gbuffer(B, H, W, seed):
-    """g-buffer of a wavy sheet rendered with the CPU oracle rasteriser (independent of the HIP rasteriser)."""
-    verts, tri = scenes.grid_sheet(12, seed)
-    mvp, cam = scenes.orbit_views(B, first=seed)
-    pos_clip = ro.xfm_points(torch.tensor(verts)[None], torch.tensor(mvp))
-    tri_l = torch.tensor(tri).long()
-    ids = torch.tensor(ro.rasterize_ids(pos_clip.numpy(), tri, H, W))
-    rast, _ = ro.rast_from_ids(pos_clip, tri_l, ids)
-    gb_pos = ro.interpolate(torch.tensor(verts)[None], rast, tri_l)
-    nrm_v = po.auto_normals(torch.tensor(verts), tri_l)
-    gb_nrm = ro.interpolate(nrm_v[None], rast, tri_l)
-    gen = torch.Generator().manual_seed(seed)
-    kd = torch.rand(B, H, W, 3, generator=gen)
-    ks = torch.rand(B, H, W, 3, generator=gen) * torch.tensor([0.3, 1.0, 1.0])
-    mask = (ids >= 0).float()
-    view = torch.tensor(cam)[:, None, None, :]
-    return verts, tri, mask, gb_pos, gb_nrm, view, kd, ks
-
-
-@pytest.mark.parametrize("bsdf,n,shadow", [("pbr", 2, 1.0), ("pbr", 4, 0.6), ("diffuse", 3, 1.0), ("pbr", 8, 1.0)])
-def test_env_shade_matches_oracle(bsdf, n, shadow):
-    from gshell_amd.render import optixutils as ou
-    B, H, W = 2, 20, 20
-    probe = (16, 32)
-    if n == 8:          # the benchmarked sample count (128 shadow rays per pixel and pass) on a 64 x 64 frame, finer probe
-        B, H, W = 1, 64, 64
-        probe = (64, 128)
-    verts, tri, mask, gb_pos, gb_nrm, view, kd, ks = _gbuffer(B, H, W, 3)
-    gen = torch.Generator().manual_seed(9)
-    light = torch.rand(probe[0], probe[1], 3, generator=gen) * 2 + 0.05
-    pdf, rows, cols = po.update_pdf(light)
-    perms = torch.argsort(torch.rand(ou.PERM_ROWS, n * n, generator=gen), dim=-1).int()
-    wd, ws = torch.rand(B, H, W, 3, generator=gen), torch.rand(B, H, W, 3, generator=gen)
-    seed = 1234
-    # ---- oracle
-    leaves = [t.clone().requires_grad_(True) for t in (gb_pos, gb_nrm, kd, ks, light)]
-    ro_ref = (gb_pos + gb_nrm * 0.001)
-    d_ref, s_ref = so.env_shade(mask, ro_ref, leaves[0], leaves[1], view, leaves[2], leaves[3], leaves[4], pdf, rows[:, 0], cols, perms.numpy(),
-                                ou._BSDF_IDS.index(bsdf), n, seed, shadow, verts, tri.astype(np.int64))
-    ((d_ref * wd).sum() + (s_ref * ws).sum()).backward()
-    # ---- HIP
-    ctx = ou.OptiXContext()
-    ou.optix_build_bvh(ctx, torch.tensor(verts, device=DEV), torch.tensor(tri, device=DEV), rebuild=1)
-    ou.set_random_perm(n, perms.to(DEV))
-    dl = [t.to(DEV).requires_grad_(True) for t in (gb_pos, gb_nrm, kd, ks, light)]
-    d, s = ou.optix_env_shade(ctx, mask.to(DEV), ro_ref.to(DEV), dl[0], dl[1], view.to(DEV), dl[2], dl[3], dl[4], pdf.to(DEV), rows[:, 0].to(DEV),
-                              cols.to(DEV), BSDF=bsdf, n_samples_x=n, rnd_seed=seed, shadow_scale=shadow)
-    ((d * wd.to(DEV)).sum() + (s * ws.to(DEV)).sum()).backward()
-
-    def close_frac(a, b, rtol=1e-4):
-        scale = b.abs().max().clamp(min=1e-12)
-        return float(((a - b).abs() <= rtol * b.abs() + rtol * scale).float().mean())
-    # sample placement uses sin/cos/acos/atan2: a GPU/CPU ulp can move a sample across a texel or lobe boundary, which changes
-    # ONE of the 2 n^2 samples of that pixel.  Measured on MI355X (r02): every pixel of every case within 1e-4, position /
-    # normal gradients 0.9998 of the pixels at n = 8 on 64 x 64.  Demand 99.9 % / 99.5 % and bound the outliers.
-    print(f"n={n} {H}x{W}: pixels within 1e-4: diffuse {close_frac(d.cpu(), d_ref.detach()):.4f} specular {close_frac(s.cpu(), s_ref.detach()):.4f}; "
-          + " ".join(f"{nm} {close_frac(a.grad.cpu(), b.grad, rtol=2e-4):.4f}" for nm, a, b in zip(("g_pos", "g_nrm", "g_kd", "g_ks", "g_light"), dl, leaves)
-                     if a.grad is not None and b.grad is not None))
-    assert close_frac(d.cpu(), d_ref.detach()) >= 0.999, close_frac(d.cpu(), d_ref.detach())
-    assert close_frac(s.cpu(), s_ref.detach()) >= 0.999, close_frac(s.cpu(), s_ref.detach())
-    # a flipped sample is ONE of the 2 n^2 samples of its pixel: no pixel may be off by more than a few samples' worth
-    worst = float(((d.cpu() - d_ref.detach()).abs().amax(dim=-1) / d_ref.detach().abs().amax().clamp_min(1e-12)).max())
-    assert worst <= 8.0 / (2 * n * n) + 1e-4, worst
-    assert abs(float(d.sum()) - float(d_ref.sum())) <= 2e-3 * float(d_ref.sum())
-    assert (d.cpu()[mask == 0] == 0).all() and (s.cpu()[mask == 0] == 0).all()
-    names = ("gb_pos", "gb_normal", "kd", "ks", "light")
-    for name, a, b in zip(names, dl, leaves):
-        if bsdf != "pbr" and name in ("gb_pos", "kd", "ks"):
-            assert a.grad is None or float(a.grad.abs().max()) == 0.0
-            continue
-        assert b.grad.abs().max() > 0, name
-        frac = close_frac(a.grad.cpu(), b.grad, rtol=2e-4)
-        assert frac >= (0.99 if name == "light" else 0.995), (name, frac)
-        assert abs(float(a.grad.sum()) - float(b.grad.sum())) <= 5e-3 * float(b.grad.abs().sum()), name
+# The pixel-by-pixel / sample-by-sample comparison of the sampler with the REFERENCE'S OWN kernel.cu (compiled for the host) lives in
+# tests/test_ref_parity_gpu.py (nine committed goldens + the 64 x 64, n = 8 case); the former statistical comparison with the python
+# restatement (>= 99.9 % of pixels) is gone -- the restatement itself is pinned to the reference kernel by tests/test_oracle_ref_cpu.py.
 
 
 def test_env_shade_analytic_white_probe():
@@ -196,7 +125,7 @@ def test_env_shade_backward_from_saved_samples_equals_the_replayed_sampler(bsdf,
     pinned to the oracle above): per-pixel gradients bit-identical, the light gradient equal up to float-atomic order."""
     from gshell_amd.render import optixutils as ou
     B, H, W = 2, 40, 36
-    verts, tri, mask, gb_pos, gb_nrm, view, kd, ks = _gbuffer(B, H, W, 5)
+    verts, tri, mask, gb_pos, gb_nrm, view, kd, ks = scenes.sheet_gbuffer(B, H, W, 5)
     gen = torch.Generator().manual_seed(3)
     light = torch.rand(32, 64, 3, generator=gen) * 2 + 0.05
     pdf, rows, cols = po.update_pdf(light)
