@@ -67,13 +67,20 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 //   EIK : 16 samples per tile, 4 VIRTUAL rows each: tile row 16 c + i = (value | d/dx | d/dy | d/dz) of sample 16 tile + i.
 //         The tangent rows carry the forward-mode derivative of the network w.r.t. the input point through the same GEMMs
 //         (no bias; activation a' = sigma'(z) z'), so that |grad f| of the eikonal term costs one pass over 4 n rows.
-enum { MODE_GRID = 0, MODE_ROWS = 1, MODE_EIK = 2 };
+//   FIX : row rows[r] of x, r < R, nothing saved: the second pass of the two-pass forward (k_h1_fwd first): out[rows[r]] is
+//         overwritten with the three-product value, the sign bit of the row is corrected, max |new - old| is recorded
+enum { MODE_GRID = 0, MODE_ROWS = 1, MODE_EIK = 2, MODE_FIX = 3 };
+// status words of the forward kernels (device, zeroed by the caller): [0] != 0: a non-finite value left the network (an activation
+// or weight beyond the fp16 range -- the caller re-runs the exact-fp32 kernel); [1]: bits of max |three-product - one-product| over
+// the rows the second pass recomputed (the a-posteriori check of the one-product pass's error bound)
+enum { ST_NONFINITE = 0, ST_MAXDEV = 1 };
 
 struct H2Args {
     const float* x;       // [N,3] points
     const int32_t* rows;  // MODE_ROWS: [R]
-    uint64_t* occ;        // MODE_GRID: optional sign bits, word t = ballot(sdf[64 t + i] > 0)
-    float* out;           // MODE_GRID: [N] sdf;  MODE_EIK: [tiles*64] per virtual row (value rows: f - b_out; tangent rows: df/dx_d)
+    uint64_t* occ;        // MODE_GRID: optional sign bits, word t = ballot(sdf[64 t + i] > 0);  MODE_FIX: the same words, corrected per row
+    uint32_t* status;     // optional status words (ST_*)
+    float* out;           // MODE_GRID / MODE_FIX: [N] sdf;  MODE_EIK: [tiles*64] per virtual row (value rows: f - b_out; tangent rows: df/dx_d)
     float* A;             // saved activations [n_layers][Rpad][256] fp32 (value rows a_l, tangent rows a'_l)   (ROWS / EIK)
     float* EMB;           // saved encoding [Rpad][EK] fp32 (tangent rows: d enc / dx_d)                            (ROWS / EIK)
     int64_t N;            // GRID: rows; ROWS: active rows R (capacity when n_dev is given); EIK: samples
@@ -93,6 +100,9 @@ __device__ __forceinline__ void split_h2(float v, _Float16& hi, _Float16& lo) {
     if (GS_H2_FLUSH && fabsf(v) < H_MIN_NORMAL) h = (_Float16)0.0f;
     hi = h;
     lo = (_Float16)((v - (float)h) * LO_SCALE);
+#ifdef GS_H2_EMU1          // numerics experiment: drop the low pieces = the arithmetic of a ONE-product fp16 kernel
+    lo = (_Float16)0.0f;
+#endif
 }
 
 // two values at a time: v_pk_* fp32 ops and v_cvt_pk_f16_f32 (the epilogue is VALU bound: see DESIGN.md)
@@ -105,6 +115,9 @@ __device__ __forceinline__ void split_h2_pair(f2 v, h2& hi, h2& lo) {
     hi = __builtin_convertvector(vh, h2);
     const f2 hf = __builtin_convertvector(hi, f2);
     lo = __builtin_convertvector((v - hf) * LO_SCALE, h2);
+#ifdef GS_H2_EMU1
+    lo = h2{(_Float16)0.0f, (_Float16)0.0f};
+#endif
 }
 
 // Softplus(beta = 100, threshold 20) on the raw v_exp_f32 / v_log_f32 (base 2, constants folded):
@@ -250,7 +263,7 @@ __device__ __forceinline__ bool tile_point(const H2Args& A, int64_t n_act, int64
     } else {
         src = tile * TM + row;
         if (src >= n_act) return false;
-        if (MODE == MODE_ROWS) src = A.rows[src];
+        if (MODE == MODE_ROWS || MODE == MODE_FIX) src = A.rows[src];
     }
     p[0] = A.x[3 * src]; p[1] = A.x[3 * src + 1]; p[2] = A.x[3 * src + 2];
     return true;
@@ -273,8 +286,8 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
     _Float16* E2 = E1 + TM * LDEH;           // [TM][LDEH]   (the output reduction scratch is overlaid on E1/E2 at the end)
     const int tid = threadIdx.x & (NT - 1), lane = tid & 63, wave = tid >> 6;
     const int64_t tile = DUAL ? 2 * (int64_t)blockIdx.x + half : (int64_t)blockIdx.x, r0 = tile * TM;
-    const int64_t n_act = (MODE == MODE_ROWS && A.n_dev) ? min(*A.n_dev, A.N) : A.N;
-    if (MODE == MODE_ROWS && (DUAL ? 2 * (int64_t)blockIdx.x : tile) * TM >= n_act) return;      // whole workgroup past the device-side count
+    const int64_t n_act = ((MODE == MODE_ROWS || MODE == MODE_FIX) && A.n_dev) ? min(*A.n_dev, A.N) : A.N;
+    if ((MODE == MODE_ROWS || MODE == MODE_FIX) && (DUAL ? 2 * (int64_t)blockIdx.x : tile) * TM >= n_act) return;      // whole workgroup past the device-side count
 
     // encoding of the tile, zero padded to EK columns, zero rows past the end.  24 work items per row: 18 (frequency, axis)
     // pairs -- ONE sincosf serves the sin and the cos column (and, on tangent rows, both derivatives) --, the 3 coordinates,
@@ -284,7 +297,7 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
         split_h2(v, hi, lo);
         E1[row * LDEH + f] = hi;
         E2[row * LDEH + f] = lo;
-        if (MODE != MODE_GRID) A.EMB[(r0 + row) * EK + f] = v;
+        if (MODE == MODE_ROWS || MODE == MODE_EIK) A.EMB[(r0 + row) * EK + f] = v;
     };
     for (int idx = tid; idx < TM * 24; idx += NT) {
         const int row = idx / 24, slot = idx - row * 24;
@@ -372,7 +385,7 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                if (MODE != MODE_GRID) {
+                if (MODE == MODE_ROWS || MODE == MODE_EIK) {
                     float* ap = A.A + plane_idx(A.Rpad, l, r0 + 32 * s + m_lane, n_base + 8 * g);
                     ap[0] = v[s][0].x; ap[32] = v[s][0].y; ap[64] = v[s][1].x; ap[96] = v[s][1].y;
                 }
@@ -418,9 +431,149 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
             // fused geometry front end: the tile is one 64-bit word of the extraction's occupancy bits (strict > 0, ref gshell_tets.py:250)
             const uint64_t m = __ballot(r < A.N && s > 0.0f);
             if (A.occ && tid == 0 && r0 < A.N) A.occ[tile] = m;
+            // an activation beyond the fp16 range turns into inf in the pair split and reaches the output as inf / NaN
+            if (A.status && __ballot(r < A.N && !(fabsf(s) < 3.0e38f)) != 0ull && tid == 0) atomicOr(&A.status[ST_NONFINITE], 1u);
+        } else if (MODE == MODE_FIX) {
+            s += A.w_out[D];
+            float dev = 0.f;
+            if (r < n_act) {
+                const int64_t g = A.rows[r];
+                const float old = A.out[g];
+                dev = fabsf(s - old);
+                A.out[g] = s;
+                if (A.occ && ((s > 0.0f) != (old > 0.0f))) atomicXor((unsigned long long*)&A.occ[g >> 6], 1ull << (g & 63));
+                if (!(fabsf(s) < 3.0e38f)) { dev = 0.f; if (A.status) atomicOr(&A.status[ST_NONFINITE], 1u); }
+            }
+            for (int o = 32; o > 0; o >>= 1) dev = fmaxf(dev, __shfl_xor(dev, o, 64));
+            if (A.status && tid == 0 && dev > 0.f) atomicMax(&A.status[ST_MAXDEV], __float_as_uint(dev));
         } else {
             A.out[r] = s;                                    // virtual rows: value rows lack b_out (unused), tangent rows = df/dx_d
         }
+    }
+}
+
+// ---- one-product forward: the FIRST pass of the two-pass full-grid evaluation --------------------------------------------------
+// Far from the surface the signed distance is consumed only through its sign (extraction: occ = sdf > 0, ref gshell_tets.py:250;
+// sdf regulariser and every gradient: end points of sign-crossing edges only, gshell_tets_geometry.py:33-39).  This kernel
+// evaluates the network with ONE fp16 product per algorithmic product (operands rounded to fp16, 2^-11; fp32 accumulate): a third
+// of the matrix work of k_h2_fwd, one activation plane (41 KB of LDS: three workgroups per CU), no pair split in the epilogue.
+// Its values carry an error of ~1e-4 (measured: max 2.3e-4, rms 3e-5 on the fitted bench network); every row that can matter --
+// |sdf| below a threshold tau >> that error, or an end point of an edge with such a row or with a sign change (gs_mtets_flag_refine_rows)
+// -- is then recomputed by k_h2_fwd<MODE_FIX>, which also MEASURES the error on those rows (ST_MAXDEV).  If the one-product error
+// is below tau everywhere, signs at all vertices and values at all crossing-edge end points equal the one-pass h2 result bit for bit
+// (argument in DESIGN.md 2.1; tests/test_fullsize_parity_gpu.py checks it on the res-256 grid).
+template <int STRIDE, int NSTEPS>
+__device__ __forceinline__ void gemm_seg1(v16f (&acc)[2], const _Float16* __restrict__ P1, const h8* __restrict__ wf, int blk, int nblk, int lane) {
+    constexpr int PD = 2 < NSTEPS ? 2 : NSTEPS - 1;
+    const int row = lane & 31, kq = lane >> 5;
+    const _Float16* b1p = P1 + row * STRIDE + kq * 8;
+    const h8* wp = wf + blk * 128 + lane;       // the high pieces of the h2 fragment set: + step * nblk * 128
+    const int sstride = nblk * 128;
+    h8 a1[PD + 1];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) a1[i] = wp[i * sstride];
+#pragma unroll
+    for (int st = 0; st < NSTEPS; ++st) {
+        if (st + PD < NSTEPS) a1[(st + PD) % (PD + 1)] = wp[(st + PD) * sstride];
+        const h8 b10 = *reinterpret_cast<const h8*>(b1p + st * 16);
+        const h8 b11 = *reinterpret_cast<const h8*>(b1p + 32 * STRIDE + st * 16);
+        const h8 w1 = a1[st % (PD + 1)];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b10, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b11, acc[1], 0, 0, 0);
+    }
+}
+
+#ifndef GS_H1_WAVES
+#define GS_H1_WAVES 6     // waves per SIMD the register budget is sized for (3 workgroups of 8 waves per CU)
+#endif
+__global__ void __launch_bounds__(NT, GS_H1_WAVES) k_h1_fwd(H2Args A) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
+    _Float16* H1 = smem_h;                   // [TM][LDH]
+    _Float16* E1 = H1 + TM * LDH;            // [TM][LDEH]   (the output reduction scratch is overlaid at the end)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t tile = blockIdx.x, r0 = tile * TM;
+    for (int idx = tid; idx < TM * 24; idx += NT) {
+        const int row = idx / 24, slot = idx - row * 24;
+        const int64_t src = r0 + row;
+        const bool valid = src < A.N;
+        float p[3] = {0.f, 0.f, 0.f};
+        if (valid) { p[0] = A.x[3 * src]; p[1] = A.x[3 * src + 1]; p[2] = A.x[3 * src + 2]; }
+        _Float16* e = E1 + row * LDEH;
+        if (slot < 18) {
+            const int k = slot / 3, ax = slot - 3 * k;
+            float sn = 0.f, cs = 0.f;
+            if (valid && k < A.n_freq) sincosf((float)(1 << k) * p[ax], &sn, &cs);
+            e[3 + 6 * k + ax] = (_Float16)sn;
+            e[3 + 6 * k + 3 + ax] = (_Float16)cs;
+        } else if (slot < 21) {
+            e[slot - 18] = (_Float16)fminf(fmaxf(p[slot - 18], -60000.0f), 60000.0f);
+        } else {
+            for (int j = 0; j < 3; ++j) e[39 + 3 * (slot - 21) + j] = (_Float16)0.0f;
+        }
+    }
+    __syncthreads();
+    const int n_base = wave * 32 + 4 * (lane >> 5);
+    const int m_lane = lane & 31;
+    for (int l = 0; l < A.n_layers; ++l) {
+        v16f acc[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+        if (l == 0) {
+            gemm_seg1<LDEH, EK / 16>(acc, E1, A.wfrag[0], wave, 8, lane);
+        } else {
+            gemm_seg1<LDH, D / 16>(acc, H1, A.wfrag[l], wave, 8, lane);
+            if (l == A.skip_layer) gemm_seg1<LDEH, EK / 16>(acc, E1, A.wfrag[l] + (D / 16) * 1024, wave, 8, lane);
+        }
+        const float* bl = A.bias[l] + n_base;
+        const bool last = l + 1 == A.n_layers;
+        float4 b4v[4], w4v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            b4v[g] = *reinterpret_cast<const float4*>(bl + 8 * g);
+            w4v[g] = last ? *reinterpret_cast<const float4*>(A.w_out + n_base + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();     // every wave is done reading the plane: it is overwritten in place
+        f2 part[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f2 bj[2] = {f2{b4v[g].x, b4v[g].y}, f2{b4v[g].z, b4v[g].w}};
+            const f2 wj[2] = {f2{w4v[g].x, w4v[g].y}, f2{w4v[g].z, w4v[g].w}};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f2 v0 = softplus100_pair(f2{acc[s][4 * g], acc[s][4 * g + 1]} + bj[0]);
+                const f2 v1 = softplus100_pair(f2{acc[s][4 * g + 2], acc[s][4 * g + 3]} + bj[1]);
+                if (last) {
+                    part[s] = part[s] + v0 * wj[0] + v1 * wj[1];
+                } else {
+                    const h2 a0 = __builtin_convertvector(v0, h2), a1 = __builtin_convertvector(v1, h2);
+                    *reinterpret_cast<h4*>(H1 + (32 * s + m_lane) * LDH + n_base + 8 * g) = h4{a0.x, a0.y, a1.x, a1.y};
+                }
+            }
+        }
+        if (last) {
+            float* red = reinterpret_cast<float*>(E1);       // [8 waves][64 rows] fp32 = 2 KB (the encoding plane is dead now)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float p = part[s].x + part[s].y;
+                p += __shfl_xor(p, 32, 64);
+                if (lane < 32) red[wave * TM + 32 * s + lane] = p;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < TM) {
+        const float* red = reinterpret_cast<const float*>(E1);
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += red[w * TM + tid];
+        s += A.w_out[D];
+        const int64_t r = r0 + tid;
+        if (r < A.N) A.out[r] = s;
+        const uint64_t m = __ballot(r < A.N && s > 0.0f);
+        if (A.occ && tid == 0) A.occ[tile] = m;
+        if (A.status && __ballot(r < A.N && !(fabsf(s) < 3.0e38f)) != 0ull && tid == 0) atomicOr(&A.status[ST_NONFINITE], 1u);
     }
 }
 
@@ -1039,6 +1192,7 @@ __global__ void __launch_bounds__(256) k_cnz_write(const float* __restrict__ g, 
 }
 
 constexpr size_t SMEM_BYTES = (size_t)(2 * TM * LDH + 2 * TM * LDEH) * sizeof(_Float16);
+constexpr size_t SMEM_H1_BYTES = (size_t)(TM * LDH + TM * LDEH) * sizeof(_Float16);
 constexpr size_t SMEM_BWD_BYTES = (size_t)(2 * TM * LDH) * sizeof(_Float16) + (size_t)(TM * LDG + TM) * sizeof(float);
 constexpr size_t SMEM_WGRAD_BYTES = (size_t)2 * WG_BUF * sizeof(float);
 static_assert(SMEM_BYTES <= 80 * 1024 && SMEM_BWD_BYTES <= 80 * 1024, "two workgroups per CU");
@@ -1081,6 +1235,7 @@ struct PackArgs {
     PackLayout L;
     h8* frags;
     float* tail;
+    uint32_t* status;                 // optional: ST_NONFINITE is raised for a weight beyond the fp16 range (split_h2 would clamp it)
 };
 
 __global__ void __launch_bounds__(256) k_h2_pack(PackArgs P) {
@@ -1103,6 +1258,7 @@ __global__ void __launch_bounds__(256) k_h2_pack(PackArgs P) {
                 else if (k < D) src = k;
                 else if (l == L.skip_layer && k - D < L.E) src = k;            // [h | emb] order of geometry/mlp.py:37
                 float v = src >= 0 ? P.w[l][(int64_t)n * Kin + src] : 0.f;
+                if (P.status && !(fabsf(v) <= 60000.0f)) atomicOr(&P.status[ST_NONFINITE], 1u);
                 _Float16 hi, lo;
                 split_h2(v, hi, lo);
                 o[q] = piece ? lo : hi;
@@ -1218,7 +1374,7 @@ extern "C" int64_t gs_sdf_mlp_h2_packed_bytes(int n_freq, int n_hidden, int skip
 // weights / biases: HOST arrays of n_hidden + 2 DEVICE pointers (torch layout, Linear.weight [out, in] row-major; the
 // output layer last).  packed: gs_sdf_mlp_h2_packed_bytes bytes, 16-byte aligned, WRITTEN.
 extern "C" int gs_sdf_mlp_h2_pack(const float* const* weights, const float* const* biases, int n_freq, int n_hidden, int skip_layer, void* packed,
-                                  gs_stream_t stream) {
+                                  uint32_t* status, gs_stream_t stream) {
     GS_REQUIRE(weights && biases && packed, "gs_sdf_mlp_h2_pack: null pointer");
     GS_REQUIRE(((uintptr_t)packed & 15) == 0, "gs_sdf_mlp_h2_pack: packed buffer must be 16-byte aligned");
     if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
@@ -1231,20 +1387,50 @@ extern "C" int gs_sdf_mlp_h2_pack(const float* const* weights, const float* cons
     }
     P.frags = (h8*)packed;
     P.tail = (float*)((char*)packed + P.L.tail_off_bytes);
+    P.status = status;
     hipLaunchKernelGGL(k_h2_pack, dim3((unsigned)gs::cdiv(P.L.total_frags, 256)), dim3(256), 0, (hipStream_t)stream, P);
     GS_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int gs_sdf_mlp_fwd_h2(const float* x, int64_t N, const void* packed, int n_freq, int n_hidden, int skip_layer, float* out,
-                                 uint64_t* occ_bits, gs_stream_t stream) {
+                                 uint64_t* occ_bits, uint32_t* status, gs_stream_t stream) {
     if (N == 0) return 0;
     GS_REQUIRE(x && packed && out, "gs_sdf_mlp_fwd_h2: null pointer");
     if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
     H2Args A{};
-    A.x = x; A.out = out; A.occ = occ_bits; A.N = N; A.n_freq = n_freq;
+    A.x = x; A.out = out; A.occ = occ_bits; A.status = status; A.N = N; A.n_freq = n_freq;
     fill_fwd_args(A, packed, make_layout(n_freq, n_hidden, skip_layer));
     return launch_fwd<MODE_GRID>(A, gs::cdiv(N, TM), (hipStream_t)stream);
+}
+
+// First pass of the two-pass forward: one fp16 product per algorithmic product (k_h1_fwd).  Same packed weights (high pieces).
+extern "C" int gs_sdf_mlp_fwd_h1(const float* x, int64_t N, const void* packed, int n_freq, int n_hidden, int skip_layer, float* out,
+                                 uint64_t* occ_bits, uint32_t* status, gs_stream_t stream) {
+    if (N == 0) return 0;
+    GS_REQUIRE(x && packed && out, "gs_sdf_mlp_fwd_h1: null pointer");
+    if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
+    H2Args A{};
+    A.x = x; A.out = out; A.occ = occ_bits; A.status = status; A.N = N; A.n_freq = n_freq;
+    fill_fwd_args(A, packed, make_layout(n_freq, n_hidden, skip_layer));
+    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h1_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_H1_BYTES));
+    hipLaunchKernelGGL(k_h1_fwd, dim3((unsigned)gs::cdiv(N, TM)), dim3(NT), SMEM_H1_BYTES, (hipStream_t)stream, A);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+// Second pass: rows[0 .. min(*count_dev, cap)) of x are recomputed with the three-product arithmetic of gs_sdf_mlp_fwd_h2 (bit
+// identical values: a row's arithmetic does not depend on its tile), written over out[rows[r]]; the rows' sign bits in occ_bits
+// are corrected; status[ST_MAXDEV] = bits of max |new - old| over the rows (atomicMax: zero it first).
+extern "C" int gs_sdf_mlp_h2_refine_rows(const float* x, const int32_t* rows, int64_t cap, const int64_t* count_dev, const void* packed, int n_freq,
+                                         int n_hidden, int skip_layer, float* out, uint64_t* occ_bits, uint32_t* status, gs_stream_t stream) {
+    if (cap == 0) return 0;
+    GS_REQUIRE(x && rows && packed && out, "gs_sdf_mlp_h2_refine_rows: null pointer");
+    if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
+    H2Args A{};
+    A.x = x; A.rows = rows; A.out = out; A.occ = occ_bits; A.status = status; A.N = cap; A.n_dev = count_dev; A.n_freq = n_freq;
+    fill_fwd_args(A, packed, make_layout(n_freq, n_hidden, skip_layer));
+    return launch_fwd<MODE_FIX>(A, gs::cdiv(cap, TM), (hipStream_t)stream);
 }
 
 extern "C" int64_t gs_sdf_mlp_h2_rows_padded(int mode, int64_t n) {      // virtual rows of the saved planes: whole PAIRS of 64-row tiles

@@ -153,6 +153,20 @@ __global__ void __launch_bounds__(256) k_edge_cross(const int2* __restrict__ edg
     }
 }
 
+// Row selection of the two-pass SDF evaluation (mlp_h2.hip: k_h1_fwd): both end points of an edge are flagged when the edge changes
+// sign or either end point lies within tau of the surface.  Plain stores of the same value: races are benign.
+__global__ void __launch_bounds__(256) k_flag_refine(const int2* __restrict__ edges, int64_t E, const float* __restrict__ sdf, float tau,
+                                                     float* __restrict__ flags) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int2 ab = edges[e];
+    const float sa = sdf[ab.x], sb = sdf[ab.y];
+    if (((sa > 0.0f) != (sb > 0.0f)) || fabsf(sa) < tau || fabsf(sb) < tau) {
+        flags[ab.x] = 1.0f;
+        flags[ab.y] = 1.0f;
+    }
+}
+
 // categories of a tet code byte: 0:n1 1:n2 2:tri->1 3:tri->2 4..7:quad->1..4
 // (tables packed into immediates: lane-varying __constant__ lookups are real memory gathers)
 __device__ __forceinline__ void code_cats(uint8_t cb, int& ntri, int& ci, int& ncut) {
@@ -736,6 +750,14 @@ extern "C" int gs_mtets_count(gs_mtets_topo* t, const float* pos, const float* s
     GS_REQUIRE(t && sdf && msdf && counts_host, "gs_mtets_count: null argument");
     (void)pos;
     return count_impl<false>(t, sdf, msdf, AugIn{}, (hipStream_t)stream_, counts_host);
+}
+
+extern "C" int gs_mtets_flag_refine_rows(const gs_mtets_topo* t, const float* sdf, float tau, float* flags, gs_stream_t stream) {
+    GS_REQUIRE(t && sdf && flags, "gs_mtets_flag_refine_rows: null argument");
+    if (t->E == 0) return 0;
+    k_flag_refine<<<(unsigned)gs::cdiv(t->E, 256), 256, 0, (hipStream_t)stream>>>((const int2*)t->edges, t->E, sdf, tau, flags);
+    GS_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int gs_mtets_occ_bits(gs_mtets_topo* t, uint64_t** bits_dev, int64_t* n_words) {

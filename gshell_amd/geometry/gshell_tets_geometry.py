@@ -9,7 +9,7 @@ from .. import _lib
 from .._lib import c_float, c_int64, check, ptr, stream
 from ..render import mesh, optixutils as ou, regularizer, render
 from .gshell_tets import GShell_Tets
-from .mlp import MLP, eikonal_sq_sum, forward_row_sharded, forward_row_sparse_backward
+from .mlp import MLP, check_forward_status, eikonal_sq_sum, forward_row_sharded, forward_row_sparse_backward
 
 
 class _SdfRegFn(torch.autograd.Function):
@@ -264,6 +264,23 @@ class GShellTetsGeometry(torch.nn.Module):
         msdf = self.msdf
         v_deformed = v_deformed + self.offset
         verts, faces, uvs, uv_idx, v_tng, extra = self.gshell_tets(v_deformed, sdf, msdf, self.indices)
+        if self.FLAGS.use_sdf_mlp:
+            # status words of the fused forward pass; the extraction's count has just synchronised the stream, so this costs no stall
+            todo = check_forward_status(self.sdf_net)
+            if todo is not None:
+                import warnings
+                if todo == "fp32":
+                    # an activation or weight beyond the fp16 range (the reference's fp32 GEMMs, geometry/mlp.py:32-40, have no such
+                    # limit): from now on plain torch fp32 ops evaluate this network and carry its gradients (counted in mlp.FALLBACKS)
+                    warnings.warn("SDF network: fp16-pair arithmetic overflowed; switching this network to torch fp32 ops")
+                    self.sdf_net._gs_precision = "torch"
+                else:
+                    warnings.warn(f"SDF network: one-product pass off by {self.sdf_net.__dict__.get('_gs_two_pass_maxdev'):.3e} on the refined rows "
+                                  "(more than tau / 4): this network is evaluated in one pass from now on")
+                    self.sdf_net._gs_one_pass = True
+                sdf = self._sdf_values(v_deformed - self.offset)
+                verts, faces, uvs, uv_idx, v_tng, extra = self.gshell_tets(v_deformed, sdf, msdf, self.indices)
+                check_forward_status(self.sdf_net)
         if self.FLAGS.use_sdf_mlp and getattr(self.FLAGS, "sync_free_rows", False):
             # d loss / d sdf is non-zero only at end points of sign-crossing edges (extraction backward + sign regulariser): a bound
             # that lets the row-sparse backward size its planes without waiting for the exact count (geometry/mlp.py).  Measured on

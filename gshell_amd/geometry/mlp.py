@@ -167,11 +167,34 @@ class MLP(nn.Module):
         return h
 
 
-def _fusable(net, x):
+# Every time an SDF-network pass leaves the hand-written kernels (a network shape they do not cover, a CPU tensor of the gloo tests,
+# or the exact-fp32 mode after an fp16-range overflow) it is counted here and announced once: bench.py refuses to report a number
+# when the count is non-zero, so a figure can never come from the torch path unnoticed.
+FALLBACKS = {}
+
+
+def _note_fallback(what, why):
+    n = FALLBACKS.get(what, 0)
+    FALLBACKS[what] = n + 1
+    if n == 0:
+        import warnings
+        warnings.warn(f"gshell_amd SDF network: {what} runs as plain torch ops, not as the HIP chain kernels ({why})")
+
+
+def _shape_fusable(net, x):
     lin = [m for m in net.net if isinstance(m, nn.Linear)]
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 3 and lin[-1].out_features == 1
+    return (x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 3 and lin[-1].out_features == 1
             and all(m.out_features == 256 for m in lin[:-1]) and len(net.skip_count) <= 1 and net.emb.N_freqs <= 6
             and all(f == 2.0 ** k for k, f in enumerate(net.emb.freq_bands)))
+
+
+def _fusable(net, x, what=None):
+    """True: the fused kernels cover this call.  False on a GPU tensor is recorded (FALLBACKS) when `what` names the pass."""
+    ok = x.is_cuda and _shape_fusable(net, x) and net.__dict__.get("_gs_precision") != "torch"
+    if not ok and x.is_cuda and what:
+        _note_fallback(what, "the exact-fp32 mode after an fp16-range overflow" if net.__dict__.get("_gs_precision") == "torch"
+                       else "hidden width != 256, more than 6 frequencies or more than one skip connection")
+    return ok
 
 
 def pack_weights(net):
@@ -202,6 +225,18 @@ SDF_MLP_PRECISION = "h2"
 SDF_MLP_WGRAD_FP32 = False
 
 
+# Full-grid forward as TWO passes when the caller hands over the grid's topology (GShellTetsGeometry.getMesh): a one-product fp16 pass
+# over every row (a third of the matrix work; error ~1e-4), then the three-product "h2" arithmetic on the rows that can matter --
+# |sdf| < SDF_TWO_PASS_TAU, or an end point of an edge that changes sign or has such an end point.  With the one-product error below
+# tau everywhere, every SIGN and the VALUE at both end points of every crossing edge equal the one-pass h2 result bit for bit; that
+# is all the reference consumes (gshell_tets.py:250, :277-290; gshell_tets_geometry.py:33-39).  Off-surface values of the returned
+# tensor carry the one-product error.  The second pass measures the error on ~1e5 rows per call; check_forward_status() compares it
+# with tau (safety factor 4) and re-runs the one-pass kernel when it is not met.
+SDF_TWO_PASS = True
+SDF_TWO_PASS_TAU = 2e-3
+SDF_TWO_PASS_SAFETY = 4.0
+
+
 def _layer_structure(net):
     lin = [m for m in net.net if isinstance(m, nn.Linear)]
     skip = -1
@@ -210,8 +245,9 @@ def _layer_structure(net):
     return lin, len(lin) - 2, skip
 
 
-def pack_weights_h2(net):
-    """Device buffer in the layout of gs_sdf_mlp_fwd_h2: ONE launch that reads the module's parameters in place."""
+def pack_weights_h2(net, status=None):
+    """Device buffer in the layout of gs_sdf_mlp_fwd_h2: ONE launch that reads the module's parameters in place.
+    status: optional int32 [2] device tensor (word 0 is raised for a weight beyond the fp16 range)."""
     import ctypes
     lin, n_hidden, skip = _layer_structure(net)
     L = _lib.lib()
@@ -227,22 +263,103 @@ def pack_weights_h2(net):
     PtrArr = ctypes.c_void_p * len(ws)
     with torch.cuda.device(dev):
         check(L.gs_sdf_mlp_h2_pack(PtrArr(*[t.data_ptr() for t in ws]), PtrArr(*[t.data_ptr() for t in bs]), c_int(nf), c_int(n_hidden), c_int(skip),
-                                   ptr(packed), stream()), "gs_sdf_mlp_h2_pack")
+                                   ptr(packed), ptr(status), stream()), "gs_sdf_mlp_h2_pack")
     return packed, n_hidden, skip
 
 
-def fused_forward(net, x, precision=None, occ_bits_ptr=None):
+class ForwardStatus:
+    """Device status words of one fused forward call + their asynchronous copy in pinned host memory."""
+
+    def __init__(self, device, tau=None):
+        self.dev = torch.zeros(2, dtype=torch.int32, device=device)
+        self.host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        self.event = None
+        self.tau = tau
+        self.n_rows = None          # device int64 [2]: rows the second pass recomputed
+
+    def fetch(self):
+        self.host.copy_(self.dev, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def result(self, wait=True):
+        """-> (non-finite flag, max |three-product - one-product| on the refined rows) or None if not ready and wait=False"""
+        if self.event is None:
+            self.fetch()
+        if not self.event.query():
+            if not wait:
+                return None
+            self.event.synchronize()
+        return bool(self.host[0].item()), float(self.host[1:2].view(torch.float32).item())
+
+
+def check_forward_status(net, wait=True):
+    """Inspect the status of the LAST fused forward pass over `net` (h2 arithmetic only).  -> None (fine / nothing to check) or a
+    string naming what the caller must do: "fp32" = the fp16-pair arithmetic overflowed (activation >= 65 504 or a weight beyond
+    the fp16 range): evaluate with precision="fp32"; "one_pass" = the one-product pass was measured too inaccurate for the
+    two-pass scheme at this tau.  GShellTetsGeometry.getMesh calls this right after the extraction's own stream sync (no
+    extra stall) and re-runs; every other caller of fused_forward gets the check synchronously."""
+    st = net.__dict__.get("_gs_fwd_status")
+    if st is None:
+        return None
+    r = st.result(wait)
+    if r is None:
+        return None
+    net.__dict__["_gs_fwd_status"] = None
+    nonfinite, maxdev = r
+    if nonfinite:
+        return "fp32"
+    if st.tau is not None and maxdev * SDF_TWO_PASS_SAFETY > st.tau:
+        net.__dict__["_gs_two_pass_maxdev"] = maxdev
+        return "one_pass"
+    if st.tau is not None:
+        net.__dict__["_gs_two_pass_maxdev"] = maxdev
+    return None
+
+
+def fused_forward(net, x, precision=None, occ_bits_ptr=None, refine_topo=None, defer_status=False):
     """sdf = net(x) through the fused MFMA kernel (no autograd).  `occ_bits_ptr`: device address of a [ceil(N/64)] uint64
-    array that receives the sign bits (h2 only; the extraction's occupancy bits)."""
-    precision = precision or SDF_MLP_PRECISION
+    array that receives the sign bits (h2 only; the extraction's occupancy bits).  `refine_topo` (a TetTopology
+    whose vertices are the rows of x): evaluate in two passes (see SDF_TWO_PASS).  The h2 paths raise GShellHipError when the
+    fp16-pair arithmetic overflowed, unless `defer_status` (then the caller must call check_forward_status)."""
+    precision = precision or net.__dict__.get("_gs_precision") or SDF_MLP_PRECISION
+    if precision == "torch":
+        precision = "fp32"
     L = _lib.lib()
     xc = x.detach().contiguous()
     out = torch.empty((xc.shape[0],), dtype=torch.float32, device=xc.device)
     if precision == "h2":
-        packed, n_hidden, skip = pack_weights_h2(net)
+        N = xc.shape[0]
+        two_pass = refine_topo is not None and SDF_TWO_PASS and refine_topo.N == N and N > 0 and not net.__dict__.get("_gs_one_pass", False)
+        st = ForwardStatus(xc.device, tau=float(net.__dict__.get("_gs_two_pass_tau", SDF_TWO_PASS_TAU)) if two_pass else None)
+        packed, n_hidden, skip = pack_weights_h2(net, st.dev)
+        nf = net.emb.N_freqs
+        occ = _lib.c_void_p(occ_bits_ptr or 0)
         with torch.cuda.device(xc.device):
-            check(L.gs_sdf_mlp_fwd_h2(ptr(xc, torch.float32, "x"), c_int64(xc.shape[0]), ptr(packed), c_int(net.emb.N_freqs), c_int(n_hidden), c_int(skip),
-                                      ptr(out), _lib.c_void_p(occ_bits_ptr or 0), stream()), "gs_sdf_mlp_fwd_h2")
+            if not two_pass:
+                check(L.gs_sdf_mlp_fwd_h2(ptr(xc, torch.float32, "x"), c_int64(N), ptr(packed), c_int(nf), c_int(n_hidden), c_int(skip),
+                                          ptr(out), occ, ptr(st.dev), stream()), "gs_sdf_mlp_fwd_h2")
+            else:
+                check(L.gs_sdf_mlp_fwd_h1(ptr(xc, torch.float32, "x"), c_int64(N), ptr(packed), c_int(nf), c_int(n_hidden), c_int(skip),
+                                          ptr(out), occ, ptr(st.dev), stream()), "gs_sdf_mlp_fwd_h1")
+                flags = torch.zeros(N, dtype=torch.float32, device=xc.device)
+                check(L.gs_mtets_flag_refine_rows(refine_topo.handle, ptr(out), _lib.c_float(st.tau), ptr(flags), stream()), "gs_mtets_flag_refine_rows")
+                rows = torch.empty(N, dtype=torch.int32, device=xc.device)
+                st.n_rows = torch.empty(2, dtype=torch.int64, device=xc.device)
+                scratch = torch.empty(int(L.gs_compact_rows_scratch_bytes(c_int64(N))) // 4 + 4, dtype=torch.int32, device=xc.device)
+                check(L.gs_compact_rows(ptr(flags), c_int64(N), c_int64(N), ptr(scratch), ptr(rows), _lib.c_void_p(0), ptr(st.n_rows), stream()), "gs_compact_rows")
+                check(L.gs_sdf_mlp_h2_refine_rows(ptr(xc), ptr(rows), c_int64(N), ptr(st.n_rows), ptr(packed), c_int(nf), c_int(n_hidden), c_int(skip),
+                                                  ptr(out), occ, ptr(st.dev), stream()), "gs_sdf_mlp_h2_refine_rows")
+        st.fetch()
+        net.__dict__["_gs_fwd_status"] = st
+        if not defer_status:
+            todo = check_forward_status(net)
+            if todo == "fp32":
+                raise _lib.GShellHipError("SDF network: a value beyond the fp16 range (activation >= 65 504 or |weight| > 60 000) overflowed the "
+                                          "fp16-pair arithmetic; evaluate with precision='fp32' (gs_sdf_mlp_fwd)")
+            if todo == "one_pass":
+                raise _lib.GShellHipError(f"SDF network, two-pass forward: the one-product pass is off by {net.__dict__.get('_gs_two_pass_maxdev')} on the refined "
+                                          f"rows, more than tau / {SDF_TWO_PASS_SAFETY} = {st.tau / SDF_TWO_PASS_SAFETY}; raise SDF_TWO_PASS_TAU or evaluate in one pass")
         return out[:, None]
     if precision != "fp32":
         raise ValueError(f"unknown SDF-MLP precision {precision!r} (h2 | fp32)")
@@ -316,7 +433,8 @@ class _RowSparseBackward(torch.autograd.Function):
     def forward(ctx, x, net, sign_sink, gate):
         with torch.no_grad():
             presign = sign_sink is not None and SDF_MLP_PRECISION == "h2" and _fusable(net, x) and sign_sink.N == x.shape[0]
-            y = (fused_forward(net, x, occ_bits_ptr=sign_sink.occ_bits_ptr() if presign else None) if _fusable(net, x) else net(x))
+            y = (fused_forward(net, x, occ_bits_ptr=sign_sink.occ_bits_ptr() if presign else None, refine_topo=sign_sink if presign else None,
+                               defer_status=presign) if _fusable(net, x, "forward") else net(x))
         ctx.net = net
         ctx.presigned = presign
         ctx.save_for_backward(x)
@@ -407,7 +525,7 @@ def row_sparse_backward(net, x, g_y, need_x):
     """(d loss / d x [N,3] or None, flat gradient of net.parameters()) from the upstream gradient g_y [N,1],
     touching only the rows where g_y != 0: they are recomputed by the h2 chain kernels (csrc/mlp_h2.hip: forward with saved
     planes -> backward chain -> weight gradients on the matrix cores); the full-grid forward pass keeps no activations."""
-    if not (_fusable(net, x) and g_y.is_cuda):
+    if not (_fusable(net, x, "row-sparse backward") and g_y.is_cuda):
         return row_sparse_backward_torch(net, x, g_y, need_x)
     g = g_y.detach().reshape(-1).contiguous().float()
     g_x = torch.zeros_like(x) if need_x else None
@@ -489,7 +607,7 @@ class _EikonalFn(torch.autograd.Function):
 def eikonal_sq_sum(net, pts):
     """sum_i (|d net / d x (pts_i)| - 1)^2, differentiable w.r.t. the parameters of `net` (the points are constants, as in the
     reference, which detaches them)."""
-    if _fusable(net, pts):
+    if _fusable(net, pts, "eikonal term"):
         return _EikonalFn.apply(pts, net, param_gate(net, reuse=True))
     v = pts.detach().requires_grad_(True)
     grad = torch.autograd.grad(net(v).sum(), v, create_graph=True)[0]
@@ -511,7 +629,7 @@ class _RowShardedForward(torch.autograd.Function):
         lo, hi = min(rank * per, N), min((rank + 1) * per, N)
         with torch.no_grad():
             x_loc = x[lo:hi].contiguous()
-            y_loc = (fused_forward(net, x_loc) if _fusable(net, x_loc) else net(x_loc)).reshape(-1)
+            y_loc = (fused_forward(net, x_loc) if _fusable(net, x_loc, "row-sharded forward") else net(x_loc)).reshape(-1)
             pad = torch.zeros(per, dtype=y_loc.dtype, device=y_loc.device)
             pad[:hi - lo] = y_loc
             y_full = shard.all_gather_rows(pad)

@@ -66,6 +66,11 @@ int gs_mtets_count(gs_mtets_topo* topo, const float* pos_nx3, const float* sdf_n
 int gs_mtets_occ_bits(gs_mtets_topo* topo, uint64_t** bits_dev, int64_t* n_words);
 int gs_mtets_count_presigned(gs_mtets_topo* topo, const float* sdf_n, const float* msdf_n,
                              gs_stream_t stream, int64_t* counts_host);
+/* Row selection of the two-pass SDF evaluation (gs_sdf_mlp_fwd_h1): flags [N] (float, zeroed by the caller) receives 1 at both
+ * end points of every edge of the static edge list whose end points differ in sign (sdf > 0, gshell_tets.py:250) or have
+ * |sdf| < tau at either end. */
+int gs_mtets_flag_refine_rows(const gs_mtets_topo* topo, const float* sdf_n, float tau, float* flags,
+                              gs_stream_t stream);
 
 /* Fill phase; must follow gs_mtets_count on the same topo/stream with the same inputs.
  *   verts_aug [V_aug,3] f32, msdf_aug [V_aug] f32 (stop-gradient mSDF, ref :386-390),
@@ -569,10 +574,30 @@ int gs_sdf_mlp_fwd(const float* x, int64_t N, const float* packed, int n_freq, i
  * ---------------------------------------------------------------------------------- */
 int64_t gs_sdf_mlp_h2_packed_bytes(int n_freq, int n_hidden, int skip_layer);
 int gs_sdf_mlp_h2_pack(const float* const* weights, const float* const* biases, int n_freq, int n_hidden,
-                       int skip_layer, void* packed, gs_stream_t stream);
+                       int skip_layer, void* packed, uint32_t* status /* [2] device words, or NULL */,
+                       gs_stream_t stream);
+/* status (device, uint32 [2], zeroed by the caller; NULL = unchecked):
+ *   [0] != 0  a non-finite signed distance left the network, or a weight lies beyond the fp16 range: the fp16-pair arithmetic
+ *             has overflowed (activations >= 65 504 become inf in the split) -- the caller must fall back to gs_sdf_mlp_fwd
+ *             (exact fp32; reference geometry/mlp.py:32-40 has no range limit);
+ *   [1]       bits of max |three-product value - one-product value| over the rows of gs_sdf_mlp_h2_refine_rows. */
 int gs_sdf_mlp_fwd_h2(const float* x, int64_t N, const void* packed, int n_freq, int n_hidden,
                       int skip_layer, float* out, uint64_t* occ_bits /* [ceil(N/64)] sign bits WRITTEN, or NULL */,
-                      gs_stream_t stream);
+                      uint32_t* status, gs_stream_t stream);
+/* Two-pass evaluation of the full grid (same function, a third of the matrix work where the value cannot matter):
+ *   1. gs_sdf_mlp_fwd_h1: ONE fp16 product per algorithmic product (operands rounded to 2^-11): out, sign bits.  Error ~1e-4.
+ *   2. gs_mtets_flag_refine_rows (extraction section): flags both end points of every grid edge that changes sign or has an end
+ *      point with |out| < tau;  gs_compact_rows turns the flags into a row list on the device.
+ *   3. gs_sdf_mlp_h2_refine_rows: those rows again with the three-product arithmetic of gs_sdf_mlp_fwd_h2 -- bit-identical
+ *      values (a row's arithmetic does not depend on its tile) --, written over out, sign bits corrected, status[1] =
+ *      max |new - old| (the measured error of pass 1 on the rows that matter; the caller checks it against tau).
+ *   If the pass-1 error is below tau at every vertex, the result equals gs_sdf_mlp_fwd_h2's in every sign and at both end
+ *   points of every sign-crossing edge -- all the reference consumes (gshell_tets.py:250, :277-290; gshell_tets_geometry.py:33-39). */
+int gs_sdf_mlp_fwd_h1(const float* x, int64_t N, const void* packed, int n_freq, int n_hidden,
+                      int skip_layer, float* out, uint64_t* occ_bits, uint32_t* status, gs_stream_t stream);
+int gs_sdf_mlp_h2_refine_rows(const float* x, const int32_t* rows, int64_t cap, const int64_t* count_dev,
+                              const void* packed, int n_freq, int n_hidden, int skip_layer, float* out,
+                              uint64_t* occ_bits, uint32_t* status, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * SDF network, gradients   (replaces autograd through geometry/mlp.py:32-40 as used by
