@@ -112,7 +112,9 @@ def main():
     # this rank's views of every global batch: ids [it*B + r, it*B + r + world, ...]
     n_iters = a.warmup + a.steps
     targets = [workload.make_targets(trainer, [(it * B_global + v) % 72 for v in shard.local_views(B_global)], (H, W)) for it in range(min(n_iters, 4))]
-    _lib.enable_op_timing(True)
+    # HIP events on the launch stream around the C-ABI calls: by default only around the candidates for the dominant kernel
+    # (~10 event pairs per step); --op-times brackets every entry point (~250 pairs per step, taxes the headline slightly)
+    _lib.enable_op_timing(True, only=None if a.op_times else ROOFLINE_CANDIDATES)
 
     def barrier():
         torch.cuda.synchronize()
@@ -142,6 +144,9 @@ def main():
         early = {"schedule_it": 0, "steps": a.early_steps, "ms_per_step": round(dt0 / a.early_steps * 1e3, 3),
                  "value": round(B_global * H * W * a.early_steps / dt0 / 1e6, 4), "bilateral_radius": 2 * math.ceil(2.5 * trainer.denoiser.sigma) + 1 if trainer.denoiser else None}
     dt, op_times = timed(a.schedule_it, a.warmup, a.steps)
+    from gshell_amd.geometry import mlp as _mlp
+    if _mlp.FALLBACKS:
+        raise SystemExit(f"bench.py: the SDF network left the HIP kernels during the run ({_mlp.FALLBACKS}); no number is reported for a torch path")
     if rank == 0:
         g = trainer.geometry
         N, Ftets = g.verts.shape[0], g.indices.shape[0]
@@ -149,11 +154,15 @@ def main():
         ms = dt / a.steps * 1e3
         mpix = B_global * H * W * a.steps / dt / 1e6
         out = {
-            "metric": "train iters/sec + rendered Mpixels/sec, tet-res256 @512², batch=4",
+            "metric": (f"train iters/sec + rendered Mpixels/sec, tet-res{a.res} @{H}², batch={B_global}" if a.geometry == "tets" else
+                       f"train iters/sec + rendered Mpixels/sec, G-FlexiCubes res{a.res} @{H}², batch={B_global}"),
             "value": round(mpix, 4), "unit": "Mpixels/s", "iters_per_sec": round(a.steps / dt, 4),
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "strong" if a.global_batch is not None else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32 (SDF-network GEMMs: fp16-pair operands = 2^-22, fp32 accumulate; its full-grid forward first as a one-product fp16 pass, "
+                     "rows near the surface re-evaluated with the pair arithmetic)" if a.geometry == "tets" else "f32",
+            "data": "synthetic",
             "config": {"workload": f"{'G-FlexiCubes res' if a.geometry == 'flexicubes' else 'tet-res'}{a.res} ({'voxel grid' if a.geometry == 'flexicubes' else 'BCC'} {N} verts / {Ftets} cells), {B_local} views/GPU x {H}x{W}, n_samples={a.n_samples} "
                                    f"({2 * a.n_samples ** 2} shadow rays/px/pass), full train iteration fwd+bwd+3xAdam",
                        "global_batch": B_global, "views_per_gpu": B_local, "schedule_it": a.schedule_it,
@@ -167,10 +176,12 @@ def main():
             out["data"] = "synthetic; PLUMBING TEST: all ranks share one device over gloo (GSHELL_BENCH_SAME_DEVICE=1) -- not a performance number"
         # rows THIS rank pushes through the SDF-network kernel (the grid rows are sharded over the ranks of a multi-GPU job)
         N_mlp = -(-N // world) if (world > 1 and getattr(trainer.FLAGS, 'shard_mlp_rows', False)) else N
-        roof = roofline(op_times, N_mlp, Ftets, V_aug, T, B_local, H, W, a.n_samples)
-        if roof:
-            out["roofline"] = roof
-        out["hbm_kernels"] = hbm_kernels(op_times, N, Ftets, V_aug, T, B_local, H, W)
+        roofs = rooflines(op_times, N_mlp, Ftets, V_aug, T, B_local, H, W, a.n_samples, trainer)
+        if roofs:
+            out["roofline"] = roofs[0]                      # the dominant hand-written kernel family by HIP-event time
+            out["roofline_others"] = roofs[1:]
+        if a.op_times:
+            out["hbm_kernels"] = hbm_kernels(op_times, N, Ftets, V_aug, T, B_local, H, W)
         if a.op_times:
             out["op_ms"] = {k: round(v["ms"], 4) for k, v in sorted(op_times.items(), key=lambda kv: -kv[1]["ms"] * kv[1]["n"])}
             out["op_calls_per_step"] = {k: v["n"] / a.steps for k, v in op_times.items()}
@@ -184,10 +195,14 @@ def main():
         dist.destroy_process_group()
 
 
+ROOFLINE_CANDIDATES = {"gs_env_shade_fwd", "gs_sdf_mlp_fwd_h1", "gs_sdf_mlp_fwd_h2", "gs_sdf_mlp_fwd", "gs_sdf_mlp_h2_refine_rows", "gs_mtets_flag_refine_rows",
+                       "gs_env_shade_bwd_saved", "gs_hashgrid_encode_bwd", "gs_sdf_mlp_h2_wgrad", "gs_sdf_mlp_h2_bwd", "gs_flexi_vd_bwd", "gs_flexi_vd_fwd"}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_traffic.json; collected with
     rocprofv3 --pmc in separate runs, corrected as MI355X_MICROARCH.md prescribes) -- None if not measured."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return float(json.load(f)[kernel]["bytes"])
@@ -233,11 +248,20 @@ def hbm_kernels(op_times, N, Ftets, V_aug, T, B, H, W):
     return sorted(out, key=lambda r: -r["ms"])
 
 
-def roofline(op_times, N, Ftets, V_aug, T, B, H, W, n):
-    """Roofline of the dominant hand-written kernel family of the iteration (HIP events around its C-ABI launch)."""
+def rooflines(op_times, N, Ftets, V_aug, T, B, H, W, n, trainer):
+    """Roofline records of the hand-written kernel families, the dominant one (by HIP-event time per step) first."""
     if not op_times:
-        return None
-    name, rec = max(op_times.items(), key=lambda kv: kv[1]["ms"] * kv[1]["n"])
+        return []
+    fams = sorted(op_times.items(), key=lambda kv: -kv[1]["ms"] * kv[1]["n"])
+    recs = []
+    for name, rec in fams[:4]:
+        r = roofline_of(name, rec, op_times, N, Ftets, V_aug, T, B, H, W, n, trainer)
+        if r:
+            recs.append(r)
+    return recs
+
+
+def roofline_of(name, rec, op_times, N, Ftets, V_aug, T, B, H, W, n, trainer):
     npix = B * H * W
     if name == "gs_sdf_mlp_fwd":
         # fp32 MFMA roofline: 2 * (39*256 + 5*256*256 + 295*256 + 256) = 826 880 flop per grid vertex (DESIGN.md section 2)
@@ -246,40 +270,65 @@ def roofline(op_times, N, Ftets, V_aug, T, B, H, W, n):
         return {"kernel": "k_sdf_mlp_fwd (gs_sdf_mlp_fwd)", "bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
                 "frac": round(tf / 157.3, 4), "traffic": pmc_traffic("k_sdf_mlp_fwd") if N == 2282489 else None, "avg_launch_ms": round(rec["ms"], 4), "algorithmic_flops": flops,
                 "note": "fp32-in/fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32); HBM traffic is 16 B/vertex by construction"}
-    if name == "gs_sdf_mlp_fwd_h2":
-        # f16 matrix path with fp16-pair operands: 826 880 ALGORITHMIC flop per grid vertex (what the network defines); the kernel
-        # executes 3 MFMA products per algorithmic product over K padded to 16 (48 + 5 x 256 + 304 input columns x 256 outputs)
+    if name in ("gs_sdf_mlp_fwd_h2", "gs_sdf_mlp_fwd_h1"):
+        # 826 880 ALGORITHMIC flop per grid vertex (what the network defines) over K padded to 16 (48 + 5 x 256 + 304 input columns x
+        # 256 outputs); h2 executes 3 MFMA products per algorithmic product, h1 (first pass of the two-pass forward) one
+        prods = 3 if name.endswith("h2") else 1
         flops = 826880.0 * N
-        executed = 2.0 * 256 * (48 + 5 * 256 + 304) * 3 * N
+        executed = 2.0 * 256 * (48 + 5 * 256 + 304) * prods * N
         tf = flops / (rec["ms"] * 1e-3) / 1e12
-        return {"kernel": "k_h2_fwd<GRID> (gs_sdf_mlp_fwd_h2)", "bound": "mfma", "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": round(tf / 2500.0, 4), "traffic": pmc_traffic("k_h2_fwd") if N == 2282489 else None, "rows_per_launch": int(N), "avg_launch_ms": round(rec["ms"], 4),
-                "algorithmic_flops": flops, "executed_mfma_flops": executed, "executed_TFLOPs": round(executed / (rec["ms"] * 1e-3) / 1e12, 1),
-                "executed_frac_of_f16_peak": round(executed / (rec["ms"] * 1e-3) / 1e12 / 2500.0, 4), "vs_fp32_mfma_peak_157.3": round(tf / 157.3, 3),
-                "note": "v_mfma_f32_32x32x16_f16, operands = fp16 pairs (2^-22), fp32 accumulate; three products per algorithmic product; "
-                        "the exact-fp32 MFMA kernel it replaces (csrc/mlp.hip) ran at 0.74 of the 157.3 TFLOP/s fp32 roofline"}
+        out = {"kernel": "k_h2_fwd<GRID> (gs_sdf_mlp_fwd_h2)" if prods == 3 else "k_h1_fwd (gs_sdf_mlp_fwd_h1)", "bound": "mfma", "achieved": round(tf, 2),
+               "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": pmc_traffic("k_h2_fwd" if prods == 3 else "k_h1_fwd") if N == 2282489 else None,
+               "rows_per_launch": int(N), "avg_launch_ms": round(rec["ms"], 4), "algorithmic_flops": flops, "executed_mfma_flops": executed,
+               "executed_TFLOPs": round(executed / (rec["ms"] * 1e-3) / 1e12, 1), "executed_frac_of_f16_peak": round(executed / (rec["ms"] * 1e-3) / 1e12 / 2500.0, 4),
+               "note": "v_mfma_f32_32x32x16_f16, fp32 accumulate; " + ("operands = fp16 pairs (2^-22): three products per algorithmic product" if prods == 3 else
+                       "ONE fp16 product per algorithmic product over every grid row; the rows whose value can matter are re-evaluated by gs_sdf_mlp_h2_refine_rows")}
+        if prods == 1:
+            ref = op_times.get("gs_sdf_mlp_h2_refine_rows", {"ms": 0.0})["ms"] + op_times.get("gs_mtets_flag_refine_rows", {"ms": 0.0})["ms"]
+            net = trainer.geometry.sdf_net if hasattr(trainer.geometry, "sdf_net") else None
+            out["two_pass"] = {"refine_ms": round(ref, 4), "whole_forward_ms": round(rec["ms"] + ref, 4),
+                               "whole_forward_algorithmic_TFLOPs": round(flops / ((rec["ms"] + ref) * 1e-3) / 1e12, 1),
+                               "max_dev_one_product_on_refined_rows": None if net is None else net.__dict__.get("_gs_two_pass_maxdev")}
+        return out
+    if name == "gs_env_shade_fwd":
+        # Monte-Carlo environment shading forward = k_shade_samples + k_shade_trace + k_shade_accumulate; the shadow-ray traversal is
+        # latency / issue bound (no RT units on CDNA4): the HBM figure is reported for the record, rays/s is the figure of merit
+        from gshell_amd.render import optixutils as _ou
+        n_cov = _ou.last_covered_pixels
+        rays = None if n_cov is None else n_cov * 2 * n * n
+        alg = npix * (4 + 6 * 12 + 24) + (rays or 0) * 40
+        gbps = alg / (rec["ms"] * 1e-3) / 1e9
+        out = {"kernel": "gs_env_shade_fwd (k_shade_samples + k_shade_trace + k_shade_accumulate)", "bound": "hbm", "achieved": round(gbps, 2), "peak": 8000.0,
+               "unit": "GB/s", "frac": round(gbps / 8000.0, 5), "traffic": pmc_traffic("gs_env_shade_fwd"), "avg_launch_ms": round(rec["ms"], 4),
+               "algorithmic_bytes": int(alg), "covered_pixels": n_cov, "shadow_rays": rays,
+               "rays_per_s": None if not rays else round(rays / (rec["ms"] * 1e-3) / 1e9, 3),
+               "note": "software BVH any-hit traversal: latency / instruction-issue bound, not an HBM stream; G rays/s over the whole family "
+                       "(sampling + traversal + accumulation); node / triangle visits per ray: profiles/r03_bvh_stats.json"}
+        return out
     alg = algorithmic_bytes(N, Ftets, V_aug, T, B, H, W).get(name)
     if alg is None:
         return {"kernel": name, "bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
                 "avg_launch_ms": round(rec["ms"], 4)}
     gbps = alg / (rec["ms"] * 1e-3) / 1e9
     return {"kernel": name, "bound": "hbm", "achieved": round(gbps, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 5), "traffic": None,
-            "avg_launch_ms": round(rec["ms"], 4), "algorithmic_bytes": int(alg),
-            "note": "ray-traversal kernels are latency/ALU bound; rays/s reported in DESIGN.md"}
+            "avg_launch_ms": round(rec["ms"], 4), "algorithmic_bytes": int(alg)}
 
 
 def cpu_baseline(res=256):
     """CPU numbers of the reference formulation on this box's host cores (reported, not the target):
-      value    end-to-end forward + backward of the oracle pipeline on a bounded sample (numpy brute-force shadow rays make the
-               config size infeasible on a CPU: 20 M rays x 2.3 10^5 triangles per pass)
-      stages   the stages whose reference formulation DOES run at the config size on a CPU: the SDF network over all grid rows
+      value    end-to-end forward + backward of the oracle pipeline on BASELINE.json configs[0] -- tet-res64 (BCC 26: 202 800 tets),
+               1 view 256 x 256, 1 MC light sample (2 shadow rays / pixel), constant kd / ks -- the reference's own CPU-runnable
+               case.  ~15-20 s of CPU work.  The headline config itself (20 M shadow rays x 2.3 10^5 triangles
+               per pass, brute force) is infeasible on a CPU.
+      stages   the stages whose reference formulation DOES run at the HEADLINE size on a CPU: the SDF network over all grid rows
                (geometry/mlp.py module, torch CPU) and the G-MarchingTets extraction (torch.unique per call + gathers, as
                geometry/gshell_tets.py:266-276 does) on the tet-res256 grid."""
     try:
         from oracle import pipeline_oracle
     except Exception as e:           # pragma: no cover
         return {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
-    out = pipeline_oracle.timed_sample()
+    out = pipeline_oracle.timed_sample(cells=26, res=(256, 256), n_samples=1, constant_kd=True)
+    out["config"] = "BASELINE.json configs[0]: tet-res64, 1 view 256x256, 1 MC light sample, constant kd"
     try:
         out["stages"] = cpu_stage_times(res)
     except Exception as e:           # pragma: no cover

@@ -81,7 +81,7 @@ def stream():
 
 
 # ---- optional per-op timing (bench.py): HIP events recorded on the launch stream around each C-ABI call -------------
-_timing = {"on": False, "pending": [], "done": {}}
+_timing = {"on": False, "only": None, "pending": [], "done": {}}
 
 
 class _TimedLib:
@@ -94,6 +94,8 @@ class _TimedLib:
     def __getattr__(self, name):
         fn = getattr(self._real, name)
         if not _timing["on"] or not name.startswith("gs_") or name.endswith(("_bytes", "_partials", "_params", "_info", "_create", "_destroy", "_padded", "_words", "last_error", "version")):
+            return fn
+        if _timing["only"] is not None and name not in _timing["only"]:
             return fn
 
         def timed(*args):
@@ -114,8 +116,11 @@ def lib():      # noqa: F811  (wraps the loader defined above)
     return _TimedLib(real) if _timing["on"] else real
 
 
-def enable_op_timing(flag):
+def enable_op_timing(flag, only=None):
+    """only: a set of entry-point names -- nothing else is bracketed with events (bench.py's default run times just the candidates
+    for the dominant kernel; --op-times times everything)"""
     _timing["on"] = bool(flag)
+    _timing["only"] = None if only is None else set(only)
 
 
 def reset_op_timing():

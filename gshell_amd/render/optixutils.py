@@ -80,6 +80,7 @@ def set_random_perm(n_samples_x, table):
     _random_perm[(n_samples_x, str(table.device))] = table.int().contiguous()
 
 
+last_covered_pixels = None      # covered pixels of the last optix_env_shade call (bench.py: rays per second)
 SAVED_SAMPLES = True      # backward from the forward pass's saved ray buffer (gs_env_shade_bwd_saved) instead of replaying the sampler
 
 
@@ -110,6 +111,8 @@ class _optix_env_shade_func(torch.autograd.Function):
             return t.detach().expand(full).contiguous().float()
         # covered pixels, ascending (one host sync for the count, like the reference's mask-dependent launches)
         pix = torch.nonzero(mask.detach().expand(B, H, W).reshape(-1) > 0).reshape(-1).int()
+        global last_covered_pixels
+        last_covered_pixels = int(pix.shape[0])
         t = dict(ro=c3(ro), pos=c3(gb_pos), nrm=c3(gb_normal), kd=c3(gb_kd), ks=c3(gb_ks))
         if tuple(gb_view_pos.shape) not in ((B, 1, 1, 3), (1, 1, 1, 3)):
             raise _lib.GShellHipError(f"gb_view_pos must be [B,1,1,3] (one eye per view), got {tuple(gb_view_pos.shape)}")

@@ -37,6 +37,17 @@ class TextureOracle:
         return out.reshape(*texc.shape[:-1], -1)
 
 
+class ConstantTextureOracle:
+    """BASELINE.json configs[0] "constant kd": an object whose .sample(pos) returns a constant [..., 6] (duck-types
+    render/mlptexture.py:87)."""
+
+    def __init__(self, value):
+        self.value = value            # [6] kd rgb, ks (o, roughness, metalness); may require grad
+
+    def sample(self, texc):
+        return self.value.expand(*texc.shape[:-1], 6) + 0.0 * texc[..., :1]
+
+
 def render_mesh(v_pos, faces, v_nrm, msdf, mvp, campos, light, background, noise, texture, n_samples, seed, shadow_scale, perms, bsdf='pbr',
                 denoise_sigma=None, resolution=(32, 32)):
     """All tensors torch CPU float32.  faces [T,3] long.  noise = {'jitter','texture','tangent'} as drawn by the product.
@@ -108,7 +119,7 @@ def render_mesh(v_pos, faces, v_nrm, msdf, mvp, campos, light, background, noise
     return out
 
 
-def timed_sample(cells=16, res=(64, 64), n_samples=4, seed=0):
+def timed_sample(cells=16, res=(64, 64), n_samples=4, seed=0, constant_kd=False):
     """CPU baseline for bench.py: ONE forward + backward pass of the oracle pipeline (extraction -> normals -> raster ->
     interpolate -> hash-grid texture -> MC shading with brute-force shadow rays -> bilateral -> composite/antialias ->
     image loss) on a bounded sample of the workload, single process, torch/numpy on the host cores."""
@@ -136,6 +147,8 @@ def timed_sample(cells=16, res=(64, 64), n_samples=4, seed=0):
                (torch.randn(6, 32, generator=gen) * 0.3).requires_grad_(True)]
     tex = TextureOracle((torch.tensor([-1.0, -1, -1]), torch.tensor([1.0, 1, 1])), cfg, params, weights, torch.tensor([0, 0, 0, 0, 0.001, 0]),
                         torch.tensor([1, 1, 1, 0, 1.0, 1]))
+    if constant_kd:
+        tex = ConstantTextureOracle(torch.tensor([0.7, 0.55, 0.4, 0.0, 0.5, 0.1], requires_grad=True))
     light = torch.full((32, 64, 3), 0.5, requires_grad=True)
     perms = torch.argsort(torch.rand(256, n_samples * n_samples, generator=gen), dim=-1).int().numpy()
     bg = torch.rand(1, H, W, 3, generator=gen)
@@ -147,5 +160,6 @@ def timed_sample(cells=16, res=(64, 64), n_samples=4, seed=0):
     dt = time.perf_counter() - t_start
     mpix = H * W / dt / 1e6
     return {"value": round(mpix, 8), "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle pipeline fwd+bwd, 1 view {H}x{W}, BCC {cells} cells ({tets.shape[0]} tets, {f.shape[0]} faces), n_samples={n_samples} "
+            "sample": f"oracle pipeline fwd+bwd, 1 view {H}x{W}, BCC {cells} cells ({tets.shape[0]} tets, {f.shape[0]} faces), "
+                      f"{'constant kd/ks' if constant_kd else 'hash-grid texture'}, n_samples={n_samples} "
                       f"({2 * n_samples ** 2} brute-force shadow rays/px), bilateral sigma 1, {dt:.1f} s wall"}
