@@ -1,0 +1,28 @@
+#!/bin/bash
+# SQ / LDS / L1 counters of one kernel run by a small python script (separate rocprofv3 --pmc passes).  GPU box.
+#   usage: tools/pmc_script.sh <tag> <kernel-substring> <script.py> [args]     -> gpurun_out/pmc_<tag>/*.stdout
+tag="$1"; sub="$2"; shift 2
+root="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+out="$root/gpurun_out/pmc_$tag"; rm -rf "$out"; mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+pass() {
+  p="$1"; shift
+  timeout 200 rocprofv3 --pmc "$@" --kernel-trace -d "$out/$p" -o r --output-format csv -- python "$root/$SCRIPT" $SARGS > "$out/$p.log" 2>&1 </dev/null
+  f=$(find "$out/$p" -name "*counter_collection.csv" | head -1)
+  python - "$f" "$sub" > "$out/$p.stdout" <<'PY'
+import csv, sys, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in csv.DictReader(open(sys.argv[1])):
+    if sys.argv[2] in r["Kernel_Name"]:
+        agg[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+if agg:
+    d = max(agg)
+    print(d, dict(agg[d]))
+PY
+  cat "$out/$p.stdout"
+  find "$out/$p" -name "*.csv" -delete
+}
+SCRIPT="$1"; shift; SARGS="$@"
+pass sq1 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU
+pass sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+pass sq3 SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAVES SQ_INSTS_SALU SQ_WAIT_INST_VALU SQ_ACTIVE_INST_MISC
