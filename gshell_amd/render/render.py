@@ -37,21 +37,32 @@ class NoiseStream:
         self.seed, self.rank, self.world, self.it = int(seed), int(rank), int(world), 0
         self.global_batch = None          # views of the global batch (None: local views x world)
         self._gens = {}
+        self._calls = {}                  # draws of each name within the current iteration
 
     def set_iteration(self, it, global_batch=None):
         self.it = int(it)
         self.global_batch = None if global_batch is None else int(global_batch)
+        self._calls = {}
 
     def generator(self, name, device):
+        """Seeded by (seed, iteration, name, how often this name has been drawn in this iteration): the second render of an
+        iteration (use_img_2nd_layer, every view of validate()) gets FRESH noise, like the reference's draws from the global RNG
+        (render.py:55, :68, :265), and all ranks -- which issue the same call sequence -- still agree."""
         g = self._gens.get(str(device))
         if g is None:
             g = self._gens[str(device)] = torch.Generator(device=device)
-        g.manual_seed((self.seed * 1000003 + self.it) * 16 + self._IDS[name])
+        k = self._calls.get(name, 0)
+        self._calls[name] = k + 1
+        g.manual_seed(((self.seed * 1000003 + self.it) * 4099 + k) * 16 + self._IDS[name])
         return g
 
     def normal(self, name, std, size, device):
         """[B_local, ...] = this rank's rows (views rank, rank + world, ...) of the [B_global, ...] global-batch draw."""
         B = self.global_batch if self.global_batch is not None else size[0] * self.world
+        if self.world > 1 and -(-B // self.world) != size[0] and B // self.world != size[0]:
+            # a render outside the training step's batch (validate(): one view at a time after step(global_batch=G)): every rank
+            # renders `size[0]` views of its own, i.e. a global batch of size[0] * world
+            B = size[0] * self.world
         full = torch.randn((B,) + tuple(size[1:]), device=device, generator=self.generator(name, device))
         if self.world > 1:
             full = full[self.rank::self.world]

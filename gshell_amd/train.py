@@ -237,8 +237,8 @@ class Trainer:
         if enc.grad is not None:
             enc.grad /= 8.0                                            # train script :435
         if self.FLAGS.clip_max_norm > 0.0:                            # train script :440-444 (after the all-reduce: global gradient)
-            torch.nn.utils.clip_grad_norm_(self.geometry.parameters(), self.FLAGS.clip_max_norm)
-            torch.nn.utils.clip_grad_norm_(self.mat_params, self.FLAGS.clip_max_norm)
+            # ONE joint norm over geometry + material parameters, as the reference's clip_grad_norm_(geometry.parameters() + params)
+            torch.nn.utils.clip_grad_norm_(list(self.geometry.parameters()) + list(self.mat_params), self.FLAGS.clip_max_norm)
         self.opt_mat.step(); self.scheds[0].step()
         self.opt_mesh.step(); self.scheds[1].step()
         self.opt_light.step(); self.scheds[2].step()

@@ -151,6 +151,29 @@ def test_env_shade_backward_from_saved_samples_equals_the_replayed_sampler(bsdf,
     assert float((a[6] - b[6]).abs().max()) <= 1e-5 * float(b[6].abs().max())
 
 
+def test_env_shade_second_backward_through_a_retained_graph_equals_the_first():
+    """The forward pass's ray buffer is consumed (overwritten in place) by the first backward pass; a second backward through a
+    retained graph falls back to the replaying kernel and must return the same gradients."""
+    from gshell_amd.render import optixutils as ou
+    B, H, W, n = 1, 32, 32, 4
+    verts, tri, mask, gb_pos, gb_nrm, view, kd, ks = scenes.sheet_gbuffer(B, H, W, 5)
+    gen = torch.Generator().manual_seed(4)
+    light = torch.rand(16, 32, 3, generator=gen) * 2 + 0.05
+    pdf, rows, cols = po.update_pdf(light)
+    wd, ws = torch.rand(B, H, W, 3, generator=gen).to(DEV), torch.rand(B, H, W, 3, generator=gen).to(DEV)
+    ctx = ou.OptiXContext()
+    ou.optix_build_bvh(ctx, torch.tensor(verts, device=DEV), torch.tensor(tri, device=DEV), rebuild=1)
+    dl = [t.to(DEV).requires_grad_(True) for t in (gb_pos, gb_nrm, kd, ks, light)]
+    d, s = ou.optix_env_shade(ctx, mask.to(DEV), (gb_pos + gb_nrm * 0.001).to(DEV), dl[0], dl[1], view.to(DEV), dl[2], dl[3], dl[4], pdf.to(DEV),
+                              rows[:, 0].to(DEV), cols.to(DEV), BSDF="pbr", n_samples_x=n, rnd_seed=5, shadow_scale=1.0)
+    loss = (d * wd).sum() + (s * ws).sum()
+    g1 = torch.autograd.grad(loss, dl, retain_graph=True)
+    g2 = torch.autograd.grad(loss, dl)
+    for name, a, b in zip(("g_pos", "g_nrm", "g_kd", "g_ks"), g1[:4], g2[:4]):
+        assert torch.equal(a, b), name
+    assert float((g1[4] - g2[4]).abs().max()) <= 1e-5 * float(g2[4].abs().max())
+
+
 @pytest.mark.parametrize("sigma,masked", [(2.0, True), (2.0, False), (0.6, True), (4.5, True)])
 def test_bilateral_pair_equals_two_single_passes(sigma, masked):
     """gs_bilateral_*_masked2 (two colour images, shared guides, weights computed once; falls back to two passes when three LDS

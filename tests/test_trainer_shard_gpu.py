@@ -28,7 +28,7 @@ def _grads(trainer):
     return [None if p.grad is None else p.grad.detach().clone() for p in trainer.all_params()]
 
 
-def _worker(rank, world, port, shard_rows, out_q):
+def _worker(rank, world, port, shard_rows, out_q, B=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -36,24 +36,24 @@ def _worker(rank, world, port, shard_rows, out_q):
     from gshell_amd.render import render
     from gshell_amd.train import ViewShard
     shard = ViewShard(rank, world)
-    tr = workload.build(res=RES, n_samples=NS, batch=2, train_res=HW, shard=shard, fit_steps=60, shard_mlp_rows=shard_rows)
+    tr = workload.build(res=RES, n_samples=NS, batch=B, train_res=HW, shard=shard, fit_steps=60, shard_mlp_rows=shard_rows)
     state = [p.detach().clone() for p in tr.all_params()]
     seed0 = render.rnd_seed
     render.rnd_seed = seed0 + 3            # the target renders draw Monte-Carlo samples too: same seed in both runs
-    target = workload.make_targets(tr, shard.local_views(2), HW)
+    target = workload.make_targets(tr, shard.local_views(B), HW)
     render.rnd_seed = seed0 + 7
     tr.it = IT
-    tr.forward_backward(target, global_batch=2)
+    tr.forward_backward(target, global_batch=B)
     g_sharded = _grads(tr)
     result = None
     if rank == 0:      # the single-process iteration over both views, from the same parameters, seed and iteration
-        single = workload.build(res=RES, n_samples=NS, batch=2, train_res=HW, shard=ViewShard(), fit_steps=0)
+        single = workload.build(res=RES, n_samples=NS, batch=B, train_res=HW, shard=ViewShard(), fit_steps=0)
         with torch.no_grad():
             for p, v in zip(single.all_params(), state):
                 p.copy_(v)
         single.lgt.update_pdf()
         render.rnd_seed = seed0 + 3
-        t2 = workload.make_targets(single, [0, 1], HW)
+        t2 = workload.make_targets(single, list(range(B)), HW)
         assert torch.allclose(t2['img'][0], target['img'][0], atol=1e-5) and torch.equal(t2['background'][0], target['background'][0])
         render.rnd_seed = seed0 + 7
         single.it = IT
@@ -73,13 +73,14 @@ def _worker(rank, world, port, shard_rows, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shard_rows", [True, False])
-def test_two_rank_iteration_equals_single_process(shard_rows):
-    world = 2
+@pytest.mark.parametrize("world,B,shard_rows", [(2, 2, True), (2, 2, False), (8, 8, True)])
+def test_sharded_iteration_equals_single_process(world, B, shard_rows):
+    """(8, 8, True) = the partitioning of BASELINE.json configs[3]: 8 ranks, global batch 8 (one view per rank), the grid rows
+    (a count that 8 does not divide) split over the ranks, union visibility -- eight processes on the one device, over gloo."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shard_rows, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shard_rows, q, B)) for r in range(world)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=600) for _ in range(world))

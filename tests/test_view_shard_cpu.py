@@ -82,3 +82,25 @@ def test_view_shard_single_process_is_identity():
     assert s.local_views(4) == [0, 1, 2, 3]
     t = torch.ones(3)
     assert s.all_reduce_sum(t) is t and s.all_reduce_max(t) is t
+
+
+def test_noise_stream_is_fresh_per_draw_rank_consistent_and_survives_a_render_outside_the_training_batch():
+    """render.NoiseStream: (i) a second draw of the same name within an iteration differs from the first (the reference draws from
+    the global RNG, render.py:55, :68, :265), (ii) re-entering the iteration repeats the sequence, (iii) rank r of W sees rows
+    r, r + W, ... of the single-process draw, (iv) a render of one local view after step(global_batch=G) (validate()) works."""
+    from gshell_amd.render.render import NoiseStream
+    single = NoiseStream(seed=5)
+    single.set_iteration(7, global_batch=4)
+    a1 = single.normal('jitter', 1.0, (4, 3, 3, 2), 'cpu')
+    a2 = single.normal('jitter', 1.0, (4, 3, 3, 2), 'cpu')
+    assert not torch.equal(a1, a2)
+    single.set_iteration(7, global_batch=4)
+    assert torch.equal(single.normal('jitter', 1.0, (4, 3, 3, 2), 'cpu'), a1)
+    assert torch.equal(single.normal('jitter', 1.0, (4, 3, 3, 2), 'cpu'), a2)
+    for rank in range(2):
+        ns = NoiseStream(seed=5, rank=rank, world=2)
+        ns.set_iteration(7, global_batch=4)
+        assert torch.equal(ns.normal('jitter', 1.0, (2, 3, 3, 2), 'cpu'), a1[rank::2])
+        assert torch.equal(ns.normal('jitter', 1.0, (2, 3, 3, 2), 'cpu'), a2[rank::2])
+        one = ns.normal('texture', 0.01, (1, 3, 3, 3), 'cpu')          # validate(): one local view although global_batch = 4
+        assert one.shape == (1, 3, 3, 3)
