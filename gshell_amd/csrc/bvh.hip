@@ -212,8 +212,7 @@ __global__ void __launch_bounds__(256) k_pack_nodes(int64_t n_internal, const fl
 
 extern "C" int gs_bvh_create(gs_bvh** out) {
     GS_REQUIRE(out != nullptr, "gs_bvh_create: out is null");
-    gs_bvh* b = new gs_bvh();
-    GS_HIP_CHECK(hipMalloc(&b->bounds, 6 * sizeof(uint32_t)));
+    gs_bvh* b = new gs_bvh();      // no device memory until the first build (the handle can be created before a device is chosen)
     *out = b;
     return 0;
 }
@@ -242,6 +241,7 @@ extern "C" int gs_bvh_build(gs_bvh* b, const float* verts, int64_t V, const int3
     GS_REQUIRE(T >= 0 && T < (1ll << 30), "gs_bvh_build: too many triangles");
     b->T = T;
     if (T == 0) return 0;  // empty meshes are legal (reference: ops.py:134-139)
+    if (!b->bounds) GS_HIP_CHECK(hipMalloc(&b->bounds, 6 * sizeof(uint32_t)));
     GS_REQUIRE(verts && tris && V > 0, "gs_bvh_build: null mesh pointer");
     // shape of the implicit heap: leaf size in 1..4, depth >= 1
     int depth = 1;

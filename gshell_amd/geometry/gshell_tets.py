@@ -29,6 +29,8 @@ class TetTopology:
         if tet_fx4.dtype != torch.int64:
             tet_fx4 = tet_fx4.long()
         tet_fx4 = tet_fx4.contiguous()
+        if not tet_fx4.is_cuda:
+            raise _lib.GShellHipError(f"the tet grid must live in HBM (got device {tet_fx4.device}); the HIP extraction has no CPU fallback")
         self.device = tet_fx4.device
         self.N, self.F = int(num_verts), int(tet_fx4.shape[0])
         self._h = c_void_p(0)

@@ -209,10 +209,17 @@ class GShellTetsGeometry(torch.nn.Module):
 
     @torch.no_grad()
     def generate_edges(self):
-        # sorted unique (min,max) grid edges: the extractor's static topology already holds exactly this list
-        topo = self.gshell_tets.topology(self.indices, self.verts.shape[0])
-        self.all_edges = topo.edges()                      # [E,2] int32, lexicographically sorted unique (min,max)
+        # sorted unique (min,max) grid edges (reference :141-156): the extractor's static topology already holds exactly this
+        # list; it is built on the device at the first use (`all_edges` below), not in the constructor
+        self._all_edges = None
         self.max_displacement = 1.0 / self.grid_res * self.scale / 2.1
+
+    @property
+    def all_edges(self):
+        if self._all_edges is None:
+            with torch.no_grad():
+                self._all_edges = self.gshell_tets.topology(self.indices, self.verts.shape[0]).edges()   # [E,2] int32, sorted unique (min,max)
+        return self._all_edges
 
     @torch.no_grad()
     def getAABB(self):

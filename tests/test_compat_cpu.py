@@ -45,3 +45,26 @@ def test_compat_install_resolves_reference_imports():
     out = subprocess.run([sys.executable, "-c", SCRIPT % ROOT], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "compat ok" in out.stdout
+
+
+def test_the_reference_training_script_runs_against_the_shim_up_to_the_first_hip_call(tmp_path):
+    """train_gshelltet_deepfashion.py itself (from /root/reference, unmodified, as __main__) under gshell_amd.compat on this GPU-less
+    box (tests/ref_script_harness.py: synthetic dataset, `cuda` redirected to the CPU): argument parsing, FLAGS, contexts, trainable
+    env light, denoiser, GShellTetsGeometry(grid, scale, FLAGS) with the SDF-network pre-fit, initial_guess_material, and
+    optimize_mesh (:278-497) -- Adam over the parameter groups picked by NAME, DataLoader + collate, prepare_batch, zero_grad,
+    lgt.update_pdf(), geometry.tick(glctx, target, lgt, opt_material, image_loss_fn, it, denoiser=...) -- all run; the first HIP
+    entry point inside tick -> render -> getMesh then refuses the CPU tensors (no CPU fallback).  Any signature / attribute /
+    state-dict-name mismatch with the reference's call sites would surface earlier as a different exception."""
+    import pytest
+    ref = os.environ.get("GSHELL_REFERENCE_ROOT", "/root/reference")
+    if not os.path.isfile(os.path.join(ref, "train_gshelltet_deepfashion.py")):
+        pytest.skip("reference tree not present (GPU box)")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_script_harness.py"), ref, str(tmp_path)], capture_output=True, text=True, timeout=900)
+    err = out.stderr
+    assert out.returncode != 0
+    assert "GShellHipError" in err and "must live in HBM" in err, err[-3000:]
+    for frame in ("train_gshelltet_deepfashion.py", "in optimize_mesh", "geometry.tick(", "in getMesh"):
+        assert frame in err, (frame, err[-3000:])
+    assert "AttributeError" not in err and "TypeError" not in err
+    # nothing was written into the reference tree (SURVEY.md hazard 1)
+    assert not os.path.exists(os.path.join(ref, "out"))
