@@ -957,6 +957,107 @@ __global__ void __launch_bounds__(256) k_surface_points(const float* __restrict_
     out[3 * i + 2] = a * v0.z + b * v1.z + c * v2.z;
 }
 
+// the face draw folded in: face = first t with cdf[t] > x * cdf[T-1] (cdf = inclusive prefix sum of the areas), x = r[3 i + 2] --
+// the inversion torch.multinomial performs after a 0.12 ms row renormalisation of its own
+__global__ void __launch_bounds__(256) k_surface_points_cdf(const float* __restrict__ v, const int32_t* __restrict__ tri, const float* __restrict__ cdf,
+                                                            int64_t T, const float* __restrict__ r, int64_t n, float* __restrict__ out,
+                                                            int64_t* __restrict__ fid_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = r[3 * i + 2] * cdf[T - 1];
+    int64_t lo = 0, hi = T - 1;                       // smallest t with cdf[t] > x (t = T - 1 if none: x < total always)
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cdf[mid] > x) hi = mid; else lo = mid + 1;
+    }
+    const int64_t t = lo;
+    if (fid_out) fid_out[i] = t;
+    const f3 v0 = ld3(v + 3 * (int64_t)tri[3 * t]), v1 = ld3(v + 3 * (int64_t)tri[3 * t + 1]), v2 = ld3(v + 3 * (int64_t)tri[3 * t + 2]);
+    const float u = sqrtf(r[3 * i]), w = r[3 * i + 1];
+    const float a = 1.0f - u, b = u * (1.0f - w), c = u * w;
+    out[3 * i] = a * v0.x + b * v1.x + c * v2.x;
+    out[3 * i + 1] = a * v0.y + b * v1.y + c * v2.y;
+    out[3 * i + 2] = a * v0.z + b * v1.z + c * v2.z;
+}
+
+// ---- light probe sampling tables (render/light.py:46-59) in ONE launch ------------------------------------------------------
+// pdf = max_c(base) sin(theta_y) / sum;  cols[y] = cumsum_x pdf[y] / its last entry;  rows = cumsum_y (row masses) / total.
+// As torch ops this is 15 launches on a 256 x 256 array before every iteration (train_gshelltet_deepfashion.py:412).  One workgroup:
+// a wave owns a row at a time (lane = W / 64 consecutive columns, wave scan of the lane totals).
+__global__ void __launch_bounds__(1024) k_light_tables(const float* __restrict__ base, int H, int W, float* __restrict__ pdf, float* __restrict__ rows,
+                                                       float* __restrict__ cols) {
+    __shared__ float s_part[16];
+    __shared__ float s_total;
+    __shared__ float s_mass[1024];        // H <= 1024
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int per = (W + 63) / 64;
+    // pass 1: total of w = max_c(base) sin(theta)
+    float acc = 0.f;
+    for (int y = wave; y < H; y += nw) {
+        const float st = sinf(((float)y + 0.5f) / (float)H * 3.14159265358979323846f);
+        for (int k = 0; k < per; ++k) {
+            const int x = lane * per + k;
+            if (x < W) {
+                const float* b = base + ((int64_t)y * W + x) * 3;
+                acc += fmaxf(fmaxf(b[0], b[1]), b[2]) * st;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) s_part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < nw; ++w) t += s_part[w];
+        s_total = t;
+    }
+    __syncthreads();
+    const float total = s_total;
+    // pass 2: pdf, per-row inclusive scan, row masses
+    for (int y = wave; y < H; y += nw) {
+        const float st = sinf(((float)y + 0.5f) / (float)H * 3.14159265358979323846f);
+        float run = 0.f;
+        for (int k = 0; k < per; ++k) {
+            const int x = lane * per + k;
+            if (x < W) {
+                const float* b = base + ((int64_t)y * W + x) * 3;
+                const float p = fmaxf(fmaxf(b[0], b[1]), b[2]) * st / total;
+                pdf[(int64_t)y * W + x] = p;
+                run += p;
+            }
+        }
+        float inc = run;                                  // inclusive scan of the lane totals
+        for (int o = 1; o < 64; o <<= 1) {
+            const float t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        const float mass = __shfl(inc, 63, 64);
+        const float inv = mass > 0.f ? mass : 1.0f;
+        float c = inc - run;
+        for (int k = 0; k < per; ++k) {
+            const int x = lane * per + k;
+            if (x < W) {
+                c += pdf[(int64_t)y * W + x];
+                cols[(int64_t)y * W + x] = c / inv;
+            }
+        }
+        if (lane == 0) s_mass[y] = mass;
+    }
+    __syncthreads();
+    // pass 3: CDF of the row masses (sequential over <= 1024 rows by one lane: 1 microsecond), broadcast over x
+    if (threadIdx.x == 0) {
+        float c = 0.f;
+        for (int y = 0; y < H; ++y) {
+            c += s_mass[y];
+            s_mass[y] = c;
+        }
+        s_total = c;
+    }
+    __syncthreads();
+    const float tot = s_total > 0.f ? s_total : 1.0f;
+    for (int64_t i = threadIdx.x; i < (int64_t)H * W; i += blockDim.x) rows[i] = s_mass[i / W] / tot;
+}
+
 // ---- mSDF open / close regularisers (gshell_tets_geometry.py:326-358) -----------------------------------------------
 // Huber (delta = 1) distance of the clamped mSDF values to -eps (all N grid values, "open") / +eps (the boundary vertices of
 // triangles some view saw, "close").  As ATen ops: clamp, expand, huber_loss, mul, sum per term plus the visibility mask
@@ -1083,6 +1184,23 @@ extern "C" int gs_tri_area(const float* v_pos, const int32_t* tri, int64_t T, fl
     if (T == 0) return 0;
     GS_REQUIRE(v_pos && tri && area, "gs_tri_area: null pointer");
     hipLaunchKernelGGL(k_tri_area, dim3((unsigned)gs::cdiv(T, 256)), dim3(256), 0, (hipStream_t)stream, v_pos, tri, T, area);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_surface_points_cdf(const float* v_pos, const int32_t* tri, const float* area_cdf, int64_t T, const float* r01x3, int64_t n, float* out,
+                                     int64_t* face_id, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_REQUIRE(v_pos && tri && area_cdf && r01x3 && out && T > 0, "gs_surface_points_cdf: null pointer / empty mesh");
+    hipLaunchKernelGGL(k_surface_points_cdf, dim3((unsigned)gs::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, v_pos, tri, area_cdf, T, r01x3, n, out, face_id);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_light_tables(const float* base, int64_t H, int64_t W, float* pdf, float* rows, float* cols, gs_stream_t stream) {
+    GS_REQUIRE(base && pdf && rows && cols, "gs_light_tables: null pointer");
+    GS_REQUIRE(H >= 1 && H <= 1024 && W >= 1, "gs_light_tables: probe height must be in 1..1024");
+    hipLaunchKernelGGL(k_light_tables, dim3(1), dim3(1024), 0, (hipStream_t)stream, base, (int)H, (int)W, pdf, rows, cols);
     GS_LAUNCH_CHECK();
     return 0;
 }

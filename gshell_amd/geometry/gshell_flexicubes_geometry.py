@@ -48,7 +48,7 @@ class GShellFlexiCubesGeometry(GShellTetsGeometry):
     def generate_edges(self):
         topo = self.gflexicubes.topology(self.indices, self.verts.shape[0], self.grid_res)
         e = topo.edges.long()
-        self.all_edges = torch.sort(e, dim=1).values.int().contiguous()      # unique (min,max) grid edges (reference :124-127)
+        self._all_edges = torch.sort(e, dim=1).values.int().contiguous()     # unique (min,max) grid edges (reference :124-127); read through the base class property `all_edges`
         self.max_displacement = util.length(self.verts[e[:, 0]] - self.verts[e[:, 1]]).mean() / 4
 
     def getMesh(self, material, _training=False):

@@ -479,6 +479,15 @@ int gs_texmlp_bwd_rows(const float* x_level_major, const int32_t* rows, const in
  *     (u, v) = (sqrt(r01[i,0]), r01[i,1]).
  * ---------------------------------------------------------------------------------- */
 int gs_tri_area(const float* v_pos, const int32_t* tri, int64_t T, float* area, gs_stream_t stream);
+/* ... with the face draw folded in: area_cdf [T] = inclusive prefix sum of gs_tri_area's output, r01x3 [n,3] uniform numbers
+ * (u, v, face); face = first t with cdf[t] > r * cdf[T-1]; face_id [n] int64 WRITTEN (may be NULL). */
+int gs_surface_points_cdf(const float* v_pos, const int32_t* tri, const float* area_cdf, int64_t T,
+                          const float* r01x3, int64_t n, float* out, int64_t* face_id, gs_stream_t stream);
+/* EnvironmentLight.update_pdf (render/light.py:46-59) in one launch: base [H,W,3] -> pdf [H,W] = max_c(base) sin(theta) / sum,
+ * cols [H,W] = per-row CDF over the columns, rows [H,W] = CDF of the row masses (constant along x; the shader reads rows[:,0]).
+ * H <= 1024. */
+int gs_light_tables(const float* base, int64_t H, int64_t W, float* pdf, float* rows, float* cols,
+                    gs_stream_t stream);
 int gs_surface_points(const float* v_pos, const int32_t* tri, const int64_t* face_id, const float* r01,
                       int64_t n, float* out, gs_stream_t stream);
 

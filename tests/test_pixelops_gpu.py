@@ -323,9 +323,9 @@ def test_msdf_regularisers_match_the_reference_formulation(N, nb, T):
 
 
 def test_surface_sampling_kernels_match_the_torch_formulation():
-    """gs_tri_area / gs_surface_points vs geometry.sample_points' torch expressions: areas 1e-6 relative (degenerate and non-finite
-    triangles included), points 1e-6 for the same face ids and random numbers; and the product function draws from the generator
-    exactly like the torch formulation (same multinomial / rand calls), so ranks of a view-sharded job agree."""
+    """gs_tri_area / gs_surface_points_cdf vs torch expressions: areas 1e-6 relative (degenerate and non-finite triangles included),
+    face ids = the inversion of the area CDF at the drawn numbers, points 1e-6; the draw consumes the generator deterministically
+    (ranks of a view-sharded job agree) and faces come out in proportion to their area."""
     from gshell_amd import _lib
     from gshell_amd._lib import c_int64, check, ptr, stream
     from gshell_amd.geometry.gshell_tets_geometry import sample_points, sample_points_detached
@@ -347,8 +347,24 @@ def test_surface_sampling_kernels_match_the_torch_formulation():
     tri_ok = tri[ok_tri].contiguous()
     gen_a, gen_b = torch.Generator(device="cuda").manual_seed(5), torch.Generator(device="cuda").manual_seed(5)
     pts_a, fid_a = sample_points_detached(vf, tri_ok, n, generator=gen_a)
-    pts_b, fid_b = sample_points(vf, tri_ok.long(), n, generator=gen_b)
-    same = fid_a == fid_b                                  # an ulp in an area can move a draw to the neighbouring face
+    # the product draws r = rand(n, 3) = (u, v, face) from the generator and inverts the area CDF in the kernel: replay it with torch ops
+    r = torch.rand(n, 3, device="cuda", generator=gen_b)
+    a0, a1, a2 = vf[tri_ok[:, 0].long()], vf[tri_ok[:, 1].long()], vf[tri_ok[:, 2].long()]
+    area_ok = torch.linalg.cross(a1 - a0, a2 - a0).norm(dim=-1) + 1e-20
+    cdf = torch.cumsum(area_ok, dim=0)
+    fid_b = torch.searchsorted(cdf, r[:, 2] * cdf[-1], right=True).clamp(max=tri_ok.shape[0] - 1)
+    same = fid_a == fid_b                                  # an ulp in an area / in the scan can move a draw to the neighbouring face
     assert float(same.float().mean()) > 0.999
+    u, w = r[:, 0:1].sqrt(), r[:, 1:2]
+    pts_b = (1 - u) * a0[fid_b] + u * (1 - w) * a1[fid_b] + u * w * a2[fid_b]
     assert torch.allclose(pts_a[same], pts_b[same], rtol=1e-5, atol=1e-6)
     assert torch.equal(torch.rand(3, device="cuda", generator=gen_a), torch.rand(3, device="cuda", generator=gen_b))    # same generator consumption
+    # faces are drawn in proportion to their area (kaolin.ops.mesh.sample_points' contract): 16 groups of faces, 5 sigma
+    grp = torch.arange(tri_ok.shape[0], device="cuda") * 16 // tri_ok.shape[0]
+    share = torch.zeros(16, device="cuda").index_add_(0, grp, area_ok) / area_ok.sum()
+    freq = torch.zeros(16, device="cuda").index_add_(0, grp[fid_a], torch.ones(n, device="cuda")) / n
+    assert float(((freq - share).abs() / (share * (1 - share) / n).sqrt()).max()) < 5.0
+    # the autograd formulation used outside the training path agrees in distribution as well (same contract, torch.multinomial)
+    pts_c, fid_c = sample_points(vf, tri_ok.long(), n, generator=gen_b)
+    freq_c = torch.zeros(16, device="cuda").index_add_(0, grp[fid_c], torch.ones(n, device="cuda")) / n
+    assert float(((freq_c - share).abs() / (share * (1 - share) / n).sqrt()).max()) < 5.0
