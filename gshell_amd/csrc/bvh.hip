@@ -10,10 +10,10 @@
 #include "../../include/gshell_hip.h"
 #include "common.hpp"
 
-#ifndef GS_BVH_LEAF
-#define GS_BVH_LEAF 2   // max triangles per leaf (measured on the res-256 mesh with the first traversal: leaf<=4 -> 25 triangle
-                        // tests / ray, leaf<=2 -> 2.8 tests / ray for 20 % more node visits); the traversal stack encodes <= 2
+#ifndef GS_BVH_HILBERT
+#define GS_BVH_HILBERT 1
 #endif
+// one triangle per leaf (round 1 measured leaf <= 4 -> 25 triangle tests / ray, leaf <= 2 -> 2.8, against 20 % more node visits)
 
 namespace {
 
@@ -103,6 +103,33 @@ __global__ void __launch_bounds__(256) k_morton(const float* __restrict__ v, con
             float ext = fmaxf(hi - lo, 1e-30f);
             q[k] = (uint32_t)fminf(fmaxf((cen[k] - lo) / ext * 1024.0f, 0.0f), 1023.0f);
         }
+#if GS_BVH_HILBERT
+        // Hilbert index instead of the Morton code (Skilling 2004, "Programming the Hilbert curve", axes -> transpose): consecutive
+        // keys are always spatially adjacent, so the equal-count ranges of the implicit heap are compact patches of the surface;
+        // the Z curve's jumps gave ranges with large, overlapping boxes (measured: node visits per shadow ray in profiles/r03_bvh_stats.json)
+        {
+            const uint32_t M = 1u << 9;
+            for (uint32_t Q = M; Q > 1u; Q >>= 1) {
+                const uint32_t P = Q - 1u;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (q[i] & Q) {
+                        q[0] ^= P;
+                    } else {
+                        const uint32_t t = (q[0] ^ q[i]) & P;
+                        q[0] ^= t;
+                        q[i] ^= t;
+                    }
+                }
+            }
+            q[1] ^= q[0];
+            q[2] ^= q[1];
+            uint32_t t = 0u;
+            for (uint32_t Q = M; Q > 1u; Q >>= 1)
+                if (q[2] & Q) t ^= Q - 1u;
+            q[0] ^= t; q[1] ^= t; q[2] ^= t;
+        }
+#endif
         key = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
     }
     keys[t] = key;
@@ -144,35 +171,40 @@ __global__ void __launch_bounds__(256) k_leaves(const float* __restrict__ v, con
             hi[k] += pad;
         }
     }
-    int64_t heap = n_internal + li, parent = (heap - 1) >> 2;
-    int slot = (int)((heap - 1) & 3);
-    float* g = groups + parent * 24;
+    int64_t heap = n_internal + li, parent = (heap - 1) >> 3;
+    int slot = (int)((heap - 1) & 7);
+    float* g = groups + parent * 48;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        g[4 * k + slot] = lo[k];
-        g[12 + 4 * k + slot] = hi[k];
+        g[8 * k + slot] = lo[k];
+        g[24 + 8 * k + slot] = hi[k];
     }
 }
 
-// box of every node at heap level `lvl` (first heap index `first`, `count` nodes) = union of its 4 child slots
+// box of every node at heap level `lvl` (first heap index `first`, `count` nodes) = union of its 8 child slots
 __global__ void __launch_bounds__(256) k_level_up(int64_t first, int64_t count, float* __restrict__ groups) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     int64_t n = first + i;
-    const float* g = groups + n * 24;
+    const float* g = groups + n * 48;
     float lo[3], hi[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        lo[k] = fminf(fminf(g[4 * k], g[4 * k + 1]), fminf(g[4 * k + 2], g[4 * k + 3]));
-        hi[k] = fmaxf(fmaxf(g[12 + 4 * k], g[12 + 4 * k + 1]), fmaxf(g[12 + 4 * k + 2], g[12 + 4 * k + 3]));
+        lo[k] = g[8 * k];
+        hi[k] = g[24 + 8 * k];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            lo[k] = fminf(lo[k], g[8 * k + j]);
+            hi[k] = fmaxf(hi[k], g[24 + 8 * k + j]);
+        }
     }
-    int64_t parent = (n - 1) >> 2;
-    int slot = (int)((n - 1) & 3);
-    float* pg = groups + parent * 24;
+    int64_t parent = (n - 1) >> 3;
+    int slot = (int)((n - 1) & 7);
+    float* pg = groups + parent * 48;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        pg[4 * k + slot] = lo[k];
-        pg[12 + 4 * k + slot] = hi[k];
+        pg[8 * k + slot] = lo[k];
+        pg[24 + 8 * k + slot] = hi[k];
     }
 }
 
@@ -190,22 +222,20 @@ __device__ __forceinline__ uint16_t half_ceil(float x) {
     return c.b;
 }
 
-// fp32 build records (24 floats) -> traversal records (24 halves in a 64-byte slot), one thread per node
+// fp32 build records (48 floats) -> traversal records (48 halves = 6 groups of 16 bytes), one thread per (node, group)
 __global__ void __launch_bounds__(256) k_pack_nodes(int64_t n_internal, const float* __restrict__ groups, uint4* __restrict__ nodes) {
-    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_internal) return;
-    const float* g = groups + n * 24;
-    uint32_t w[12];
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_internal * 6) return;
+    const int grp = (int)(i % 6);                       // 0..2 lo (round down), 3..5 hi (round up)
+    const float* g = groups + (i / 6) * 48 + grp * 8;
+    uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int h0 = 2 * i, h1 = 2 * i + 1;
-        const uint16_t a = h0 < 12 ? half_floor(g[h0]) : half_ceil(g[h0]);
-        const uint16_t b = h1 < 12 ? half_floor(g[h1]) : half_ceil(g[h1]);
-        w[i] = (uint32_t)a | ((uint32_t)b << 16);
+    for (int q = 0; q < 4; ++q) {
+        const uint16_t a = grp < 3 ? half_floor(g[2 * q]) : half_ceil(g[2 * q]);
+        const uint16_t b = grp < 3 ? half_floor(g[2 * q + 1]) : half_ceil(g[2 * q + 1]);
+        w[q] = (uint32_t)a | ((uint32_t)b << 16);
     }
-    nodes[4 * n] = make_uint4(w[0], w[1], w[2], w[3]);
-    nodes[4 * n + 1] = make_uint4(w[4], w[5], w[6], w[7]);
-    nodes[4 * n + 2] = make_uint4(w[8], w[9], w[10], w[11]);
+    nodes[i] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 }  // namespace
@@ -231,7 +261,7 @@ extern "C" int gs_bvh_info(const gs_bvh* b, int64_t* T, int64_t* depth, int64_t*
     if (T) *T = b->T;
     if (depth) *depth = b->depth;
     if (leaf_size) *leaf_size = b->leaf;
-    if (bytes) *bytes = b->n_internal * 64 + b->T * 48;   // what traversal reads
+    if (bytes) *bytes = b->n_internal * 96 + b->T * 48;   // what traversal reads
     return 0;
 }
 
@@ -243,16 +273,16 @@ extern "C" int gs_bvh_build(gs_bvh* b, const float* verts, int64_t V, const int3
     if (T == 0) return 0;  // empty meshes are legal (reference: ops.py:134-139)
     if (!b->bounds) GS_HIP_CHECK(hipMalloc(&b->bounds, 6 * sizeof(uint32_t)));
     GS_REQUIRE(verts && tris && V > 0, "gs_bvh_build: null mesh pointer");
-    // shape of the implicit heap: leaf size in 1..4, depth >= 1
+    // shape of the implicit heap: 8^depth leaf slots >= T, one triangle per leaf, depth >= 1
     int depth = 1;
-    while ((1ll << (2 * depth)) * GS_BVH_LEAF < T) ++depth;
-    int64_t slots = 1ll << (2 * depth);
-    int leaf = (int)gs::cdiv(T, slots);
-    GS_REQUIRE(depth <= BVH_STACK && leaf <= 2, "gs_bvh_build: mesh too large for the traversal stack");
+    while ((1ll << (3 * depth)) < T) ++depth;
+    int64_t slots = 1ll << (3 * depth);
+    GS_REQUIRE(depth <= BVH_STACK, "gs_bvh_build: mesh too large for the traversal stack");
     b->depth = depth;
-    b->leaf = leaf;
-    b->n_leaf = gs::cdiv(T, leaf);
-    b->n_internal = (slots - 1) / 3;
+    b->leaf = 1;
+    b->n_leaf = T;
+    b->n_internal = (slots - 1) / 7;
+    GS_REQUIRE(b->n_internal < (1ll << 24), "gs_bvh_build: too many nodes for the 24-bit node index of a stack entry");
     if (T > b->cap_T) {
         GS_HIP_CHECK(hipStreamSynchronize(stream));
         for (void* p : {(void*)b->tris, (void*)b->tri_id, (void*)b->keys, (void*)b->keys2, (void*)b->vals, (void*)b->vals2, b->sort_tmp}) (void)hipFree(p);
@@ -273,8 +303,8 @@ extern "C" int gs_bvh_build(gs_bvh* b, const float* verts, int64_t V, const int3
         GS_HIP_CHECK(hipStreamSynchronize(stream));
         (void)hipFree(b->groups);
         (void)hipFree(b->nodes);
-        GS_HIP_CHECK(hipMalloc(&b->groups, (size_t)b->n_internal * 96));
-        GS_HIP_CHECK(hipMalloc(&b->nodes, (size_t)b->n_internal * 64));
+        GS_HIP_CHECK(hipMalloc(&b->groups, (size_t)b->n_internal * 192));
+        GS_HIP_CHECK(hipMalloc(&b->nodes, (size_t)b->n_internal * 96));
         b->cap_internal = b->n_internal;
     }
     hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, stream, b->bounds);
@@ -282,13 +312,13 @@ extern "C" int gs_bvh_build(gs_bvh* b, const float* verts, int64_t V, const int3
     hipLaunchKernelGGL(k_morton, dim3((unsigned)gs::cdiv(T, 256)), dim3(256), 0, stream, verts, tris, T, V, b->bounds, b->keys, b->vals);
     size_t tmp = b->sort_tmp_bytes;
     GS_HIP_CHECK(rocprim::radix_sort_pairs(b->sort_tmp, tmp, b->keys, b->keys2, b->vals, b->vals2, (size_t)T, 0, 30, stream));
-    hipLaunchKernelGGL(k_leaves, dim3((unsigned)gs::cdiv(slots, 256)), dim3(256), 0, stream, verts, tris, T, V, b->vals2, leaf, slots, b->n_internal,
+    hipLaunchKernelGGL(k_leaves, dim3((unsigned)gs::cdiv(slots, 256)), dim3(256), 0, stream, verts, tris, T, V, b->vals2, 1, slots, b->n_internal,
                        b->tris, b->tri_id, (float*)b->groups);
     for (int lvl = depth - 1; lvl >= 1; --lvl) {
-        int64_t count = 1ll << (2 * lvl), first = (count - 1) / 3;
+        int64_t count = 1ll << (3 * lvl), first = (count - 1) / 7;
         hipLaunchKernelGGL(k_level_up, dim3((unsigned)gs::cdiv(count, 256)), dim3(256), 0, stream, first, count, (float*)b->groups);
     }
-    hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)gs::cdiv(b->n_internal, 256)), dim3(256), 0, stream, b->n_internal, (const float*)b->groups,
+    hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)gs::cdiv(b->n_internal * 6, 256)), dim3(256), 0, stream, b->n_internal, (const float*)b->groups,
                        b->nodes);
     GS_LAUNCH_CHECK();
     return 0;

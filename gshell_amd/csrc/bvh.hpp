@@ -1,23 +1,28 @@
-// Implicit 4-ary BVH over Morton-sorted triangles (device side: any-hit shadow-ray traversal).
+// Implicit 8-ary BVH over Morton-sorted triangles (device side: any-hit shadow-ray traversal).
 //
 // Replaces the OptiX geometry-acceleration structure the reference rebuilds every iteration
 // (render/optixutils/c_src/torch_bindings.cpp:37-116, called from geometry/gshell_tets_geometry.py:211)
 // and the hardware any-hit query `optixTrace(... TERMINATE_ON_FIRST_HIT ...)`
 // (render/optixutils/c_src/envsampling/kernel.cu:101-117).  CDNA4 has no ray-tracing units, so:
-//   * build  = one 30-bit Morton radix sort of the centroids + a pointer-free complete 4-ary heap:
-//              leaf i owns the sorted triangles [i*leaf, (i+1)*leaf), node n has children 4n+1..4n+4,
-//              so "refit" is D tiny launches of min/max over 4 slots -- no atomics, no fences, no
-//              parent pointers; the whole rebuild is a handful of launches per iteration.
-//   * layout = per internal node ONE 64-byte-aligned record holding its 4 child boxes in SoA form as
-//              24 half floats (lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4], lo rounded down / hi rounded
-//              up, so the boxes only grow): 48 bytes = the size of a triangle record, so a traversal step
-//              fetches node or triangle with the same three dwordx4 loads.  Triangles are stored pre-gathered
-//              in sorted order as (v0, e1, e2) = 3 x float4 and tested in full fp32: hits are unchanged by the
-//              rounding.  Measured on the bench mesh: 32 node + 2 triangle visits per ray.
-//   * traverse = see BvhRay below: one record per step, branch-free slab test of the 4 children, pending work
-//              kept as (node, child mask) with one 32-bit word per tree level in LDS.  What limited the first
-//              version was occupancy (a 32-entry LDS stack = 32 KB per block), not bytes: narrowing the nodes
-//              alone changed nothing, the 12-word stack took the stand-alone any-hit from 1.7 to 4.3 G rays/s.
+//   * build  = one 30-bit Morton radix sort of the centroids + a pointer-free complete 8-ary heap:
+//              leaf i owns sorted triangle i, node n has children 8n+1..8n+8 (one octree level of the Morton
+//              order per tree level), so "refit" is D tiny launches of min/max over 8 slots -- no atomics, no
+//              fences, no parent pointers; the whole rebuild is a handful of launches per iteration.
+//   * layout = per internal node ONE 96-byte record holding its 8 child boxes in SoA form as 48 half floats:
+//              six 16-byte groups lo.x[8] lo.y[8] lo.z[8] hi.x[8] hi.y[8] hi.z[8] (lo rounded down / hi rounded
+//              up, so the boxes only grow).  A ray picks the NEAR and FAR plane group of each axis by the sign
+//              of its direction once (a byte offset), so the slab test of a child is 6 fma + max3 + min3 with no
+//              per-plane min / max.  Triangles are stored pre-gathered in sorted order as (v0, e1, e2) = 3 x
+//              float4 and tested in full fp32: hits are unchanged by the rounding.
+//   * why 8 = the traversal kernel is VALU-issue bound (rocprofv3: VALU busy 96 %, profiles/r03_pmc_trace.json):
+//              its cost is (steps per ray) x (instructions per step), and shadow rays from a surface almost all MISS
+//              (0.5 % hits on the bench mesh): a miss must visit every internal node whose box the ray pierces --
+//              its own ancestors plus their pierced siblings.  The 4-ary heap (depth 9 on 2.3 10^5 triangles) cost
+//              32 node + 2 triangle visits per ray at ~220 instructions per step; the 8-ary one has 3/7 of the
+//              internal nodes and a fixed per-step overhead (stack, addressing, the divergent triangle block) paid
+//              half as often.
+//   * traverse = see BvhRay below: one record per step, branch-free slab test of the 8 children, pending work
+//              kept as (node, child mask) with one 32-bit word per tree level in LDS.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -25,11 +30,11 @@
 struct gs_bvh {
     int64_t T = 0;           // triangles in the current build
     int depth = 0;           // leaves live at heap level `depth` (>= 1)
-    int leaf = 1;            // triangles per leaf (1..GS_BVH_LEAF)
-    int64_t n_internal = 0;  // (4^depth - 1) / 3
-    int64_t n_leaf = 0;      // ceil(T / leaf)
-    float4* groups = nullptr;   // [n_internal * 6]  fp32 child boxes (build buffer)
-    uint4* nodes = nullptr;     // [n_internal * 4]  half-float child boxes, 64-byte records (traversal)
+    int leaf = 1;            // triangles per leaf (always 1)
+    int64_t n_internal = 0;  // (8^depth - 1) / 7
+    int64_t n_leaf = 0;      // T
+    float4* groups = nullptr;   // [n_internal * 12]  fp32 child boxes (build buffer)
+    uint4* nodes = nullptr;     // [n_internal * 6]  half-float child boxes, 96-byte records (traversal)
     float4* tris = nullptr;     // [T * 3]  v0, e1, e2 in Morton order
     int32_t* tri_id = nullptr;  // [T] original triangle id of each sorted slot
     // build scratch
@@ -50,13 +55,6 @@ struct BvhView {  // passed by value to kernels
 static inline BvhView bvh_view(const gs_bvh* b) { return {b->nodes, b->tris, b->T, b->n_internal, b->n_leaf, b->leaf}; }
 
 constexpr int BVH_STACK = 12;  // entries per lane: one (node, pending-children mask) word per tree level (checked at build time)
-
-// half number `i` of a packed record (compile-time i after unrolling)
-__device__ __forceinline__ float bvh_half(const uint32_t* w, int i) {
-    union { uint32_t u; _Float16 h[2]; } c;
-    c.u = w[i >> 1];
-    return (float)c.h[i & 1];
-}
 
 // Moeller-Trumbore, t in (0, 1e16); the record is (v0, e1, e2) as 3 x float4
 __device__ __forceinline__ bool tri_hit(float4 v0, float4 e1, float4 e2, float ox, float oy, float oz, float dx, float dy, float dz) {
@@ -79,19 +77,22 @@ __device__ __forceinline__ float4 bvh_as_float4(uint4 q) {
 
 // Traversal state of one shadow ray (registers).  The loop is instruction-issue bound (a wave64 VALU op takes
 // 4 cycles and the lanes of a wave follow unrelated paths), so a step is written short and nearly branch-free:
-//   * every visit -- internal node or triangle -- is ONE 48-byte record fetched by the same three dwordx4
-//     loads from a lane-dependent base: one memory latency per step however the wave is split;
-//   * the four child slabs are tested with fma (origin pre-multiplied by 1/d) and min3/max3, no early outs;
+//   * every visit is ONE record fetched from a lane-dependent base (96-byte node or 48-byte triangle): one memory
+//     latency per step however the wave is split;
+//   * the eight child slabs are tested with fma (origin pre-multiplied by 1/d) on the near / far plane groups the
+//     ray selected at start, max3 / min3, no early outs;
 //   * pending work is (node, bit mask of its children still to visit): the current pair lives in registers and
 //     ONE 32-bit word (node << 8 | mask) per tree level is spilled to LDS, so the stack is `depth` entries deep
-//     (768 B per wave instead of 9 KB) and occupancy is no longer limited by LDS.
-// For a node whose children are leaves the mask bits index the 4*leaf triangles below it.
+//     and occupancy is not limited by LDS.
+// For a node whose children are leaves the mask bits index the 8 triangles below it.
 // Entry e of a lane lives at st[e * nthreads] (st = stack base + the lane's thread index).
+constexpr int BVH_W = 8;
 struct BvhRay {
     float ox, oy, oz, dx, dy, dz, ix, iy, iz, nox, noy, noz;
     int32_t node;    // -1 = virtual parent of the root
     uint32_t mask;   // children of `node` not visited yet (never 0 between steps)
     int sp;
+    uint32_t sel;    // bit k: direction component k is negative -> the near plane of axis k is the child's hi plane
 };
 
 // false = the direction is degenerate (zero / NaN): the ray hits nothing
@@ -103,6 +104,7 @@ __device__ __forceinline__ bool bvh_ray_init(BvhRay& r, float ox, float oy, floa
     r.iy = fabsf(dy) > 1e-18f ? 1.0f / dy : copysignf(1e18f, dy);
     r.iz = fabsf(dz) > 1e-18f ? 1.0f / dz : copysignf(1e18f, dz);
     r.nox = -ox * r.ix; r.noy = -oy * r.iy; r.noz = -oz * r.iz;
+    r.sel = (r.ix < 0.f ? 1u : 0u) | (r.iy < 0.f ? 2u : 0u) | (r.iz < 0.f ? 4u : 0u);
     r.node = -1;
     r.mask = 1u;
     r.sp = 0;
@@ -111,53 +113,46 @@ __device__ __forceinline__ bool bvh_ray_init(BvhRay& r, float ox, float oy, floa
 
 constexpr int BVH_CONTINUE = 0, BVH_MISS = 1, BVH_HIT = 2;
 
+// half number `i` (0..7) of a 16-byte group
+__device__ __forceinline__ float bvh_half8(const uint4& g, int i) {
+    union { uint32_t u; _Float16 h[2]; } c;
+    c.u = i < 2 ? g.x : (i < 4 ? g.y : (i < 6 ? g.z : g.w));
+    return (float)c.h[i & 1];
+}
+
 // visits the lowest pending child of r.node.  Returns BVH_CONTINUE / BVH_MISS (nothing pending) / BVH_HIT.
 template <bool STATS = false>
 __device__ __forceinline__ int bvh_step(const BvhView& bv, BvhRay& r, int32_t* st, int nthreads, int* n_nodes = nullptr, int* n_tris = nullptr) {
     const uint4* __restrict__ tri_rec = reinterpret_cast<const uint4*>(bv.tris);
     const int32_t n_internal = (int32_t)bv.n_internal;
-    const int32_t leaf = bv.leaf, T = (int32_t)bv.T;
     const int k = __builtin_ctz(r.mask);
     uint32_t mask = r.mask & (r.mask - 1u);
-    const int32_t c0 = 4 * r.node + 1;                                  // first child of r.node (-3 for the virtual parent)
+    const int32_t c0 = BVH_W * r.node + 1;                              // first child of r.node (-7 for the virtual parent)
     const bool at_tris = c0 >= n_internal;                              // r.node's children are leaves: bit k = k-th triangle below it
     const int32_t c = r.node < 0 ? 0 : c0 + k;                          // node to visit (when !at_tris)
-    const int32_t t = (c0 - n_internal) * leaf + k;                     // triangle to test (when at_tris)
-    const uint4* rec = at_tris ? tri_rec + (int64_t)t * 3 : bv.nodes + (int64_t)c * 4;
-    const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+    const int32_t t = (c0 - n_internal) + k;                            // triangle to test (when at_tris)
     if (at_tris) {
         if (STATS) ++*n_tris;
+        const uint4* rec = tri_rec + (int64_t)t * 3;
+        const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
         if (tri_hit(bvh_as_float4(q0), bvh_as_float4(q1), bvh_as_float4(q2), r.ox, r.oy, r.oz, r.dx, r.dy, r.dz)) return BVH_HIT;
     } else {
         if (STATS) ++*n_nodes;
-        const uint32_t w[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+        // groups of the record: 0..2 = lo.x lo.y lo.z, 3..5 = hi.x hi.y hi.z; near plane of axis a = group a + 3 [d_a < 0]
+        const uint4* rec = bv.nodes + (int64_t)c * 6;
+        const int sx = (int)(r.sel & 1u) * 3, sy = (int)((r.sel >> 1) & 1u) * 3, sz = (int)((r.sel >> 2) & 1u) * 3;
+        const uint4 nx = rec[sx], ny = rec[1 + sy], nz = rec[2 + sz];
+        const uint4 fx = rec[3 - sx], fy = rec[4 - sy], fz = rec[5 - sz];
         uint32_t m2 = 0u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // half h of the record = component (h >> 2) of child (h & 3): lo.x lo.y lo.z hi.x hi.y hi.z
-            const float lx = bvh_half(w, j), ly = bvh_half(w, 4 + j), lz = bvh_half(w, 8 + j);
-            const float hx = bvh_half(w, 12 + j), hy = bvh_half(w, 16 + j), hz = bvh_half(w, 20 + j);
-            const float ax = __builtin_fmaf(lx, r.ix, r.nox), bx = __builtin_fmaf(hx, r.ix, r.nox);
-            const float ay = __builtin_fmaf(ly, r.iy, r.noy), by = __builtin_fmaf(hy, r.iy, r.noy);
-            const float az = __builtin_fmaf(lz, r.iz, r.noz), bz = __builtin_fmaf(hz, r.iz, r.noz);
-            const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-            const bool inside = (lx <= hx) & (tf >= tn);                 // empty slots have lo > hi
-            m2 |= inside ? (1u << j) : 0u;
-        }
-        if (leaf > 1) {                                                  // uniform: 2 triangles per leaf
-            const int32_t cc0 = 4 * c + 1;
-            if (cc0 >= n_internal) {                                     // spread child bit j to triangle bits 2j, 2j+1
-                const int32_t t0 = (cc0 - n_internal) * 2;
-                uint32_t m3 = 0u;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t on = (m2 >> j) & 1u;
-                    m3 |= on << (2 * j);
-                    m3 |= (t0 + 2 * j + 1 < T ? on : 0u) << (2 * j + 1);
-                }
-                m2 = m3;
-            }
+        for (int j = 0; j < BVH_W; ++j) {
+            const float tnx = __builtin_fmaf(bvh_half8(nx, j), r.ix, r.nox), tfx = __builtin_fmaf(bvh_half8(fx, j), r.ix, r.nox);
+            const float tny = __builtin_fmaf(bvh_half8(ny, j), r.iy, r.noy), tfy = __builtin_fmaf(bvh_half8(fy, j), r.iy, r.noy);
+            const float tnz = __builtin_fmaf(bvh_half8(nz, j), r.iz, r.noz), tfz = __builtin_fmaf(bvh_half8(fz, j), r.iz, r.noz);
+            // an empty slot has lo > hi on every axis: its near plane lies behind its far plane for either sign of d -> tf < tn
+            const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+            const float tf = fminf(fminf(tfx, tfy), tfz);
+            m2 |= (tf >= tn) ? (1u << j) : 0u;
         }
         if (m2 != 0u) {
             if (mask != 0u) {
