@@ -980,82 +980,81 @@ __global__ void __launch_bounds__(256) k_surface_points_cdf(const float* __restr
     out[3 * i + 2] = a * v0.z + b * v1.z + c * v2.z;
 }
 
-// ---- light probe sampling tables (render/light.py:46-59) in ONE launch ------------------------------------------------------
+// ---- light probe sampling tables (render/light.py:46-59) in two launches -----------------------------------------------------
 // pdf = max_c(base) sin(theta_y) / sum;  cols[y] = cumsum_x pdf[y] / its last entry;  rows = cumsum_y (row masses) / total.
-// As torch ops this is 15 launches on a 256 x 256 array before every iteration (train_gshelltet_deepfashion.py:412).  One workgroup:
-// a wave owns a row at a time (lane = W / 64 consecutive columns, wave scan of the lane totals).
-__global__ void __launch_bounds__(1024) k_light_tables(const float* __restrict__ base, int H, int W, float* __restrict__ pdf, float* __restrict__ rows,
-                                                       float* __restrict__ cols) {
-    __shared__ float s_part[16];
-    __shared__ float s_total;
-    __shared__ float s_mass[1024];        // H <= 1024
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+// As torch ops this is 15 launches on a 256 x 256 array before every iteration (train_gshelltet_deepfashion.py:412).
+//   k_light_rows : a wave owns a row (lane = W / 64 consecutive columns, wave scan of the lane totals): w -> pdf (unnormalised), the row's
+//                  CDF -> cols (the total cancels in cols), the row's mass -> mass[y]
+//   k_light_norm : every workgroup scans the H row masses itself (H <= 1024 values), then normalises its share of pdf and writes rows
+// (a first version did all of it in ONE workgroup: 104 us on one CU against 140 us for the 15 launches -- no gain)
+__global__ void __launch_bounds__(256) k_light_rows(const float* __restrict__ base, int H, int W, float* __restrict__ pdf, float* __restrict__ cols,
+                                                    float* __restrict__ mass) {
+    const int lane = threadIdx.x & 63, y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (y >= H) return;
     const int per = (W + 63) / 64;
-    // pass 1: total of w = max_c(base) sin(theta)
-    float acc = 0.f;
-    for (int y = wave; y < H; y += nw) {
-        const float st = sinf(((float)y + 0.5f) / (float)H * 3.14159265358979323846f);
-        for (int k = 0; k < per; ++k) {
-            const int x = lane * per + k;
-            if (x < W) {
-                const float* b = base + ((int64_t)y * W + x) * 3;
-                acc += fmaxf(fmaxf(b[0], b[1]), b[2]) * st;
-            }
+    const float st = sinf(((float)y + 0.5f) / (float)H * 3.14159265358979323846f);
+    float run = 0.f;
+    for (int k = 0; k < per; ++k) {
+        const int x = lane * per + k;
+        if (x < W) {
+            const float* b = base + ((int64_t)y * W + x) * 3;
+            const float w = fmaxf(fmaxf(b[0], b[1]), b[2]) * st;
+            pdf[(int64_t)y * W + x] = w;
+            run += w;
         }
     }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (lane == 0) s_part[wave] = acc;
+    float inc = run;                                  // inclusive scan of the lane totals
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    const float m = __shfl(inc, 63, 64);
+    const float inv = m > 0.f ? m : 1.0f;
+    float c = inc - run;
+    for (int k = 0; k < per; ++k) {
+        const int x = lane * per + k;
+        if (x < W) {
+            c += pdf[(int64_t)y * W + x];
+            cols[(int64_t)y * W + x] = c / inv;
+        }
+    }
+    if (lane == 0) mass[y] = m;
+}
+
+__global__ void __launch_bounds__(256) k_light_norm(const float* __restrict__ mass, int H, int W, float* __restrict__ pdf, float* __restrict__ rows) {
+    __shared__ float s_cdf[1024];
+    __shared__ float s_part[4];
+    // inclusive scan of the row masses: thread t owns 4 consecutive rows, wave scan, 4 wave totals
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float v[4], run = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = 4 * t + k;
+        v[k] = y < H ? mass[y] : 0.f;
+        run += v[k];
+    }
+    float inc = run;
+    for (int o = 1; o < 64; o <<= 1) {
+        const float u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) s_part[wave] = inc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int w = 0; w < nw; ++w) t += s_part[w];
-        s_total = t;
+    float off = 0.f;
+    for (int w = 0; w < wave; ++w) off += s_part[w];
+    const float total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    float c = off + inc - run;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        c += v[k];
+        if (4 * t + k < H) s_cdf[4 * t + k] = c;
     }
     __syncthreads();
-    const float total = s_total;
-    // pass 2: pdf, per-row inclusive scan, row masses
-    for (int y = wave; y < H; y += nw) {
-        const float st = sinf(((float)y + 0.5f) / (float)H * 3.14159265358979323846f);
-        float run = 0.f;
-        for (int k = 0; k < per; ++k) {
-            const int x = lane * per + k;
-            if (x < W) {
-                const float* b = base + ((int64_t)y * W + x) * 3;
-                const float p = fmaxf(fmaxf(b[0], b[1]), b[2]) * st / total;
-                pdf[(int64_t)y * W + x] = p;
-                run += p;
-            }
-        }
-        float inc = run;                                  // inclusive scan of the lane totals
-        for (int o = 1; o < 64; o <<= 1) {
-            const float t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
-        const float mass = __shfl(inc, 63, 64);
-        const float inv = mass > 0.f ? mass : 1.0f;
-        float c = inc - run;
-        for (int k = 0; k < per; ++k) {
-            const int x = lane * per + k;
-            if (x < W) {
-                c += pdf[(int64_t)y * W + x];
-                cols[(int64_t)y * W + x] = c / inv;
-            }
-        }
-        if (lane == 0) s_mass[y] = mass;
+    const float tinv = total > 0.f ? total : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + t; i < (int64_t)H * W; i += (int64_t)gridDim.x * 256) {
+        pdf[i] = pdf[i] / total;
+        rows[i] = s_cdf[i / W] / tinv;
     }
-    __syncthreads();
-    // pass 3: CDF of the row masses (sequential over <= 1024 rows by one lane: 1 microsecond), broadcast over x
-    if (threadIdx.x == 0) {
-        float c = 0.f;
-        for (int y = 0; y < H; ++y) {
-            c += s_mass[y];
-            s_mass[y] = c;
-        }
-        s_total = c;
-    }
-    __syncthreads();
-    const float tot = s_total > 0.f ? s_total : 1.0f;
-    for (int64_t i = threadIdx.x; i < (int64_t)H * W; i += blockDim.x) rows[i] = s_mass[i / W] / tot;
 }
 
 // ---- mSDF open / close regularisers (gshell_tets_geometry.py:326-358) -----------------------------------------------
@@ -1197,10 +1196,13 @@ extern "C" int gs_surface_points_cdf(const float* v_pos, const int32_t* tri, con
     return 0;
 }
 
-extern "C" int gs_light_tables(const float* base, int64_t H, int64_t W, float* pdf, float* rows, float* cols, gs_stream_t stream) {
-    GS_REQUIRE(base && pdf && rows && cols, "gs_light_tables: null pointer");
+extern "C" int gs_light_tables(const float* base, int64_t H, int64_t W, float* pdf, float* rows, float* cols, float* row_mass_scratch,
+                               gs_stream_t stream) {
+    GS_REQUIRE(base && pdf && rows && cols && row_mass_scratch, "gs_light_tables: null pointer");
     GS_REQUIRE(H >= 1 && H <= 1024 && W >= 1, "gs_light_tables: probe height must be in 1..1024");
-    hipLaunchKernelGGL(k_light_tables, dim3(1), dim3(1024), 0, (hipStream_t)stream, base, (int)H, (int)W, pdf, rows, cols);
+    hipLaunchKernelGGL(k_light_rows, dim3((unsigned)gs::cdiv(H, 4)), dim3(256), 0, (hipStream_t)stream, base, (int)H, (int)W, pdf, cols, row_mass_scratch);
+    hipLaunchKernelGGL(k_light_norm, dim3((unsigned)std::min<int64_t>(gs::cdiv(H * W, 256), 64)), dim3(256), 0, (hipStream_t)stream, row_mass_scratch, (int)H,
+                       (int)W, pdf, rows);
     GS_LAUNCH_CHECK();
     return 0;
 }

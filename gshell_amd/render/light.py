@@ -36,14 +36,15 @@ class EnvironmentLight:
     def update_pdf(self):
         Hl, Wl = self.base.shape[0], self.base.shape[1]
         if self.base.is_cuda and Hl <= 1024:
-            # one launch (csrc/pixelops.hip: k_light_tables) instead of 15 ATen launches before every iteration
+            # two launches (csrc/pixelops.hip: k_light_rows / k_light_norm) instead of 15 ATen launches before every iteration
             from .. import _lib
             base = self.base.detach().contiguous().float()
             self._pdf = torch.empty((Hl, Wl), dtype=torch.float32, device=base.device)
             self.rows, self.cols = torch.empty_like(self._pdf), torch.empty_like(self._pdf)
+            mass = torch.empty(Hl, dtype=torch.float32, device=base.device)
             with torch.cuda.device(base.device):
                 _lib.check(_lib.lib().gs_light_tables(_lib.ptr(base, torch.float32, "base"), _lib.c_int64(Hl), _lib.c_int64(Wl), _lib.ptr(self._pdf),
-                                                      _lib.ptr(self.rows), _lib.ptr(self.cols), _lib.stream()), "gs_light_tables")
+                                                      _lib.ptr(self.rows), _lib.ptr(self.cols), _lib.ptr(mass), _lib.stream()), "gs_light_tables")
             return
         # CPU tensors (host-side tests, the reference script's set-up on a GPU-less box): the same tables as torch ops
         if self._sin_theta is None or self._sin_theta.device != self.base.device:

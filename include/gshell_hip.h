@@ -483,11 +483,11 @@ int gs_tri_area(const float* v_pos, const int32_t* tri, int64_t T, float* area, 
  * (u, v, face); face = first t with cdf[t] > r * cdf[T-1]; face_id [n] int64 WRITTEN (may be NULL). */
 int gs_surface_points_cdf(const float* v_pos, const int32_t* tri, const float* area_cdf, int64_t T,
                           const float* r01x3, int64_t n, float* out, int64_t* face_id, gs_stream_t stream);
-/* EnvironmentLight.update_pdf (render/light.py:46-59) in one launch: base [H,W,3] -> pdf [H,W] = max_c(base) sin(theta) / sum,
+/* EnvironmentLight.update_pdf (render/light.py:46-59) in two launches: base [H,W,3] -> pdf [H,W] = max_c(base) sin(theta) / sum,
  * cols [H,W] = per-row CDF over the columns, rows [H,W] = CDF of the row masses (constant along x; the shader reads rows[:,0]).
- * H <= 1024. */
+ * H <= 1024; row_mass_scratch [H] floats. */
 int gs_light_tables(const float* base, int64_t H, int64_t W, float* pdf, float* rows, float* cols,
-                    gs_stream_t stream);
+                    float* row_mass_scratch, gs_stream_t stream);
 int gs_surface_points(const float* v_pos, const int32_t* tri, const int64_t* face_id, const float* r01,
                       int64_t n, float* out, gs_stream_t stream);
 

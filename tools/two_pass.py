@@ -76,7 +76,43 @@ def timed(fn, reps=10):
     return e0.elapsed_time(e1) / reps
 
 
+def precision_table(res=256, states=(30, 400, 1500)):
+    """error of the one-pass h2 kernel and of the one-product pass against float64, and the two-pass equalities, for several
+    states of the network (fit steps; the last entry of each row scales the fitted hidden weights by 1.5 -- a sharper network)"""
+    rows = []
+    for steps in states:
+        net, verts, topo = build(res, steps=steps)
+        for scale in (1.0, 1.5):
+            if scale != 1.0:
+                with torch.no_grad():
+                    for m in net.net:
+                        if isinstance(m, torch.nn.Linear) and m.in_features == 256 and m.out_features == 256:
+                            m.weight.mul_(scale ** (1.0 / 5.0))
+            with torch.no_grad():
+                net64 = MLP(n_freq=6, d_hidden=256, n_hidden=6, skip_in=[3]).cuda().double()
+                net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+                y64 = torch.cat([net64(verts[i:i + (1 << 18)].double()) for i in range(0, verts.shape[0], 1 << 18)])[:, 0]
+                y3 = fused_forward(net, verts, "h2")[:, 0]
+                L = __import__("gshell_amd")._lib.lib()
+                from gshell_amd import _lib
+                packed, n_hidden, skip = mlp.pack_weights_h2(net)
+                y1 = torch.empty(verts.shape[0], device=verts.device)
+                _lib.check(L.gs_sdf_mlp_fwd_h1(_lib.ptr(verts), _lib.c_int64(verts.shape[0]), _lib.ptr(packed), _lib.c_int(6), _lib.c_int(n_hidden), _lib.c_int(skip),
+                                               _lib.ptr(y1), _lib.c_void_p(0), _lib.c_void_p(0), _lib.stream()))
+            r = compare(net, verts, topo, mlp.SDF_TWO_PASS_TAU)
+            rows.append({"fit_steps": steps, "hidden_weight_scale": scale, "max_abs_sdf": float(y64.abs().max()),
+                         "h2_one_pass": {"max_abs_err_vs_f64": float((y3.double() - y64).abs().max()), "sign_flips_vs_f64": int(((y3 > 0) != (y64 > 0)).sum())},
+                         "h1_one_product": {"max_abs_err_vs_f64": float((y1.double() - y64).abs().max()), "rms_err": float((y1.double() - y64).pow(2).mean().sqrt()),
+                                            "sign_flips_vs_f64": int(((y1 > 0) != (y64 > 0)).sum())},
+                         "two_pass": {k: r[k] for k in ("refined_fraction", "max_abs_dev_one_product_on_refined_rows", "sign_disagreements", "end_point_values_bit_identical",
+                                                        "occupancy_words_equal", "max_abs_diff_all_rows")}})
+    return rows
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--states":
+        print(json.dumps({"grid": "tet-res256", "tau": mlp.SDF_TWO_PASS_TAU, "safety": mlp.SDF_TWO_PASS_SAFETY, "states": precision_table()}, indent=1))
+        return
     res = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     tau = float(sys.argv[2]) if len(sys.argv) > 2 else mlp.SDF_TWO_PASS_TAU
     net, verts, topo = build(res)
