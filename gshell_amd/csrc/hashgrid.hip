@@ -37,13 +37,14 @@ struct GridMeta {
 
 __device__ __forceinline__ uint32_t grid_index(uint32_t x, uint32_t y, uint32_t z, uint32_t res, uint32_t size) {
     // dense while res^3 fits, else spatial hash (coherent prime hash of tiny-cuda-nn)
+    // `idx % size` without the 40-instruction integer division (8 corners x 16 levels per point) wherever it is the identity: a hashed
+    // level's table has 2^log2_T entries (make_meta); a dense level's size is >= res^3, so only coordinates outside [0,1] wrap.
     uint64_t dense = (uint64_t)res * res * res;
-    uint32_t idx;
-    if (dense <= (uint64_t)size)
-        idx = x + y * res + z * res * res;
-    else
-        idx = x ^ (y * 2654435761u) ^ (z * 805459861u);
-    return idx % size;
+    if (dense <= (uint64_t)size) {
+        const uint32_t idx = x + y * res + z * res * res;
+        return idx >= size ? idx % size : idx;
+    }
+    return (x ^ (y * 2654435761u) ^ (z * 805459861u)) & (size - 1u);
 }
 
 template <bool BWD>
@@ -142,12 +143,17 @@ __global__ void __launch_bounds__(256) k_hashgrid(GridMeta M, const float* __res
 //   * the normalisation (x - lo) / (hi - lo), the clamp to [0,1], its gradient mask and the reference's 1/128 gradient
 //     scaling hook (mlptexture.py:74) are folded in (they were ~12 + 35 ATen launches around the two kernels).
 // Backward: float atomics on gfx950 are fabric writes at a flat 21 G atomics/s whatever the address pattern
-// (tools/micro/atomic_scope.hip), so the kernel's time IS its atomic count.  The two features of an entry go in ONE
-// 64-bit atomic (atomics.hpp).  A workgroup owns a 16x16-pixel tile of an
-// image (neighbouring pixels = neighbouring surface points), walks the levels itself and combines the tile's
-// contributions per table entry in an LDS hash table (ds_cmpst + ds_add_f32) before ONE global atomic per entry,
-// feature and tile; once a level shows no sharing (>= 3/4 of the inserts claim a fresh slot) the finer levels go to
-// global atomics directly.  d loss / d position is accumulated over the levels in registers and written once.
+// (tools/micro/atomic_scope.hip), so an atomic-only kernel's time IS its atomic count (1.55 ms for the 25 M of the bench frame).
+// A workgroup owns a 16x16-pixel tile of an image (neighbouring pixels = neighbouring surface points) and walks the levels itself:
+//   * runs of equal entries along a 16-pixel row are summed with DPP row shifts, the head lane owns the run;
+//   * DENSE levels (res^3 fits the table: spatially coherent): the tile's updates are combined per entry in an LDS hash table
+//     (ds_cmpst + ds_add_f32) and flushed with ONE global atomic per entry, feature and tile; what does not combine goes to the table as
+//     one 64-bit compare-and-swap per feature pair (atomics.hpp);
+//   * HASHED levels (3/4 of all updates, scattered pseudo-randomly, nothing to combine): no atomics on the table at all, see "Binned
+//     table gradient" above -- records sorted by bin in LDS, written as contiguous runs, summed per bin by k_encode_bin_reduce.
+// Measured (profiles/r03_hashgrid_bwd.txt): 1.55 ms -> 0.58 + 0.28 ms; LDS float adds cost 3 cycles per lane on gfx950, integer ones
+// 0.34 (tools/micro/lds_atomic.hip), which is what the reducer's 0.28 ms is.  d loss / d position is accumulated over the levels in
+// registers and written once.
 #ifndef GS_HG_LOG_SLOTS
 #define GS_HG_LOG_SLOTS 10
 #endif
@@ -161,7 +167,20 @@ struct EncArgs {
     const float* g_feat; float* g_params; float* g_pos; float grad_scale, table_scale;
     int img_w, img_h;
     const int32_t* rows; const int64_t* count_dev;     // forward: optional compact list of the points to encode (count on the device)
+    // backward, binned table gradient (below): per-bin fill counters, per-bin record arrays of `bin_cap` records, first bin of a level (-1: atomics)
+    uint32_t* bin_count; struct BinRec* bin_rec; uint32_t bin_cap; int bin_base[MAX_LEVELS];
 };
+// Binned table gradient.  The hashed levels (res^3 > table size) scatter a tile's updates pseudo-randomly over the level's table: no
+// sharing to combine, one fabric atomic per (pixel, corner) -- 3/4 of the kernel's atomics.  Instead the table of such a level is cut
+// into bins of BIN_ENTRIES consecutive entries; a workgroup ranks its updates per bin in LDS, reserves a run of records per bin with ONE
+// returning atomic, and writes (entry, d feature pair) records there with plain 12-byte stores; k_encode_bin_reduce then sums a bin's
+// records in 32 KB of LDS and adds them to the table gradient with plain loads and stores (it owns the bin: no atomics at all).
+// A reservation past the bin's capacity falls back to the atomic path, so any capacity is correct; the reducer resets the counters.
+struct BinRec { uint32_t e; float a, b; };
+#ifndef GS_HG_BIN_LOG
+#define GS_HG_BIN_LOG 12
+#endif
+constexpr int BIN_LOG = GS_HG_BIN_LOG, BIN_ENTRIES = 1 << BIN_LOG, BIN_MAX_PER_LEVEL = 256;
 
 __device__ __forceinline__ bool enc_coord(const EncArgs& A, int64_t i, float (&t)[3], bool (&inside)[3]) {
 #pragma unroll
@@ -226,10 +245,21 @@ __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, Enc
 #ifndef GS_HG_WAVETAB
 #define GS_HG_WAVETAB 0      // 1: every wave (4 rows x 16 pixels) combines in its OWN quarter of the table: no workgroup barriers
 #endif
-    __shared__ uint32_t s_key_all[CMB_SLOTS];
-    __shared__ float2 s_val_all[CMB_SLOTS];
-    __shared__ uint16_t s_list_all[CMB_SLOTS];   // the slots claimed at the current level (flush + clear walk this list, not the table)
+    // One LDS block, two uses: the combine table of the dense levels (keys, values, the list of slots claimed at the current level: flush
+    // and clear walk that list, not the table) and the staging buffer of a binned level's records (sorted by bin before they leave).
+    constexpr int STAGE = 256 * 8;                                                     // records of one level: 8 corners per pixel
+    constexpr int TAB_WORDS = CMB_SLOTS + 2 * CMB_SLOTS + CMB_SLOTS / 2, RAW_WORDS = TAB_WORDS > 3 * STAGE ? TAB_WORDS : 3 * STAGE;
+    __shared__ uint32_t s_raw[RAW_WORDS];
+    uint32_t* const s_key_all = s_raw;
+    float2* const s_val_all = reinterpret_cast<float2*>(s_raw + CMB_SLOTS);
+    uint16_t* const s_list_all = reinterpret_cast<uint16_t*>(s_raw + 3 * CMB_SLOTS);
+    uint32_t* const s_rec_e = s_raw;
+    float* const s_rec_a = reinterpret_cast<float*>(s_raw + STAGE);
+    float* const s_rec_b = reinterpret_cast<float*>(s_raw + 2 * STAGE);
+    __shared__ uint32_t s_wave_total[4];
+    static_assert(!GS_HG_WAVETAB, "the per-wave combine tables are not laid out for the staging buffer");
     __shared__ int s_claimed_all[4][2];          // bank = level step & 1
+    __shared__ uint32_t s_bin_fill[BIN_MAX_PER_LEVEL], s_bin_at[BIN_MAX_PER_LEVEL], s_bin_start[BIN_MAX_PER_LEVEL];
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr int TSLOTS = GS_HG_WAVETAB ? CMB_SLOTS / 4 : CMB_SLOTS, TLOG = GS_HG_WAVETAB ? CMB_LOG_SLOTS - 2 : CMB_LOG_SLOTS;
     const int tw = GS_HG_WAVETAB ? (tid >> 6) : 0, tn = GS_HG_WAVETAB ? 64 : 256, tl = GS_HG_WAVETAB ? lane : tid;   // table owner, its threads
@@ -270,6 +300,7 @@ __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, Enc
         s_val[s] = make_float2(0.f, 0.f);
     }
     if (tl < 2) s_claimed[tl] = 0;
+    if (tid < BIN_MAX_PER_LEVEL) s_bin_fill[tid] = 0u;
     table_sync();
     float gx[3] = {0.f, 0.f, 0.f};
     const float2* gf = reinterpret_cast<const float2*>(A.g_feat);
@@ -277,6 +308,51 @@ __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, Enc
     // The coarse levels are LDS / barrier latency, the fine levels are global-atomic throughput: neighbouring workgroups walk the
     // levels in opposite directions so that the chip always has both kinds of work in flight.
     const bool descending = GS_HG_ALTERNATE && (wg_linear & 1);
+    // Updates straight to the table: both features in ONE 64-bit compare-and-swap (atomics.hpp), the eight loads and then the eight swaps
+    // issued back to back so that their latencies overlap.
+    auto direct_pairs = [&](float* gtab, const uint32_t (&idx)[8], const float (&v0)[8], const float (&v1)[8], uint32_t todo) {
+#ifndef GS_HG_DIRECT_PAIR
+#define GS_HG_DIRECT_PAIR 1
+#endif
+        if (todo && !GS_HG_DIRECT_PAIR) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if ((todo >> c) & 1u) {
+                    if (v0[c] != 0.f) atomicAdd(&gtab[(int64_t)idx[c] * 2], v0[c]);
+                    if (v1[c] != 0.f) atomicAdd(&gtab[(int64_t)idx[c] * 2 + 1], v1[c]);
+                }
+        } else if (todo) {
+            union PairBits {
+                unsigned long long u;
+                float2 f;
+            };
+            PairBits cur[8], seen[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if ((todo >> c) & 1u)
+                    cur[c].u = __hip_atomic_load(reinterpret_cast<unsigned long long*>(gtab) + idx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if ((todo >> c) & 1u) {
+                    PairBits nxt;
+                    nxt.f = make_float2(cur[c].f.x + v0[c], cur[c].f.y + v1[c]);
+                    seen[c].u = atomicCAS(reinterpret_cast<unsigned long long*>(gtab) + idx[c], cur[c].u, nxt.u);
+                }
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (((todo >> c) & 1u) && seen[c].u != cur[c].u) {      // lost a race: retry from the value the swap returned
+                    PairBits c2 = seen[c];
+                    for (;;) {
+                        PairBits nxt;
+                        nxt.f = make_float2(c2.f.x + v0[c], c2.f.y + v1[c]);
+                        const unsigned long long sn = atomicCAS(reinterpret_cast<unsigned long long*>(gtab) + idx[c], c2.u, nxt.u);
+                        if (sn == c2.u) break;
+                        c2.u = sn;
+                    }
+                }
+        }
+    };
+    bool table_dirty = false;            // the staging buffer overwrote the (empty) combine table
     for (int step = 0; step < M.n_levels; ++step) {
         const int l = descending ? M.n_levels - 1 - step : step;
         const float scale = M.scale[l];
@@ -321,35 +397,102 @@ __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, Enc
         gx[1] += ly * scale;
         gx[2] += lz * scale;
         if (!gtab) continue;
-        // phase B: runs of equal entries along the wave (16-pixel row segments): segmented suffix sums, the head lane owns the run
+        // phase B: runs of equal entries along a 16-pixel row segment (= a DPP row of the wave): segmented suffix sums, the head lane owns
+        // the run.  Row shifts are DPP operands of the adds (no LDS traffic); a run never leaves its row, which costs nothing: merging is an
+        // optimisation, every head issues its own update.
         float v0[8], v1[8];
         uint32_t todo = 0u;      // corners this lane has to add to the table
         int n_heads = 0;         // wave-uniform
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const uint32_t key = active ? idx[c] : (0x80000000u | (uint32_t)lane);
-            const uint32_t prev = __shfl_up(key, 1, 64);
-            const bool head = lane == 0 || key != prev;
+            const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x111, 0xf, 0xf, false);      // row_shr:1 = lane - 1's key
+            const bool head = (lane & 15) == 0 || key != prev;
             const uint64_t heads = __ballot(head);
             n_heads += __popcll(__ballot(head && active));
             const uint64_t after = lane == 63 ? 0ull : (heads & ~((2ull << lane) - 1ull));
-            const int end = after ? (__ffsll((long long)after) - 2) : 63;
+            const int end = after ? (__ffsll((long long)after) - 2) : 63;        // <= the row's last lane: the next row starts with a head
             float a = active ? wgt[c] * (go.x * A.table_scale) : 0.0f, b = active ? wgt[c] * (go.y * A.table_scale) : 0.0f;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const float o0 = __shfl_down(a, d, 64), o1 = __shfl_down(b, d, 64);
-                if (lane + d <= end) {
-                    a += o0;
-                    b += o1;
-                }
+#define GS_HG_ROW_STEP(D)                                                                                                  \
+    if (__ballot(lane + D <= end)) {                                                                                       \
+        const float o0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x100 + D, 0xf, 0xf, true));     \
+        const float o1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), 0x100 + D, 0xf, 0xf, true));     \
+        if (lane + D <= end) {                                                                                             \
+            a += o0;                                                                                                       \
+            b += o1;                                                                                                       \
+        }                                                                                                                  \
+    }
+            if (__ballot(!head)) {           // (wave-uniform) some run is longer than one lane
+                GS_HG_ROW_STEP(1) GS_HG_ROW_STEP(2) GS_HG_ROW_STEP(4) GS_HG_ROW_STEP(8)
             }
+#undef GS_HG_ROW_STEP
             v0[c] = a;
             v1[c] = b;
             if (head && active && (a != 0.f || b != 0.f)) todo |= 1u << c;
         }
         // phase C: where neighbouring pixels share entries along the rows they share them across the rows too: combine the tile's
         // updates per entry in LDS (stateless per level and wave, so the level order is free) ...
-        const bool combine = 8 * n_heads < GS_HG_RUNS * n_active8;       // wave-uniform
+        const int bbase = A.bin_rec ? A.bin_base[l] : -1;               // workgroup-uniform
+        if (bbase >= 0) {
+            // (1) rank of every update inside its bin, (2) per bin: reserve a run of records in the bin's array (ONE returning atomic) and
+            // scan the counts, (3) stage the records in LDS sorted by bin, (4) copy them out: consecutive lanes write consecutive records of
+            // a run (scattered 12-byte stores leave L2 as partial lines: 2.5x the bytes measured, profiles/r03_pmc_hashgrid_bwd.json)
+            uint32_t rank[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if ((todo >> c) & 1u) rank[c] = atomicAdd(&s_bin_fill[idx[c] >> BIN_LOG], 1u);
+            __syncthreads();
+            {
+                const uint32_t cnt = tid < (int)((size + BIN_ENTRIES - 1) >> BIN_LOG) ? s_bin_fill[tid] : 0u;    // <= 256 bins: one per thread
+                uint32_t incl = cnt;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += o;
+                }
+                if (lane == 63) s_wave_total[tid >> 6] = incl;
+                s_bin_start[tid] = incl - cnt;                               // exclusive inside the wave; the waves before are added by the readers
+                if (cnt) {
+                    s_bin_fill[tid] = 0u;
+                    s_bin_at[tid] = atomicAdd(&A.bin_count[bbase + tid], cnt);
+                }
+            }
+            __syncthreads();
+            const uint32_t wt0 = s_wave_total[0], wt1 = wt0 + s_wave_total[1], wt2 = wt1 + s_wave_total[2], n_rec = wt2 + s_wave_total[3];
+            auto bin_start = [&](uint32_t bin) { return s_bin_start[bin] + (bin < 64u ? 0u : bin < 128u ? wt0 : bin < 192u ? wt1 : wt2); };
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if ((todo >> c) & 1u) {
+                    const uint32_t j = bin_start(idx[c] >> BIN_LOG) + rank[c];
+                    s_rec_e[j] = idx[c];
+                    s_rec_a[j] = v0[c];
+                    s_rec_b[j] = v1[c];
+                }
+            todo = 0u;
+            table_dirty = true;
+            __syncthreads();
+            for (uint32_t j = tid; j < n_rec; j += 256) {
+                const uint32_t e = s_rec_e[j], bin = e >> BIN_LOG, at = s_bin_at[bin] + (j - bin_start(bin));
+                const float a = s_rec_a[j], b = s_rec_b[j];
+                if (at < A.bin_cap) {
+                    A.bin_rec[(size_t)(bbase + bin) * A.bin_cap + at] = BinRec{e & (BIN_ENTRIES - 1), a, b};
+                } else {                                                     // past the capacity: the atomic path
+                    if (a != 0.f) atomicAdd(&gtab[(int64_t)e * 2], a);
+                    if (b != 0.f) atomicAdd(&gtab[(int64_t)e * 2 + 1], b);
+                }
+            }
+            continue;                     // the next level's first barrier orders these reads before the buffers' next writes
+        }
+        if (table_dirty) {                // (workgroup-uniform) first dense level after binned ones: the combine table starts empty again
+            __syncthreads();
+            for (int sl = tid; sl < CMB_SLOTS; sl += 256) {
+                s_key[sl] = CMB_EMPTY;
+                s_val[sl] = make_float2(0.f, 0.f);
+            }
+            table_dirty = false;
+            __syncthreads();
+        }
+        const bool combine = bbase < 0 && 8 * n_heads < GS_HG_RUNS * n_active8;       // wave-uniform
         if (combine) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -370,48 +513,8 @@ __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, Enc
                 if (done) todo &= ~(1u << c);
             }
         }
-        // ... and whatever is left straight to the table: both features in ONE 64-bit compare-and-swap (atomics.hpp), the eight
-        // loads and then the eight swaps issued back to back so that their latencies overlap
-#ifndef GS_HG_DIRECT_PAIR
-#define GS_HG_DIRECT_PAIR 1
-#endif
-        if (todo && !GS_HG_DIRECT_PAIR) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if ((todo >> c) & 1u) {
-                    if (v0[c] != 0.f) atomicAdd(&gtab[(int64_t)idx[c] * 2], v0[c]);
-                    if (v1[c] != 0.f) atomicAdd(&gtab[(int64_t)idx[c] * 2 + 1], v1[c]);
-                }
-        } else if (todo) {
-            union PairBits {
-                unsigned long long u;
-                float2 f;
-            };
-            PairBits cur[8], seen[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if ((todo >> c) & 1u)
-                    cur[c].u = __hip_atomic_load(reinterpret_cast<unsigned long long*>(gtab) + idx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if ((todo >> c) & 1u) {
-                    PairBits nxt;
-                    nxt.f = make_float2(cur[c].f.x + v0[c], cur[c].f.y + v1[c]);
-                    seen[c].u = atomicCAS(reinterpret_cast<unsigned long long*>(gtab) + idx[c], cur[c].u, nxt.u);
-                }
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (((todo >> c) & 1u) && seen[c].u != cur[c].u) {      // lost a race: retry from the value the swap returned
-                    PairBits c2 = seen[c];
-                    for (;;) {
-                        PairBits nxt;
-                        nxt.f = make_float2(c2.f.x + v0[c], c2.f.y + v1[c]);
-                        const unsigned long long sn = atomicCAS(reinterpret_cast<unsigned long long*>(gtab) + idx[c], c2.u, nxt.u);
-                        if (sn == c2.u) break;
-                        c2.u = sn;
-                    }
-                }
-        }
+        // ... and whatever is left straight to the table
+        direct_pairs(gtab, idx, v0, v1, todo);
         if (GS_HG_WAVETAB ? (table_sync(), combine) : (bool)__syncthreads_or(combine)) {   // uniform over the table's owner; orders inserts before the flush
             const int n = *claimed;
             for (int j = tl; j < n; j += tn) {
@@ -440,6 +543,62 @@ __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, Enc
     }
 }
 
+// One workgroup per bin: sum the bin's records per entry in LDS, add to the table gradient (plain read-modify-write: the bin is this
+// workgroup's alone and every atomic of k_encode_bwd has landed), reset the bin's counter for the next call.
+__global__ void __launch_bounds__(256) k_encode_bin_reduce(GridMeta M, EncArgs A) {
+    __shared__ float2 acc[BIN_ENTRIES];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = min(A.bin_count[b], A.bin_cap);
+    if (n == 0u) return;                                    // (a counter that overflowed is > 0, so it is reset below)
+    int l = 0;
+    for (int k = 0; k < M.n_levels; ++k)
+        if (A.bin_base[k] >= 0 && A.bin_base[k] <= b) l = k;
+    for (int e = tid; e < BIN_ENTRIES; e += 256) acc[e] = make_float2(0.f, 0.f);
+    __syncthreads();
+    const BinRec* rec = A.bin_rec + (size_t)b * A.bin_cap;
+    for (uint32_t j0 = tid; j0 < n; j0 += 256 * 8) {            // eight record loads in flight per lane (clamped, not predicated: a branch
+        BinRec r[8];                                            //  around a load makes the compiler wait for it at the join)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = rec[min(j0 + 256u * u, n - 1u)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j0 + 256u * u < n) {
+                atomicAdd(&acc[r[u].e].x, r[u].a);
+                atomicAdd(&acc[r[u].e].y, r[u].b);
+            }
+    }
+    __syncthreads();
+    if (tid == 0) A.bin_count[b] = 0u;
+    const uint32_t first = (uint32_t)(b - A.bin_base[l]) << BIN_LOG, size = M.offset[l + 1] - M.offset[l];
+    float2* g = reinterpret_cast<float2*>(A.g_params) + M.offset[l] + first;
+    const int ne = (int)min((uint32_t)BIN_ENTRIES, size - first);
+    for (int e = tid; e < ne; e += 256) {
+        const float2 v = acc[e];
+        if (v.x != 0.f || v.y != 0.f) {
+            float2 t = g[e];
+            t.x += v.x;
+            t.y += v.y;
+            g[e] = t;
+        }
+    }
+}
+
+// levels whose table gradient is binned: hashed (no spatial coherence to combine) and at most BIN_MAX_PER_LEVEL bins; -> number of bins
+static int bin_layout(const GridMeta& M, int (&bin_base)[MAX_LEVELS]) {
+    int n = 0;
+    for (int l = 0; l < M.n_levels; ++l) {
+        const uint64_t size = M.offset[l + 1] - M.offset[l], dense = (uint64_t)M.res[l] * M.res[l] * M.res[l];
+        const uint64_t nb = (size + BIN_ENTRIES - 1) >> BIN_LOG;
+        if (dense > size && nb <= (uint64_t)BIN_MAX_PER_LEVEL) {
+            bin_base[l] = n;
+            n += (int)nb;
+        } else {
+            bin_base[l] = -1;
+        }
+    }
+    return n;
+}
+
 }  // namespace
 
 static int make_meta(GridMeta& M, int n_levels, int F, int log2_T, int base_res, float per_level_scale) {
@@ -453,7 +612,7 @@ static int make_meta(GridMeta& M, int n_levels, int F, int log2_T, int base_res,
         uint32_t res = (uint32_t)std::ceil(scale) + 1u;
         uint64_t n = (uint64_t)res * res * res;
         n = (n + 7) / 8 * 8;
-        n = std::min<uint64_t>(n, 1ull << log2_T);
+        n = std::min<uint64_t>(n, 1ull << log2_T);        // (a hashed level, res^3 > n, therefore has exactly 2^log2_T entries: grid_index masks)
         M.scale[l] = scale;
         M.res[l] = res;
         M.offset[l] = (uint32_t)off;
@@ -528,9 +687,10 @@ extern "C" int gs_hashgrid_encode_fwd_rows(int n_levels, int F, int log2_T, int 
     return 0;
 }
 
-extern "C" int gs_hashgrid_encode_bwd(int n_levels, int F, int log2_T, int base_res, float per_level_scale, const float* pos, const float* aabb,
-                                      const float* mask, int64_t N, const float* params, const float* g_feat_level_major, float* g_params,
-                                      float* g_pos, float grad_scale, float table_scale, int64_t img_w, int64_t img_h, gs_stream_t stream) {
+static int encode_bwd_impl(int n_levels, int F, int log2_T, int base_res, float per_level_scale, const float* pos, const float* aabb, const float* mask,
+                           int64_t N, const float* params, const float* g_feat_level_major, float* g_params, float* g_pos, float grad_scale,
+                           float table_scale, int64_t img_w, int64_t img_h, uint32_t* bin_count, void* bin_records, int64_t bin_capacity,
+                           gs_stream_t stream, const char* who) {
     GridMeta M;
     int rc = make_meta(M, n_levels, F, log2_T, base_res, per_level_scale);
     if (rc) return rc;
@@ -541,11 +701,45 @@ extern "C" int gs_hashgrid_encode_bwd(int n_levels, int F, int log2_T, int base_
     EncArgs A{};
     A.pos = pos; A.aabb = aabb; A.mask = mask; A.N = N; A.params = params; A.g_feat = g_feat_level_major; A.g_params = g_params; A.g_pos = g_pos;
     A.grad_scale = grad_scale; A.table_scale = table_scale;
+    int n_bins = 0;
+    if (bin_records && g_params) {
+        GS_REQUIRE(bin_count && bin_capacity > 0 && bin_capacity < (1ll << 31), "gs_hashgrid_encode_bwd_binned: bin counters / capacity missing");
+        n_bins = bin_layout(M, A.bin_base);
+        if (n_bins > 0) {
+            A.bin_count = bin_count; A.bin_rec = static_cast<BinRec*>(bin_records); A.bin_cap = (uint32_t)bin_capacity;
+        }
+    }
     const bool tiled = img_w > 0 && img_h > 0 && img_w % 16 == 0 && img_h % 16 == 0 && N % (img_w * img_h) == 0 && N / (img_w * img_h) < 65536 &&
                        img_h / 16 < 65536;
     A.img_w = (int)img_w; A.img_h = (int)img_h;
     dim3 grid = tiled ? dim3((unsigned)(img_w / 16), (unsigned)(img_h / 16), (unsigned)(N / (img_w * img_h))) : dim3((unsigned)gs::cdiv(N, 256));
     hipLaunchKernelGGL(k_encode_bwd, grid, dim3(256), 0, (hipStream_t)stream, M, A, tiled ? 1 : 0);
+    if (n_bins > 0) hipLaunchKernelGGL(k_encode_bin_reduce, dim3((unsigned)n_bins), dim3(256), 0, (hipStream_t)stream, M, A);
     GS_LAUNCH_CHECK();
+    (void)who;
     return 0;
+}
+
+extern "C" int gs_hashgrid_encode_bwd(int n_levels, int F, int log2_T, int base_res, float per_level_scale, const float* pos, const float* aabb,
+                                      const float* mask, int64_t N, const float* params, const float* g_feat_level_major, float* g_params,
+                                      float* g_pos, float grad_scale, float table_scale, int64_t img_w, int64_t img_h, gs_stream_t stream) {
+    return encode_bwd_impl(n_levels, F, log2_T, base_res, per_level_scale, pos, aabb, mask, N, params, g_feat_level_major, g_params, g_pos, grad_scale,
+                           table_scale, img_w, img_h, nullptr, nullptr, 0, stream, "gs_hashgrid_encode_bwd");
+}
+
+extern "C" int64_t gs_hashgrid_bin_count(int n_levels, int F, int log2_T, int base_res, float per_level_scale) {
+    GridMeta M;
+    if (make_meta(M, n_levels, F, log2_T, base_res, per_level_scale)) return -1;
+    int bin_base[MAX_LEVELS];
+    return bin_layout(M, bin_base);
+}
+
+extern "C" int64_t gs_hashgrid_bin_entries(void) { return BIN_ENTRIES; }
+
+extern "C" int gs_hashgrid_encode_bwd_binned(int n_levels, int F, int log2_T, int base_res, float per_level_scale, const float* pos, const float* aabb,
+                                             const float* mask, int64_t N, const float* params, const float* g_feat_level_major, float* g_params,
+                                             float* g_pos, float grad_scale, float table_scale, int64_t img_w, int64_t img_h, uint32_t* bin_count,
+                                             void* bin_records, int64_t bin_capacity, gs_stream_t stream) {
+    return encode_bwd_impl(n_levels, F, log2_T, base_res, per_level_scale, pos, aabb, mask, N, params, g_feat_level_major, g_params, g_pos, grad_scale,
+                           table_scale, img_w, img_h, bin_count, bin_records, bin_capacity, stream, "gs_hashgrid_encode_bwd_binned");
 }

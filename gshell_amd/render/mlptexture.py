@@ -82,6 +82,26 @@ class _TexMlpFn(torch.autograd.Function):
         return g_x, None, g_w1, g_w2, g_w3, None, None
 
 
+BINNED_TABLE_GRAD = True   # _FieldFn backward: hashed levels' table gradient through per-bin record arrays (gs_hashgrid_encode_bwd_binned), no atomics
+import os as _os
+BIN_COVERAGE = float(_os.environ.get('GS_BIN_COVERAGE', 0.2))         # bin capacity is sized for this fraction of the rows having mask > 0 (x1.25 slack); fuller frames spill to the atomic path
+_bin_scratch = {}
+
+
+def _bins(cfg, N, device):
+    """(counters, records, capacity) of the binned table gradient, cached per device and size (the reducer leaves the counters zero)."""
+    nb = int(_lib.lib().gs_hashgrid_bin_count(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4])))
+    if nb <= 0:
+        return None
+    per_level = max(1, (1 << cfg[2]) // int(_lib.lib().gs_hashgrid_bin_entries()))      # bins of a full-size (hashed) level
+    cap = int(1.25 * BIN_COVERAGE * N * 8 / per_level) + 1024 + int(_os.environ.get('GS_BIN_SKEW', 0))
+    key = (str(device), nb, cap)
+    if key not in _bin_scratch:
+        _bin_scratch.clear()
+        _bin_scratch[key] = (torch.zeros(nb, dtype=torch.int32, device=device), torch.empty(nb * cap * 3, dtype=torch.int32, device=device), cap)
+    return _bin_scratch[key]
+
+
 COMPACT_ROWS = True      # _FieldFn: texture MLP over a device-compacted list of the masked rows (False: masked waves over all rows)
 
 
@@ -155,9 +175,17 @@ class _FieldFn(torch.autograd.Function):
                                                   ptr(g_feat), ptr(g_w1), ptr(g_w2), ptr(g_w3), stream()), "gs_texmlp_bwd_level_major")
             if g_feat is not None:
                 # d/d feat of the MLP carries the x128 hook; the table gradient takes it as is, the position gradient takes x128 / 128
-                check(L.gs_hashgrid_encode_bwd(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4]), ptr(pos_c), ptr(ab), ptr(m_c),
-                                               c_int64(N), ptr(p_c), ptr(g_feat), ptr(g_params), ptr(g_pos), c_float(mlp_scale * enc_scale),
-                                               c_float(mlp_scale), c_int64(W), c_int64(H), stream()), "gs_hashgrid_encode_bwd")
+                bins = _bins(cfg, N, g.device) if (BINNED_TABLE_GRAD and need_p) else None
+                if bins is not None:
+                    check(L.gs_hashgrid_encode_bwd_binned(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4]), ptr(pos_c), ptr(ab),
+                                                          ptr(m_c), c_int64(N), ptr(p_c), ptr(g_feat), ptr(g_params), ptr(g_pos),
+                                                          c_float(mlp_scale * enc_scale), c_float(mlp_scale), c_int64(W), c_int64(H), ptr(bins[0]),
+                                                          ptr(bins[1]), c_int64(bins[2]), stream()), "gs_hashgrid_encode_bwd_binned")
+                else:
+                    check(L.gs_hashgrid_encode_bwd(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4]), ptr(pos_c), ptr(ab),
+                                                   ptr(m_c), c_int64(N), ptr(p_c), ptr(g_feat), ptr(g_params), ptr(g_pos),
+                                                   c_float(mlp_scale * enc_scale), c_float(mlp_scale), c_int64(W), c_int64(H), stream()),
+                          "gs_hashgrid_encode_bwd")
         return g_pos, g_params, None, g_w1, g_w2, g_w3, None, None, None, None, None, None, None
 
 

@@ -395,6 +395,20 @@ int gs_hashgrid_encode_bwd(int n_levels, int F, int log2_T, int base_res, float 
                            float* g_pos, float grad_scale, float table_scale, int64_t img_w,
                            int64_t img_h,
                            gs_stream_t stream);
+/* The same backward with the table gradient of the HASHED levels (res^3 > table size) gathered without atomics: the level's
+ * table is cut into bins of 4096 entries, k_encode_bwd writes (entry, d pair) records into per-bin arrays of `bin_capacity`
+ * 12-byte records (one returning atomic per workgroup, level and bin reserves the run), a second launch sums every bin in LDS
+ * and adds it to g_params.  A reservation past `bin_capacity` takes the atomic path, so the result is correct for ANY capacity;
+ * uniform hashing puts ~ 8 * (rows with mask > 0) / 128 records in a bin.  `bin_count` [gs_hashgrid_bin_count()] uint32, zero
+ * before the first call (the reducer leaves it zero); `bin_records` [bins * bin_capacity * 12 bytes] scratch. */
+int64_t gs_hashgrid_bin_count(int n_levels, int F, int log2_T, int base_res, float per_level_scale);
+int64_t gs_hashgrid_bin_entries(void);     /* table entries per bin */
+int gs_hashgrid_encode_bwd_binned(int n_levels, int F, int log2_T, int base_res, float per_level_scale,
+                                  const float* pos, const float* aabb, const float* mask, int64_t N,
+                                  const float* params, const float* g_feat_level_major,
+                                  float* g_params, float* g_pos, float grad_scale, float table_scale,
+                                  int64_t img_w, int64_t img_h, uint32_t* bin_count,
+                                  void* bin_records, int64_t bin_capacity, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Softplus with first and second derivative   (the activation of geometry/mlp.py:19-33, nn.Softplus(beta=100);

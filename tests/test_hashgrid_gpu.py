@@ -155,3 +155,41 @@ def test_texture_field_fused_path_matches_separate_operators(shape, smooth):
     tex.fused_field = True
     one = tex.sample(pos.to(DEV), mask=mask.to(DEV))
     assert torch.equal(one * m, res[True][1] * m)
+
+
+@pytest.mark.parametrize("capacity", [3, 64, 100000])
+def test_binned_table_gradient_equals_the_atomic_path_for_any_capacity(capacity):
+    """gs_hashgrid_encode_bwd_binned (hashed levels' table gradient through per-bin record arrays summed in LDS) against
+    gs_hashgrid_encode_bwd (atomics): same sums in another order -> 1e-5 of the maximum; the position gradient is computed by the
+    same code -> bit equal.  capacity 3 / 64: almost every reservation overflows and spills to the atomic path; the reducer must
+    leave the counters at zero (they are not cleared between calls), so the call is repeated on the same scratch."""
+    from gshell_amd import _lib
+    from gshell_amd._lib import c_float, c_int, c_int64, check, ptr, stream
+    L = _lib.lib()
+    cfg = (16, 2, 19, 16, float(np.exp(np.log(4096 / 16) / 15)))
+    n_par = int(L.gs_hashgrid_num_params(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4])))
+    nb = int(L.gs_hashgrid_bin_count(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4])))
+    assert nb == 11 * 128            # levels 5..15 of the reference's texture configuration are hashed, 2^19 entries = 128 bins each
+    pos, mask = _field_case((2, 64, 64), True, seed=9)
+    pos, mask = pos.reshape(-1, 3).to(DEV).contiguous(), mask.reshape(-1).to(DEV).contiguous()
+    N = pos.shape[0]
+    g = torch.Generator().manual_seed(10)
+    params = ((torch.rand(n_par, generator=g) - 0.5) * 0.6).to(DEV)
+    g_feat = torch.randn(16, N, 2, generator=g).to(DEV)
+    aabb = torch.tensor([[-1.0, -0.9, -0.8], [1.0, 1.1, 0.9]], device=DEV)
+    head = (c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4]), ptr(pos), ptr(aabb), ptr(mask), c_int64(N), ptr(params), ptr(g_feat))
+    tail = (c_float(1.0), c_float(128.0), c_int64(64), c_int64(64))
+    gp_a, gx_a = torch.zeros(n_par, device=DEV), torch.empty_like(pos)
+    check(L.gs_hashgrid_encode_bwd(*head, ptr(gp_a), ptr(gx_a), *tail, stream()), "gs_hashgrid_encode_bwd")
+    count = torch.zeros(nb, dtype=torch.int32, device=DEV)
+    rec = torch.empty(nb * capacity * 3, dtype=torch.int32, device=DEV)
+    scale = float(gp_a.abs().max())
+    assert scale > 0
+    for rep in range(2):
+        gp_b, gx_b = torch.zeros(n_par, device=DEV), torch.empty_like(pos)
+        check(L.gs_hashgrid_encode_bwd_binned(*head, ptr(gp_b), ptr(gx_b), *tail, ptr(count), ptr(rec), c_int64(capacity), stream()), "binned")
+        assert int(count.abs().max()) == 0, "the reducer must leave the bin counters at zero"
+        assert torch.equal(gx_a, gx_b)
+        err = float((gp_a - gp_b).abs().max()) / scale
+        assert err <= 1e-5, (rep, err)
+        assert torch.equal(gp_a != 0, gp_b != 0), "the two paths must touch the same table entries"
