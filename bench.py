@@ -196,7 +196,7 @@ def main():
 
 
 ROOFLINE_CANDIDATES = {"gs_env_shade_fwd", "gs_sdf_mlp_fwd_h1", "gs_sdf_mlp_fwd_h2", "gs_sdf_mlp_fwd", "gs_sdf_mlp_h2_refine_rows", "gs_mtets_flag_refine_rows",
-                       "gs_env_shade_bwd_saved", "gs_hashgrid_encode_bwd", "gs_sdf_mlp_h2_wgrad", "gs_sdf_mlp_h2_bwd", "gs_flexi_vd_bwd", "gs_flexi_vd_fwd"}
+                       "gs_env_shade_bwd_saved", "gs_hashgrid_encode_bwd", "gs_hashgrid_encode_bwd_binned", "gs_sdf_mlp_h2_wgrad", "gs_sdf_mlp_h2_bwd", "gs_flexi_vd_bwd", "gs_flexi_vd_fwd"}
 
 
 def pmc_traffic(kernel):

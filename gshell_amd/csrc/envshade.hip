@@ -371,6 +371,7 @@ struct ShadeArgs {
     float *diff, *spec;                                  // fwd outputs [B,H,W,3]
     const float *g_diff, *g_spec;                        // bwd inputs
     float *g_pos, *g_nrm, *g_kd, *g_ks, *g_light;        // bwd outputs
+    int tex_stride, g_tex_stride;                       // floats between pixels in kd / ks (g_kd / g_ks): 3, or 6 when both are channel halves of one [B,H,W,6] tensor
     // light gradient by binning instead of atomics (backward from saved samples, see k_light_*):
     float4* rec;               // [n_rays] (d loss / d light texel rgb, texel id as bits) per sample, LG_NONE = nothing to add
     uint32_t* hist;            // [nbins][workgroups of k_shade_grad]
@@ -471,8 +472,8 @@ __global__ void __launch_bounds__(256, BWD ? 1 : GS_SAMPLES_WAVES) k_shade_sampl
     c.pos = ld3(A.pos + 3 * gid);
     c.nrm = ld3(A.nrm + 3 * gid);
     c.view = ld3(A.view_pos + 3 * b);
-    c.kd = ld3(A.kd + 3 * gid);
-    c.ks = ld3(A.ks + 3 * gid);
+    c.kd = ld3(A.kd + A.tex_stride * gid);
+    c.ks = ld3(A.ks + A.tex_stride * gid);
     v3 g_diff = V3(0.f), g_spec = V3(0.f);
     if (BWD) {
         g_diff = ld3(A.g_diff + 3 * gid);
@@ -555,8 +556,8 @@ __global__ void __launch_bounds__(256, BWD ? 1 : GS_SAMPLES_WAVES) k_shade_sampl
             float* p;
             p = A.g_pos + 3 * gid; p[0] = a_pos.x; p[1] = a_pos.y; p[2] = a_pos.z;
             p = A.g_nrm + 3 * gid; p[0] = a_nrm.x; p[1] = a_nrm.y; p[2] = a_nrm.z;
-            p = A.g_kd + 3 * gid;  p[0] = a_kd.x;  p[1] = a_kd.y;  p[2] = a_kd.z;
-            p = A.g_ks + 3 * gid;  p[0] = a_ks.x;  p[1] = a_ks.y;  p[2] = a_ks.z;
+            p = A.g_kd + A.g_tex_stride * gid;  p[0] = a_kd.x;  p[1] = a_kd.y;  p[2] = a_kd.z;
+            p = A.g_ks + A.g_tex_stride * gid;  p[0] = a_ks.x;  p[1] = a_ks.y;  p[2] = a_ks.z;
         }
     }
 }
@@ -586,8 +587,8 @@ __global__ void __launch_bounds__(256, GS_GRAD_WAVES) k_shade_grad(ShadeArgs A) 
         c.pos = ld3(A.pos + 3 * gid);
         c.nrm = ld3(A.nrm + 3 * gid);
         c.view = ld3(A.view_pos + 3 * b);
-        c.kd = ld3(A.kd + 3 * gid);
-        c.ks = ld3(A.ks + 3 * gid);
+        c.kd = ld3(A.kd + A.tex_stride * gid);
+        c.ks = ld3(A.ks + A.tex_stride * gid);
         const v3 g_diff = ld3(A.g_diff + 3 * gid), g_spec = ld3(A.g_spec + 3 * gid);
         const int S = A.n * A.n;
         c.alpha = c.ks.y * c.ks.y;
@@ -625,8 +626,8 @@ __global__ void __launch_bounds__(256, GS_GRAD_WAVES) k_shade_grad(ShadeArgs A) 
             float* p;
             p = A.g_pos + 3 * gid; p[0] = a_pos.x; p[1] = a_pos.y; p[2] = a_pos.z;
             p = A.g_nrm + 3 * gid; p[0] = a_nrm.x; p[1] = a_nrm.y; p[2] = a_nrm.z;
-            p = A.g_kd + 3 * gid;  p[0] = a_kd.x;  p[1] = a_kd.y;  p[2] = a_kd.z;
-            p = A.g_ks + 3 * gid;  p[0] = a_ks.x;  p[1] = a_ks.y;  p[2] = a_ks.z;
+            p = A.g_kd + A.g_tex_stride * gid;  p[0] = a_kd.x;  p[1] = a_kd.y;  p[2] = a_kd.z;
+            p = A.g_ks + A.g_tex_stride * gid;  p[0] = a_ks.x;  p[1] = a_ks.y;  p[2] = a_ks.z;
         }
     }
     if (binned) {
@@ -771,8 +772,14 @@ __global__ void __launch_bounds__(256) k_shade_trace(ShadeArgs A, int64_t n_rays
                 live = !(__float_as_uint(d.w) >> 31);              // sign bit of k = dead ray (k_shade_samples)
                 if (live) {
                     const int64_t gid = A.pix[r / rays_per_pixel];
-                    const float* o = A.ro + 3 * gid;
-                    o0 = o[0]; o1 = o[1]; o2 = o[2]; d0 = d.x; d1 = d.y; d2 = d.z;
+                    if (A.ro) {
+                        const float* o = A.ro + 3 * gid;
+                        o0 = o[0]; o1 = o[1]; o2 = o[2];
+                    } else {            // ro = gb_pos + gb_normal * 0.001, the reference's call site (render/render.py:131), rounded like its two ATen ops
+                        const float *pp = A.pos + 3 * gid, *nn = A.nrm + 3 * gid;
+                        o0 = pp[0] + nn[0] * 0.001f; o1 = pp[1] + nn[1] * 0.001f; o2 = pp[2] + nn[2] * 0.001f;
+                    }
+                    d0 = d.x; d1 = d.y; d2 = d.z;
                     live = (d0 == d0 && d1 == d1 && d2 == d2) && !(d0 == 0.f && d1 == 0.f && d2 == 0.f);
                 }
             }
@@ -855,13 +862,15 @@ int fill_args(ShadeArgs& A, const gs_bvh* bvh, const int32_t* pix, int64_t n_cov
               int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B, int64_t H, int64_t W, int64_t view_offset, int64_t view_stride,
               int bsdf, int n, uint32_t seed, float shadow_scale, uint64_t* vis_bits) {
     GS_REQUIRE(bvh != nullptr, "env_shade: bvh is null");
-    GS_REQUIRE(pix && ro && pos && nrm && view_pos && kd && ks && light && pdf && rows && cols && perms && vis_bits, "env_shade: null pointer");
+    GS_REQUIRE(pix && pos && nrm && view_pos && kd && ks && light && pdf && rows && cols && perms && vis_bits, "env_shade: null pointer");
     GS_REQUIRE(bsdf >= 0 && bsdf <= 2, "env_shade: BSDF id must be 0 (pbr), 1 (diffuse) or 2 (white)");
     GS_REQUIRE(n >= 1 && n <= 64 && P >= 1 && Hl >= 2 && Wl >= 2, "env_shade: bad sample / probe configuration");
     GS_REQUIRE(B * H * W < (1ll << 31), "env_shade: too many pixels for 32-bit pixel ids");
     A.bvh = bvh_view(bvh);
     A.probe = {light, pdf, rows, cols, (int)Hl, (int)Wl, cdf_iters((int)Hl), cdf_iters((int)Wl)};
     A.pix = pix; A.n_cov = n_cov; A.ro = ro; A.pos = pos; A.nrm = nrm; A.view_pos = view_pos; A.kd = kd; A.ks = ks;
+    A.tex_stride = (ks == kd + 3 && n_cov > 0) ? 6 : 3;        // ks = kd + 3: kd | ks interleaved in one 6-channel tensor (include/gshell_hip.h)
+    A.g_tex_stride = 3;
     A.perms = perms; A.P = (int)P; A.HW = H * W; A.bsdf = bsdf; A.n = n;
     int G = 1;
     while (G * 2 <= std::min(n * n, 64)) G *= 2;
@@ -1166,14 +1175,16 @@ static int env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, c
     size_t nb = (size_t)B * H * W * 12;
     GS_HIP_CHECK(hipMemsetAsync(g_pos, 0, nb, stream));
     GS_HIP_CHECK(hipMemsetAsync(g_normal, 0, nb, stream));
-    GS_HIP_CHECK(hipMemsetAsync(g_kd, 0, nb, stream));
-    GS_HIP_CHECK(hipMemsetAsync(g_ks, 0, nb, stream));
+    const bool g_tex6 = g_ks == g_kd + 3;          // g_kd | g_ks interleaved in one [B,H,W,6] tensor
+    GS_HIP_CHECK(hipMemsetAsync(g_kd, 0, g_tex6 ? 2 * nb : nb, stream));
+    if (!g_tex6) GS_HIP_CHECK(hipMemsetAsync(g_ks, 0, nb, stream));
     if (n_cov == 0) return 0;
     ShadeArgs A{};
     int rc = fill_args(A, bvh, pix, n_cov, gb_pos /* ro unused in bwd */, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl,
                        perms, P, B, H, W, view_offset, view_stride, bsdf, n_samples_x, rnd_seed, shadow_scale, const_cast<uint64_t*>(vis_bits));
     if (rc) return rc;
     A.g_diff = g_diff; A.g_spec = g_spec; A.g_pos = g_pos; A.g_nrm = g_normal; A.g_kd = g_kd; A.g_ks = g_ks; A.g_light = g_light;
+    A.g_tex_stride = g_tex6 ? 6 : 3;
     if (saved_rays) {
         // the forward scratch = [n_rays] float4 (direction, k) | [n_rays] 6 floats of unshadowed contributions (dead by now).
         // Records go over the contributions, the sorted records over (direction, k) once the gradient kernel has read them; the

@@ -463,6 +463,75 @@ __global__ void __launch_bounds__(256) k_interp_bwd(const float* __restrict__ at
 }
 
 
+// ---- interpolate, several per-vertex attribute tensors in one pass ------------------------------------------------------
+// The g-buffer of a frame is position, smooth normal (and mSDF) interpolated with the same barycentrics (reference
+// render/render.py:240, :263, :306 interpolates them one by one).  One launch, one contiguous output per attribute: no stacked [V,7] copy, no
+// channel slices downstream (a slice of a stacked output costs a copy per consumer forward and a zero fill + copy + add backward).
+// Per channel the arithmetic is k_interp_fwd / k_interp_bwd's, in the order of the stacked tensor: bit-identical results.
+struct InterpGroups {
+    const float* attr[4];
+    float* out[4];
+    const float* g_out[4];
+    float* g_attr[4];
+    int ch[4];
+    int n;
+};
+
+__global__ void __launch_bounds__(256) k_interp_groups_fwd(InterpGroups G, const float4* __restrict__ rast, const int32_t* __restrict__ tri, int64_t T,
+                                                           int64_t npix) {
+    int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npix) return;
+    const float4 r = rast[pix];
+    const int32_t t = (int32_t)r.w - 1;
+    const bool hit = t >= 0 && t < T;
+    int64_t i0 = 0, i1 = 0, i2 = 0;
+    if (hit) {
+        i0 = tri[3 * (int64_t)t];
+        i1 = tri[3 * (int64_t)t + 1];
+        i2 = tri[3 * (int64_t)t + 2];
+    }
+    const float b0 = r.x, b1 = r.y, b2 = 1.0f - r.x - r.y;
+    for (int k = 0; k < G.n; ++k) {
+        const int A = G.ch[k];
+        float* o = G.out[k] + pix * A;
+        const float* a = G.attr[k];
+        for (int c = 0; c < A; ++c) o[c] = hit ? b0 * a[i0 * A + c] + b1 * a[i1 * A + c] + b2 * a[i2 * A + c] : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_interp_groups_bwd(InterpGroups G, const float4* __restrict__ rast, const int32_t* __restrict__ tri, int64_t T,
+                                                           int64_t npix, float4* __restrict__ g_rast) {
+    int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npix) return;
+    const float4 r = rast[pix];
+    const int32_t t = (int32_t)r.w - 1;
+    float gb0 = 0.f, gb1 = 0.f;
+    if (t >= 0 && t < T) {
+        const int64_t i0 = tri[3 * (int64_t)t], i1 = tri[3 * (int64_t)t + 1], i2 = tri[3 * (int64_t)t + 2];
+        const float b0 = r.x, b1 = r.y, b2 = 1.0f - r.x - r.y;
+        for (int k = 0; k < G.n; ++k) {
+            if (!G.g_out[k]) continue;
+            const int A = G.ch[k];
+            const float* g = G.g_out[k] + pix * A;
+            const float* a = G.attr[k];
+            float* ga = G.g_attr[k];
+            for (int c = 0; c < A; ++c) {
+                const float gc = g[c];
+                if (gc == 0.0f) continue;
+                const float v0 = a[i0 * A + c], v1 = a[i1 * A + c], v2 = a[i2 * A + c];
+                gb0 += gc * (v0 - v2);
+                gb1 += gc * (v1 - v2);
+                if (ga) {
+                    atomicAdd(&ga[i0 * A + c], gc * b0);
+                    atomicAdd(&ga[i1 * A + c], gc * b1);
+                    atomicAdd(&ga[i2 * A + c], gc * b2);
+                }
+            }
+        }
+    }
+    if (g_rast) g_rast[pix] = make_float4(gb0, gb1, 0.f, 0.f);
+}
+
 // ---- per-pixel geometric (face) normal ---------------------------------------------------------------
 // The reference interpolates a per-face constant with index [[i,i,i]] (render/render.py:243-248), i.e. a gather by
 // triangle id.  n = cross(v1-v0, v2-v0) / sqrt(max(|.|^2, 1e-20))  (util.safe_normalize).
@@ -622,6 +691,52 @@ extern "C" int gs_interpolate_bwd(const float* attr, int64_t Ba, int64_t V, int6
     GS_REQUIRE(T == 0 || (attr && tri), "gs_interpolate_bwd: null mesh pointer");
     hipLaunchKernelGGL(k_interp_bwd, dim3((unsigned)gs::cdiv(npix, 256)), dim3(256), 0, (hipStream_t)stream, attr, Ba, V, (int)A,
                        (const float4*)rast, tri, T, B, H * W, g_out, g_attr, (float4*)g_rast);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+static int interp_groups_args(InterpGroups& G, int n_groups, const int32_t* channels, const float* const* attrs, int64_t T, const char* who) {
+    GS_REQUIRE(n_groups >= 1 && n_groups <= 4 && channels && attrs, "gs_interpolate_groups: 1..4 attribute tensors");
+    G.n = n_groups;
+    for (int k = 0; k < n_groups; ++k) {
+        GS_REQUIRE(channels[k] >= 1 && channels[k] <= 64 && (attrs[k] || T == 0), "gs_interpolate_groups: bad attribute tensor");   // empty mesh: nothing is read
+        G.ch[k] = channels[k];
+        G.attr[k] = attrs[k];
+    }
+    (void)who;
+    return 0;
+}
+
+extern "C" int gs_interpolate_groups_fwd(int n_groups, const int32_t* channels, const float* const* attrs, const float* rast, const int32_t* tri, int64_t T,
+                                         int64_t B, int64_t H, int64_t W, float* const* outs, gs_stream_t stream) {
+    const int64_t npix = B * H * W;
+    if (npix == 0) return 0;
+    InterpGroups G{};
+    if (int rc = interp_groups_args(G, n_groups, channels, attrs, T, "gs_interpolate_groups_fwd")) return rc;
+    GS_REQUIRE(rast && outs && (T == 0 || tri), "gs_interpolate_groups_fwd: null pointer");
+    for (int k = 0; k < n_groups; ++k) {
+        GS_REQUIRE(outs[k], "gs_interpolate_groups_fwd: null output");
+        G.out[k] = outs[k];
+    }
+    hipLaunchKernelGGL(k_interp_groups_fwd, dim3((unsigned)gs::cdiv(npix, 256)), dim3(256), 0, (hipStream_t)stream, G, (const float4*)rast, tri, T, npix);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_interpolate_groups_bwd(int n_groups, const int32_t* channels, const float* const* attrs, const float* rast, const int32_t* tri, int64_t T,
+                                         int64_t B, int64_t H, int64_t W, const float* const* g_outs, float* const* g_attrs, float* g_rast,
+                                         gs_stream_t stream) {
+    const int64_t npix = B * H * W;
+    if (npix == 0) return 0;
+    InterpGroups G{};
+    if (int rc = interp_groups_args(G, n_groups, channels, attrs, T, "gs_interpolate_groups_bwd")) return rc;
+    GS_REQUIRE(rast && g_outs && g_attrs && (T == 0 || tri), "gs_interpolate_groups_bwd: null pointer");
+    for (int k = 0; k < n_groups; ++k) {
+        G.g_out[k] = g_outs[k];        // NULL: no gradient flows into this output
+        G.g_attr[k] = g_attrs[k];      // NULL: this attribute needs no gradient; otherwise ACCUMULATED (atomics)
+    }
+    hipLaunchKernelGGL(k_interp_groups_bwd, dim3((unsigned)gs::cdiv(npix, 256)), dim3(256), 0, (hipStream_t)stream, G, (const float4*)rast, tri, T, npix,
+                       (float4*)g_rast);
     GS_LAUNCH_CHECK();
     return 0;
 }

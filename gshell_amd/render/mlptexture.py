@@ -114,7 +114,7 @@ class _FieldFn(torch.autograd.Function):
     pos [N,3] world positions, mask [N] or None, img = (H, W) when the rows are whole images (tiles the backward)."""
 
     @staticmethod
-    def forward(ctx, pos, params, mask, w1, w2, w3, lo, hi, aabb, cfg, mlp_scale, enc_scale, img):
+    def forward(ctx, pos, params, mask, w1, w2, w3, lo, hi, aabb, cfg, mlp_scale, enc_scale, img, parts=1):
         L = _lib.lib()
         f = lambda t: None if t is None else t.detach().contiguous().float()
         pos_c, p_c, m_c = f(pos), f(params), (None if mask is None else f(mask.reshape(-1)))
@@ -148,15 +148,24 @@ class _FieldFn(torch.autograd.Function):
                                                   ptr(out), stream()), "gs_texmlp_fwd_level_major")
         ctx.rows = (rows, count)
         ctx.save_for_backward(pos_c, p_c, m_c, feat, ab, *ws)
-        ctx.cfg, ctx.scales, ctx.img = cfg, (float(mlp_scale), float(enc_scale)), img
-        return out
+        ctx.cfg, ctx.scales, ctx.img, ctx.parts = cfg, (float(mlp_scale), float(enc_scale)), img, parts
+        if parts == 1:
+            return out
+        # the `parts` coordinate sets as separate outputs (row blocks of the one buffer): slicing a single output instead costs a zero fill,
+        # a copy and an add of the whole [parts * n, C] gradient per part in backward
+        n = N // parts
+        return tuple(out[j * n:(j + 1) * n] for j in range(parts))
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, *g_outs):
         pos_c, p_c, m_c, feat, ab, w1, w2, w3, lo, hi = ctx.saved_tensors
         cfg, (mlp_scale, enc_scale), img = ctx.cfg, ctx.scales, ctx.img
         L = _lib.lib()
-        g = g_out.contiguous().float()
+        if ctx.parts == 1:
+            g = g_outs[0].contiguous().float()
+        else:
+            n = pos_c.shape[0] // ctx.parts
+            g = torch.cat([torch.zeros((n, w3.shape[0]), dtype=torch.float32, device=pos_c.device) if t is None else t.float() for t in g_outs], 0)
         N, C = pos_c.shape[0], w3.shape[0]
         need_pos, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g_feat = torch.empty_like(feat) if (need_pos or need_p) else None
@@ -186,7 +195,7 @@ class _FieldFn(torch.autograd.Function):
                                                    ptr(m_c), c_int64(N), ptr(p_c), ptr(g_feat), ptr(g_params), ptr(g_pos),
                                                    c_float(mlp_scale * enc_scale), c_float(mlp_scale), c_int64(W), c_int64(H), stream()),
                           "gs_hashgrid_encode_bwd")
-        return g_pos, g_params, None, g_w1, g_w2, g_w3, None, None, None, None, None, None, None
+        return g_pos, g_params, None, g_w1, g_w2, g_w3, None, None, None, None, None, None, None, None
 
 
 class HashGridEncoding(torch.nn.Module):
@@ -301,9 +310,8 @@ class MLPTexture3D(torch.nn.Module):
         img = (int(shp[-3]), int(shp[-2])) if texcs[0].dim() >= 3 else None
         out = _FieldFn.apply(pos, self.encoder.params, m, lin[0].weight, lin[1].weight, lin[2].weight, self.min_max[0], self.min_max[1],
                              self._aabb_tensor(),
-                             self.encoder.cfg, self.net.loss_scale, 1.0 / self.gradient_scaling, img)
-        n = out.shape[0] // k
-        return [out[j * n:(j + 1) * n].view(*shp[:-1], self.channels) for j in range(k)]
+                             self.encoder.cfg, self.net.loss_scale, 1.0 / self.gradient_scaling, img, k)
+        return [o.view(*shp[:-1], self.channels) for o in ((out,) if k == 1 else out)]
 
     def clamp_(self):
         pass

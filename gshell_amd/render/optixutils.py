@@ -94,7 +94,7 @@ class _optix_env_shade_func(torch.autograd.Function):
         n_cov = pix.shape[0]
         scratch = torch.empty((max(int(L.gs_env_shade_scratch_bytes(c_int64(n_cov), c_int(n))), 8) + 7) // 8, dtype=torch.int64, device=pix.device)
         check(L.gs_env_shade_fwd(optix_ctx.handle, ptr(pix, torch.int32), c_int64(n_cov), ptr(t["ro"]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view),
-                                 ptr(t["kd"]), ptr(t["ks"]), ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]), c_int64(lgt.shape[1]),
+                                 t["kd_ptr"], t["ks_ptr"], ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]), c_int64(lgt.shape[1]),
                                  ptr(perms, torch.int32), c_int64(perms.shape[0]), c_int64(B), c_int64(H), c_int64(W), c_int64(view_map[0]), c_int64(view_map[1]),
                                  c_int(BSDF), c_int(n), c_uint32(seed & 0xFFFFFFFF), c_float(shadow_scale), ptr(scratch), ptr(vis), ptr(diff), ptr(spec), stream()),
               "gs_env_shade_fwd")
@@ -102,7 +102,7 @@ class _optix_env_shade_func(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, BSDF, n_samples_x, rnd_seed,
-                shadow_scale, view_map=(0, 1)):
+                shadow_scale, view_map=(0, 1), kd_ks=None):
         L = _lib.lib()
         _rnd_seed = int(np.random.randint(2 ** 31)) if rnd_seed is None else int(rnd_seed)
         B, H, W, _ = gb_pos.shape
@@ -115,7 +115,15 @@ class _optix_env_shade_func(torch.autograd.Function):
         pix = torch.nonzero(mask.detach().expand(B, H, W).reshape(-1) > 0).reshape(-1).int()
         global last_covered_pixels
         last_covered_pixels = int(pix.shape[0])
-        t = dict(ro=c3(ro), pos=c3(gb_pos), nrm=c3(gb_normal), kd=c3(gb_kd), ks=c3(gb_ks))
+        t = dict(ro=None if ro is None else c3(ro), pos=c3(gb_pos), nrm=c3(gb_normal))      # ro None: gb_pos + gb_normal * 0.001 inside the kernel
+        if kd_ks is not None:      # kd | ks as the channel halves of one [B,H,W,6] tensor (gs_env_shade_*: ks = kd + 3 -> pixel stride 6)
+            if tuple(kd_ks.shape) != (B, H, W, 6):
+                raise _lib.GShellHipError(f"kd_ks must be [B,H,W,6], got {tuple(kd_ks.shape)}")
+            t["tex"] = kd_ks.detach().contiguous().float()
+            t["kd_ptr"], t["ks_ptr"] = ptr(t["tex"]), c_void_p(t["tex"].data_ptr() + 12)
+        else:
+            t["kd"], t["ks"] = c3(gb_kd), c3(gb_ks)
+            t["kd_ptr"], t["ks_ptr"] = ptr(t["kd"]), ptr(t["ks"])
         if tuple(gb_view_pos.shape) not in ((B, 1, 1, 3), (1, 1, 1, 3)):
             raise _lib.GShellHipError(f"gb_view_pos must be [B,1,1,3] (one eye per view), got {tuple(gb_view_pos.shape)}")
         view = gb_view_pos.detach().expand(B, 1, 1, 3).reshape(B, 3).contiguous().float()
@@ -132,7 +140,7 @@ class _optix_env_shade_func(torch.autograd.Function):
         ctx.scratch = scratch if (SAVED_SAMPLES and any(ctx.needs_input_grad)) else None
         ctx.args = (optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, rnd_seed, _rnd_seed, shadow_scale, vis)
         ctx.view_map = view_map
-        ctx.shapes = (gb_pos.shape, gb_normal.shape, gb_kd.shape, gb_ks.shape, light.shape)
+        ctx.shapes = (gb_pos.shape, gb_normal.shape, None if kd_ks is not None else gb_kd.shape, None if kd_ks is not None else gb_ks.shape, light.shape)
         return diff, spec
 
     @staticmethod
@@ -141,7 +149,14 @@ class _optix_env_shade_func(torch.autograd.Function):
         B, H, W, _ = t["pos"].shape
         dev = t["pos"].device
         gd, gs = diff_grad.contiguous().float(), spec_grad.contiguous().float()
-        g_pos, g_nrm, g_kd, g_ks = (torch.empty((B, H, W, 3), dtype=torch.float32, device=dev) for _ in range(4))
+        g_pos, g_nrm = (torch.empty((B, H, W, 3), dtype=torch.float32, device=dev) for _ in range(2))
+        packed = "tex" in t
+        if packed:
+            g_tex = torch.empty((B, H, W, 6), dtype=torch.float32, device=dev)
+            g_kd_ptr, g_ks_ptr = ptr(g_tex), c_void_p(g_tex.data_ptr() + 12)
+        else:
+            g_kd, g_ks = (torch.empty((B, H, W, 3), dtype=torch.float32, device=dev) for _ in range(2))
+            g_kd_ptr, g_ks_ptr = ptr(g_kd), ptr(g_ks)
         g_light = torch.zeros_like(lgt)
         with torch.cuda.device(dev):
             if rnd_seed is None:
@@ -156,29 +171,34 @@ class _optix_env_shade_func(torch.autograd.Function):
                 _rnd_seed = _fwd_seed      # same seed -> same rays -> the cached visibility bits are exact
                 scratch = ctx.scratch
             fn, extra = ((_lib.lib().gs_env_shade_bwd_saved, (ptr(scratch),)) if scratch is not None else (_lib.lib().gs_env_shade_bwd, ()))
-            check(fn(optix_ctx.handle, ptr(pix), c_int64(pix.shape[0]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view), ptr(t["kd"]),
-                                              ptr(t["ks"]), ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]),
+            check(fn(optix_ctx.handle, ptr(pix), c_int64(pix.shape[0]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view), t["kd_ptr"],
+                                              t["ks_ptr"], ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]),
                                               c_int64(lgt.shape[1]), ptr(perms), c_int64(perms.shape[0]), c_int64(B), c_int64(H), c_int64(W),
                                               c_int64(ctx.view_map[0]), c_int64(ctx.view_map[1]), c_int(BSDF), c_int(n_samples_x), c_uint32(_rnd_seed & 0xFFFFFFFF), c_float(shadow_scale), ptr(vis),
-                                              *extra, ptr(gd), ptr(gs), ptr(g_pos), ptr(g_nrm), ptr(g_kd), ptr(g_ks), ptr(g_light), stream()),
+                                              *extra, ptr(gd), ptr(gs), ptr(g_pos), ptr(g_nrm), g_kd_ptr, g_ks_ptr, ptr(g_light), stream()),
                   "gs_env_shade_bwd")
         ctx.scratch = None
         s = ctx.shapes
 
         def red(g, shape):
             return g if tuple(shape) == tuple(g.shape) else g.sum_to_size(shape)
+        if packed:
+            return (None, None, None, red(g_pos, s[0]), red(g_nrm, s[1]), None, None, None, g_light, None, None, None, None, None, None, None, None, g_tex)
         return (None, None, None, red(g_pos, s[0]), red(g_nrm, s[1]), None, red(g_kd, s[2]), red(g_ks, s[3]), g_light, None, None, None, None, None,
-                None, None, None)
+                None, None, None, None)
 
 
 def optix_env_shade(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, BSDF='pbr', n_samples_x=8,
-                    rnd_seed=None, shadow_scale=1.0, view_offset=0, view_stride=1):
+                    rnd_seed=None, shadow_scale=1.0, view_offset=0, view_stride=1, kd_ks=None):
     """-> (diffuse [B,H,W,3], specular [B,H,W,3]) demodulated radiance (ops.py:141-143).
     `view_offset`, `view_stride` (not in the reference, which is single-GPU): local view b is view b*stride + offset of the
-    global batch -- the sampler hashes the GLOBAL pixel index so that view-sharded ranks draw the single-GPU samples."""
+    global batch -- the sampler hashes the GLOBAL pixel index so that view-sharded ranks draw the single-GPU samples.
+    `kd_ks` (not in the reference): the [B,H,W,6] tensor whose channel halves gb_kd / gb_ks are (what MLPTexture3D.sample returns); the
+    kernels then read it in place and the gradient comes back as one tensor (gb_kd / gb_ks are ignored).  `ro` None: gb_pos + 0.001 gb_normal."""
     iBSDF = _BSDF_IDS.index(BSDF)
-    return _optix_env_shade_func.apply(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, iBSDF,
-                                       n_samples_x, rnd_seed, shadow_scale, (int(view_offset), int(view_stride)))
+    return _optix_env_shade_func.apply(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, None if kd_ks is not None else gb_kd,
+                                       None if kd_ks is not None else gb_ks, light, pdf, rows, cols, iBSDF,
+                                       n_samples_x, rnd_seed, shadow_scale, (int(view_offset), int(view_stride)), kd_ks)
 
 
 def optix_env_shade_samples(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, BSDF='pbr', n_samples_x=8,
@@ -196,6 +216,7 @@ def optix_env_shade_samples(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos,
         return t.detach().expand(full).contiguous().float()
     pix = torch.nonzero(mask.detach().expand(B, H, W).reshape(-1) > 0).reshape(-1).int()
     t = dict(ro=c3(ro), pos=c3(gb_pos), nrm=c3(gb_normal), kd=c3(gb_kd), ks=c3(gb_ks))
+    t["kd_ptr"], t["ks_ptr"] = ptr(t["kd"]), ptr(t["ks"])
     view = gb_view_pos.detach().expand(B, 1, 1, 3).reshape(B, 3).contiguous().float()
     lgt, t_pdf, t_rows, t_cols = (x.detach().contiguous().float() for x in (light, pdf, rows, cols))
     perms = random_perm(n_samples_x, dev)

@@ -15,7 +15,7 @@ There is no CPU / eager fallback: tensors must live in HBM and the HIP library m
 import torch
 
 from .. import _lib
-from .._lib import c_int64, c_void_p, check, ptr, stream
+from .._lib import c_int, c_int64, c_void_p, check, ptr, stream
 
 
 def _scratch(nbytes, device):
@@ -161,6 +161,64 @@ def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
         out, out_da = _InterpolateFn.apply(attr, rast, tri, rast_db)
         return out, out_da
     return _InterpolateFn.apply(attr, rast, tri, None), None
+
+
+class _InterpolateGroupsFn(torch.autograd.Function):
+    """interpolate() of several per-vertex attribute tensors in one launch, one contiguous output each (gs_interpolate_groups_*)."""
+
+    @staticmethod
+    def forward(ctx, rast, tri, *attrs):
+        import ctypes
+        L = _lib.lib()
+        rast_c = rast.detach().contiguous().float()
+        tri_c = tri.detach().contiguous()
+        if tri_c.dtype != torch.int32:
+            tri_c = tri_c.int()
+        a_c = [a.detach().contiguous().float() for a in attrs]
+        V = a_c[0].shape[0]
+        for a in a_c:
+            if a.dim() != 2 or a.shape[0] != V:
+                raise _lib.GShellHipError("interpolate_groups: attributes must be [V, C] over the same vertices")
+        B, H, W, _ = rast_c.shape
+        n = len(a_c)
+        outs = [torch.empty((B, H, W, a.shape[1]), dtype=torch.float32, device=rast_c.device) for a in a_c]
+        ch = (ctypes.c_int32 * n)(*[int(a.shape[1]) for a in a_c])
+        ap = (ctypes.c_void_p * n)(*[ptr(a, torch.float32, "attr").value for a in a_c])
+        op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+        ctx.set_materialize_grads(False)          # an output nobody differentiates arrives as None in backward, not as a zero tensor
+        with torch.cuda.device(rast_c.device):
+            check(L.gs_interpolate_groups_fwd(c_int(n), ch, ap, ptr(rast_c), ptr(tri_c, torch.int32, "tri"), c_int64(tri_c.shape[0]), c_int64(B), c_int64(H),
+                                              c_int64(W), op, stream()), "gs_interpolate_groups_fwd")
+        ctx.save_for_backward(rast_c, tri_c, *a_c)
+        ctx.shapes = [a.shape for a in attrs]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g_outs):
+        import ctypes
+        rast_c, tri_c, *a_c = ctx.saved_tensors
+        B, H, W, _ = rast_c.shape
+        n = len(a_c)
+        need_rast = ctx.needs_input_grad[0]
+        g_c = [None if g is None else g.contiguous().float() for g in g_outs]
+        g_attr = [torch.zeros_like(a) if (ctx.needs_input_grad[2 + k] and g_c[k] is not None) else None for k, a in enumerate(a_c)]
+        g_rast = torch.empty_like(rast_c) if need_rast else None
+        ch = (ctypes.c_int32 * n)(*[int(a.shape[1]) for a in a_c])
+        ap = (ctypes.c_void_p * n)(*[a.data_ptr() for a in a_c])
+        gp = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in g_c])
+        gap = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in g_attr])
+        with torch.cuda.device(rast_c.device):
+            check(_lib.lib().gs_interpolate_groups_bwd(c_int(n), ch, ap, ptr(rast_c), ptr(tri_c), c_int64(tri_c.shape[0]), c_int64(B), c_int64(H), c_int64(W),
+                                                       gp, gap, ptr(g_rast), stream()), "gs_interpolate_groups_bwd")
+        return (g_rast, None) + tuple(None if g is None else g.reshape(s) for g, s in zip(g_attr, ctx.shapes))
+
+
+def interpolate_groups(attrs, rast, tri):
+    """[interpolate(a[None], rast, tri)[0] for a in attrs] in ONE launch each way: attrs = per-vertex tensors [V, C_k] over the same
+    vertices -> list of [B,H,W,C_k].  Values and gradients are bit-identical to interpolating torch.cat(attrs, -1) and slicing."""
+    if not all(a.is_cuda for a in attrs):
+        raise _lib.GShellHipError("interpolate_groups: attributes must live in HBM; the HIP path has no CPU fallback")
+    return list(_InterpolateGroupsFn.apply(rast, tri, *attrs))
 
 
 class _FaceNormalFn(torch.autograd.Function):

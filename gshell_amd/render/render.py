@@ -198,7 +198,7 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
         raise NotImplementedError("only the combined 'kd_ks' material of the G-Shell scripts is supported (uv-textured materials need "
                                   "mip-mapped texture sampling, which the G-Shell path never enters)")
 
-    alpha = kd[..., 3:4] if kd.shape[-1] == 4 else torch.ones_like(kd[..., 0:1])
+    alpha = kd[..., 3:4] if kd.shape[-1] == 4 else None       # None: all ones, materialised only where the unfused tail needs it
     kd = kd[..., 0:3]
 
     # ---- normal regulariser + shading normal ---------------------------------------------------------
@@ -220,12 +220,16 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
     if bsdf in ('pbr', 'diffuse', 'white'):
         kd = torch.ones_like(kd) if bsdf == 'white' else kd
         assert isinstance(lgt, light.EnvironmentLight) and optix_ctx is not None
-        ro = gb_pos + gb_normal * 0.001
         global rnd_seed
-        diffuse_accum, specular_accum = ou.optix_env_shade(optix_ctx, rast[..., -1], ro, gb_pos, gb_normal, view_pos, kd, ks, lgt.base, lgt._pdf,
+        # reference (render.py:131-133): ro = gb_pos + gb_normal * 0.001, kd / ks as channel slices of the texture sample.  Here the
+        # kernel forms ro itself (ro=None) and, when kd / ks are the plain halves of the MLP texture's output, reads that tensor in
+        # place (kd_ks=...): no slice copies forward, ONE gradient tensor instead of two slice backward passes
+        packed = fused and bsdf == 'pbr'
+        extra = dict(kd_ks=all_tex) if packed else {}
+        diffuse_accum, specular_accum = ou.optix_env_shade(optix_ctx, rast[..., -1], None, gb_pos, gb_normal, view_pos, kd, ks, lgt.base, lgt._pdf,
                                                            lgt.rows[:, 0], lgt.cols, BSDF=bsdf, n_samples_x=FLAGS.n_samples,
                                                            rnd_seed=None if FLAGS.decorrelated else rnd_seed, shadow_scale=shadow_scale,
-                                                           **_view_map(FLAGS))
+                                                           **extra, **_view_map(FLAGS))
         rnd_seed += 1
         if fused:
             # everything below (demodulated filtering weights, kd * (1 - metalness), the buffer dictionary with its alpha
@@ -262,6 +266,8 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
     else:
         assert False, "Invalid BSDF '%s'" % bsdf
 
+    if alpha is None:
+        alpha = torch.ones_like(kd[..., 0:1])
     if kd_grad is None:          # the fused path was requested but this configuration is not covered by the kernel
         kd_grad = torch.abs(all_tex_jitter[..., 0:3] - all_tex[..., 0:3])
         ks_grad = torch.abs(all_tex_jitter[..., 3:6] - ks) * _const_011(dev)
@@ -301,14 +307,14 @@ def render_layer(FLAGS, v_pos_clip, rast, rast_deriv, mesh, view_pos, lgt, resol
     tri = mesh.faces_i32()
     assert mesh.v_nrm is not None
 
-    # position + smooth normal (+ mSDF) in one stacked interpolation
+    # position + smooth normal (+ mSDF) in one interpolation pass (reference render.py:240, :263, :306: one call each)
     msdf = None
     if extra_dict is not None and extra_dict.get('msdf', None) is not None:
         msdf = extra_dict['msdf']
         assert msdf.dim() == 1 or (msdf.dim() == 2 and msdf.size(1) == 1)
     stack = [mesh.v_pos, mesh.v_nrm] + ([msdf.reshape(-1, 1)] if msdf is not None else [])
-    gb, _ = interpolate(torch.cat(stack, dim=-1)[None, ...], rast_out_s, tri)
-    gb_pos, gb_normal = gb[..., 0:3], gb[..., 3:6]
+    gb = dr.interpolate_groups(stack, rast_out_s, tri)          # one launch, one contiguous tensor per attribute
+    gb_pos, gb_normal = gb[0], gb[1]
 
     # geometric (face) normal of the covering triangle (fused gather + normalise; a torch gather here would
     # back-propagate through index_put with ~1e6 duplicate indices: 260 ms at 4 x 512^2)
@@ -334,10 +340,10 @@ def render_layer(FLAGS, v_pos_clip, rast, rast_deriv, mesh, view_pos, lgt, resol
                     mesh.material, optix_ctx, mesh, bsdf, denoiser, shadow_scale, use_uv=use_uv, finetune_normal=finetune_normal, xfm_lgt=xfm_lgt,
                     shade_data=shade_data, _defer=_defer and spp == 1)
     if isinstance(buffers, PendingFrame):
-        buffers.msdf_image = gb[..., 6:7] if msdf is not None else None
+        buffers.msdf_image = gb[2] if msdf is not None else None
         return buffers
     if msdf is not None:
-        buffers['msdf_image'] = gb[..., 6:7]
+        buffers['msdf_image'] = gb[2]
     if spp > 1 and msaa:
         for key in buffers.keys():
             buffers[key] = util.scale_img_nhwc(buffers[key], full_res, mag='nearest', min='nearest')

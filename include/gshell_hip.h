@@ -177,6 +177,18 @@ int gs_interpolate_fwd(const float* attr, int64_t Ba, int64_t V, int64_t A, cons
 int gs_interpolate_bwd(const float* attr, int64_t Ba, int64_t V, int64_t A, const float* rast,
                        const int32_t* tri, int64_t T, int64_t B, int64_t H, int64_t W,
                        const float* g_out, float* g_attr, float* g_rast, gs_stream_t stream);
+/* Several per-vertex attribute tensors [V, channels[k]] (k < n_groups <= 4, batch 1) interpolated in ONE pass into one contiguous
+ * output each (the g-buffer of a frame: position, smooth normal, mSDF; reference render/render.py:240, :263, :306).  `attrs`, `outs`,
+ * `g_outs`, `g_attrs` are HOST arrays of device pointers.  Per channel the same arithmetic as gs_interpolate_*, g_rast accumulated
+ * in the channel order of the concatenated tensor: bit-identical to interpolating torch.cat(attrs, -1).
+ * bwd: g_outs[k] NULL = no gradient into that output; g_attrs[k] ACCUMULATED (zero it first), NULL = not needed; g_rast WRITTEN or NULL. */
+int gs_interpolate_groups_fwd(int n_groups, const int32_t* channels, const float* const* attrs,
+                              const float* rast, const int32_t* tri, int64_t T, int64_t B, int64_t H,
+                              int64_t W, float* const* outs, gs_stream_t stream);
+int gs_interpolate_groups_bwd(int n_groups, const int32_t* channels, const float* const* attrs,
+                              const float* rast, const int32_t* tri, int64_t T, int64_t B, int64_t H,
+                              int64_t W, const float* const* g_outs, float* const* g_attrs,
+                              float* g_rast, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Antialias   (replaces dr.antialias, render/render.py:352-359 composite_buffer; the
@@ -292,7 +304,10 @@ int gs_bvh_any_hit_stats(const gs_bvh* bvh, const float* origins, const float* d
  *        diff, spec [B,H,W,3] WRITTEN (both NULL = trace only, used when the backward pass wants fresh samples).
  *   bwd: identical sampling with the cached visibility (no rays are traced):
  *        g_pos, g_normal, g_kd, g_ks [B,H,W,3] WRITTEN; g_light [Hl,Wl,3] ACCUMULATED (atomics).
- *   ro and view_pos receive no gradient, as in the reference (ops.py:108).
+ *   ro and view_pos receive no gradient, as in the reference (ops.py:108).  ro NULL: gb_pos + gb_normal * 0.001f, what the reference's caller passes.
+ *   gb_kd / gb_ks (and likewise g_kd / g_ks) may be the two channel halves of ONE [B,H,W,6] tensor -- the layout MLPTexture3D
+ *        produces -- instead of two [B,H,W,3] tensors: pass gb_ks = gb_kd + 3 (g_ks = g_kd + 3); the pixel stride is then 6 floats
+ *        and the gradient tensor is written (and zeroed) as one.  Saves the channel-split copies and the slice backward.
  *   view_offset / view_stride: local view b is view  b*view_stride + view_offset  of the GLOBAL batch; the per-pixel
  *        RNG stream hashes that global pixel index (kernel.cu:504), so a view-sharded N-GPU step draws exactly the
  *        samples of the single-GPU step.  Single GPU: (0, 1).

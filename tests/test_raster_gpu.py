@@ -227,3 +227,38 @@ def test_antialias_cache_is_keyed_on_tensor_identity():
         outs.append((a, ptrs))
         del rast, pos_d, col          # free the blocks so that the second pass may receive the same addresses
     assert not torch.equal(outs[0][0], outs[1][0])
+
+
+@pytest.mark.parametrize("channels,skip", [((3, 3, 1), None), ((3, 3), None), ((3, 3, 1), 1), ((2,), None), ((1, 4, 3, 2), 2)])
+def test_interpolate_groups_equals_the_stacked_interpolation(channels, skip):
+    """dr.interpolate_groups (one launch, one contiguous output per attribute tensor: the g-buffer of render_layer) against
+    dr.interpolate of torch.cat(attrs, -1) + channel slices: values and the barycentric gradient bit-identical, attribute gradients
+    up to the float atomics' order; `skip`: an output nobody differentiates (NULL g_out, no gradient tensor for that attribute)."""
+    from gshell_amd.render import rast as dr
+    verts, tri = _scene("sheet", 3)
+    pos, _, _ = _clip(verts, 2)
+    H, W = 64, 64
+    tri_l = torch.tensor(tri).long()
+    ids = torch.tensor(ro.rasterize_ids(pos.numpy(), tri, H, W))
+    rast_ref, _ = ro.rast_from_ids(pos, tri_l, ids)
+    g = torch.Generator().manual_seed(15)
+    attrs = [torch.rand(verts.shape[0], c, generator=g) for c in channels]
+    wgts = [torch.rand(2, H, W, c, generator=g).to(DEV) for c in channels]
+    tri_d = torch.tensor(tri, device=DEV)
+    a1 = [a.to(DEV).requires_grad_(True) for a in attrs]
+    r1 = rast_ref.to(DEV).requires_grad_(True)
+    stacked, _ = dr.interpolate(torch.cat(a1, -1)[None], r1, tri_d)
+    parts = torch.split(stacked, list(channels), dim=-1)
+    sum((p * w).sum() for k, (p, w) in enumerate(zip(parts, wgts)) if k != skip).backward()
+    a2 = [a.to(DEV).requires_grad_(True) for a in attrs]
+    r2 = rast_ref.to(DEV).requires_grad_(True)
+    outs = dr.interpolate_groups(a2, r2, tri_d)
+    sum((o * w).sum() for k, (o, w) in enumerate(zip(outs, wgts)) if k != skip).backward()
+    for o, p in zip(outs, parts):
+        assert o.is_contiguous() and torch.equal(o, p)
+    assert torch.equal(r1.grad, r2.grad)
+    for k, (x, y) in enumerate(zip(a1, a2)):
+        if k == skip:
+            assert y.grad is None and float(x.grad.abs().max()) == 0
+        else:
+            assert float((x.grad - y.grad).abs().max()) <= 1e-5 * float(x.grad.abs().max())

@@ -194,3 +194,33 @@ def test_bilateral_pair_equals_two_single_passes(sigma, masked):
     ((ra * wa).sum() + (rb * wb).sum()).backward()
     assert torch.equal(oa, ra) and torch.equal(ob, rb)
     assert torch.equal(a1.grad, a2.grad) and torch.equal(b1.grad, b2.grad)
+
+
+@pytest.mark.parametrize("bsdf", ["pbr", "diffuse"])
+def test_env_shade_reads_an_interleaved_kd_ks_tensor_in_place_and_forms_the_ray_origin_itself(bsdf):
+    """optix_env_shade(kd_ks=[B,H,W,6], ro=None) -- the kernels read kd | ks at a pixel stride of 6 floats (gs_env_shade_*: ks = kd + 3)
+    and compute ro = gb_pos + gb_normal * 0.001 -- against the reference's call shape (separate kd, ks, explicit ro): every output and
+    gradient bit-identical (the light gradient up to its atomics' order), and the texture gradient is the concatenation of g_kd, g_ks."""
+    from gshell_amd.render import optixutils as ou
+    B, H, W, n = 2, 40, 48, 4
+    verts, tri, mask, gb_pos, gb_nrm, view, kd, ks = scenes.sheet_gbuffer(B, H, W, 7)
+    gen = torch.Generator().manual_seed(14)
+    light = torch.rand(16, 32, 3, generator=gen) * 2 + 0.05
+    pdf, rows, cols = po.update_pdf(light)
+    wd, ws = torch.rand(B, H, W, 3, generator=gen).to(DEV), torch.rand(B, H, W, 3, generator=gen).to(DEV)
+    ctx = ou.OptiXContext()
+    ou.optix_build_bvh(ctx, torch.tensor(verts, device=DEV), torch.tensor(tri, device=DEV), rebuild=1)
+    tail = (pdf.to(DEV), rows[:, 0].to(DEV), cols.to(DEV))
+    a = [t.to(DEV).requires_grad_(True) for t in (gb_pos, gb_nrm, kd, ks, light)]
+    d1, s1 = ou.optix_env_shade(ctx, mask.to(DEV), (gb_pos.to(DEV) + gb_nrm.to(DEV) * 0.001), a[0], a[1], view.to(DEV), a[2], a[3], a[4], *tail,
+                                BSDF=bsdf, n_samples_x=n, rnd_seed=5, shadow_scale=1.0)
+    ((d1 * wd).sum() + (s1 * ws).sum()).backward()
+    b = [t.to(DEV).requires_grad_(True) for t in (gb_pos, gb_nrm, torch.cat((kd, ks), -1), light)]
+    d2, s2 = ou.optix_env_shade(ctx, mask.to(DEV), None, b[0], b[1], view.to(DEV), None, None, b[3], *tail, BSDF=bsdf, n_samples_x=n, rnd_seed=5,
+                                shadow_scale=1.0, kd_ks=b[2])
+    ((d2 * wd).sum() + (s2 * ws).sum()).backward()
+    assert torch.equal(d1, d2) and torch.equal(s1, s2)
+    assert torch.equal(a[0].grad, b[0].grad) and torch.equal(a[1].grad, b[1].grad)
+    assert torch.equal(torch.cat((a[2].grad, a[3].grad), -1), b[2].grad)
+    assert bsdf != "pbr" or float(b[2].grad.abs().max()) > 0        # (the demodulated diffuse term does not depend on kd / ks)
+    assert float((a[4].grad - b[3].grad).abs().max()) <= 1e-5 * float(a[4].grad.abs().max())
