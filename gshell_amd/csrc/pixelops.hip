@@ -490,6 +490,22 @@ __global__ void __launch_bounds__(256) k_face_normals_bwd(const float* __restric
     atomicAdd(&g_v[3 * i2 + 2], db.z);
 }
 
+// ---- depth + depth-slope guide of the denoiser (reference render/render.py:273-279, ~14 ATen launches on one-channel images) ---------
+// out[p] = (z0, |z1 - z0|),  z0 = max(c.z, eps) / max(c.w, eps),  z1 = max(c.z + |dd[2]|, eps) / max(c.w + |dd[3]|, eps),  with c the
+// interpolated clip position [n,4] and dd its screen-space derivative image [n,8] (the reference reads channels 2 and 3 of it as is).
+// torch.clamp(min) propagates NaN: so does the explicit form below.  Same operations in the same order: bit-identical.
+__device__ __forceinline__ float clamp_min_nan(float x, float lo) { return x != x ? x : fmaxf(x, lo); }
+__global__ void __launch_bounds__(256) k_depth_zgrad(const float4* __restrict__ clip, const float4* __restrict__ dd, int64_t n, float eps,
+                                                     float2* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = clip[i];
+    const float4 d = dd[2 * i];                      // channels 0..3 of the 8
+    const float z0 = clamp_min_nan(c.z, eps) / clamp_min_nan(c.w, eps);
+    const float z1 = clamp_min_nan(c.z + fabsf(d.z), eps) / clamp_min_nan(c.w + fabsf(d.w), eps);
+    out[i] = make_float2(z0, fabsf(z1 - z0));
+}
+
 // ---- bilinear texture tap, clamp addressing ----------------------------------------------------------
 // texel centres at (i + .5) / W ;  tex [B,H,W,C], uv [B,h,w,2] -> out [B,h,w,C]
 template <bool BWD>
@@ -1175,6 +1191,15 @@ extern "C" int gs_msdf_reg_bwd(const float* msdf, int64_t N, const float* msdf_b
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_msdf_reg_bwd, dim3((unsigned)std::min<int64_t>(gs::cdiv(n, 256), 2048)), dim3(256), 0, (hipStream_t)stream, msdf, N, msdf_boundary,
                        weight, n_boundary, eps, open_w, close_w, g_out2_dev, g_msdf, g_boundary);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_depth_zgrad(const float* clip_pos, const float* clip_pos_deriv, int64_t n, float eps, float* out, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_REQUIRE(clip_pos && clip_pos_deriv && out, "gs_depth_zgrad: null pointer");
+    hipLaunchKernelGGL(k_depth_zgrad, dim3((unsigned)gs::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)clip_pos, (const float4*)clip_pos_deriv,
+                       n, eps, (float2*)out);
     GS_LAUNCH_CHECK();
     return 0;
 }

@@ -349,6 +349,8 @@ def antialias_stacked(colors, rast, pos, tri, topo=None):
         return list(colors)
     if topo is None:
         topo = AATopology(tri, pos.shape[1])
+    if len(colors) == 1:          # (torch.cat / torch.split of ONE tensor still copy it, forward and backward: 2 x 190 MB at 4 x 512^2 x 45)
+        return [_AntialiasFn.apply(colors[0], pos, rast, tri, topo, None)]
     sizes = [c.shape[-1] for c in colors]
     out = _AntialiasFn.apply(torch.cat(colors, dim=-1), pos, rast, tri, topo, None)
     return list(torch.split(out, sizes, dim=-1))

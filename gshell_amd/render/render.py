@@ -323,18 +323,16 @@ def render_layer(FLAGS, v_pos_clip, rast, rast_deriv, mesh, view_pos, lgt, resol
     with torch.no_grad():
         noise = _noise('tangent', lambda: torch.randn_like(gb_normal), FLAGS, 1.0, tuple(gb_normal.shape), gb_normal.device)
         noise = noise / noise.norm(dim=-1, keepdim=True)
-    gb_tangent = torch.cross(noise, gb_normal, dim=-1)       # only used to add isotropic noise (no uv maps)
+    # only used to add isotropic noise (no uv maps).  With perturbed_nrm = None the shading normal is tng * 0 + btng * 0 + nrm * 1: the
+    # tangent's gradient is exactly zero, so the cross product is taken of the detached normal (saves its backward and an add of zeros)
+    gb_tangent = torch.cross(noise, gb_normal.detach(), dim=-1)
     gb_texc, gb_texc_deriv = None, None
 
     with torch.no_grad():
         eps = 0.00001
         clip_pos, clip_pos_deriv = interpolate(v_pos_clip, rast_out_s, tri, rast_db=rast_out_deriv_s)
-        z0 = torch.clamp(clip_pos[..., 2:3], min=eps) / torch.clamp(clip_pos[..., 3:4], min=eps)
         # clip_pos_deriv layout: (d/dX, d/dY) interleaved per attribute -> the reference reads [2:3], [3:4]
-        z1 = torch.clamp(clip_pos[..., 2:3] + torch.abs(clip_pos_deriv[..., 2:3]), min=eps) / \
-            torch.clamp(clip_pos[..., 3:4] + torch.abs(clip_pos_deriv[..., 3:4]), min=eps)
-        z_grad = torch.abs(z1 - z0)
-        gb_depth = torch.cat((z0, z_grad), dim=-1)
+        gb_depth = ru.depth_zgrad(clip_pos, clip_pos_deriv, eps)          # (z0, |z1 - z0|), reference :276-279 in one launch
 
     buffers = shade(FLAGS, rast_out_s, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_texc, gb_texc_deriv, view_pos, lgt,
                     mesh.material, optix_ctx, mesh, bsdf, denoiser, shadow_scale, use_uv=use_uv, finetune_normal=finetune_normal, xfm_lgt=xfm_lgt,
@@ -435,7 +433,6 @@ def render_mesh(FLAGS, ctx, mesh, mtx_in, view_pos, lgt, resolution, spp=1, num_
     # composite every buffer over its background, then antialias all of them in one stacked launch.  The reference loops
     # over the ~12 buffers (render.py:417-433: alpha, cat, lerp, antialias each); here the buffers are stacked once along
     # the channel axis and composited with a handful of whole-stack ops: out = lerp(bg, [rgb.., 1], cover * alpha_of_group).
-    cover = (rast[..., -1:] > 0).float()
     if isinstance(buffers, PendingFrame):
         pf = buffers
         keys = list(PendingFrame.KEYS) + (['msdf_image'] if pf.msdf_image is not None else [])
@@ -451,6 +448,7 @@ def render_mesh(FLAGS, ctx, mesh, mtx_in, view_pos, lgt, resolution, spp=1, num_
         pass
     elif keys:
         sizes = [buffers[k].shape[-1] for k in keys]
+        cover = (rast[..., -1:] > 0).float()
         layout = _composite_layout(tuple(sizes), dev)
         stacked = torch.cat([buffers[k] for k in keys], dim=-1)                       # [B,H,W,sum C]
         a = cover * torch.matmul(stacked, layout['pick_alpha'])                        # alpha of each channel's own buffer (0/1 matrix: exact,

@@ -113,6 +113,20 @@ _LOSS = {'l1': 0, 'mse': 1, 'relmse': 2, 'smape': 3}
 _TONEMAP = {'none': 0, 'log_srgb': 1}
 
 
+@torch.no_grad()
+def depth_zgrad(clip_pos, clip_pos_deriv, eps=0.00001):
+    """Depth + depth-slope guide of the denoiser, [...,2] = (z0, |z1 - z0|) from the interpolated clip position [...,4] and its
+    screen-space derivatives [...,8] (reference render/render.py:276-279, there ~14 ATen launches; no gradient, as there)."""
+    c = clip_pos.detach().contiguous().float()
+    d = clip_pos_deriv.detach().contiguous().float()
+    if c.shape[-1] != 4 or d.shape[-1] != 8 or c.shape[:-1] != d.shape[:-1]:
+        raise _lib.GShellHipError(f"depth_zgrad: clip_pos {tuple(c.shape)} / clip_pos_deriv {tuple(d.shape)} must be [...,4] / [...,8]")
+    out = torch.empty(tuple(c.shape[:-1]) + (2,), dtype=torch.float32, device=c.device)
+    with torch.cuda.device(c.device):
+        check(_lib.lib().gs_depth_zgrad(ptr(c, torch.float32, "clip_pos"), ptr(d), c_int64(c.numel() // 4), c_float(eps), ptr(out), stream()), "gs_depth_zgrad")
+    return out
+
+
 class _ImageLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, target, loss, tonemapper):

@@ -501,6 +501,15 @@ int gs_texmlp_bwd_rows(const float* x_level_major, const int32_t* rows, const in
                        float* g_w1, float* g_w2, float* g_w3, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Depth + depth-slope guide image of the denoiser   (render/render.py:273-279: clamp / add / abs / div on one-channel images)
+ *   clip_pos [n,4] interpolated clip-space position, clip_pos_deriv [n,8] its screen-space derivatives (gs_interpolate_fwd's out_da);
+ *   out [n,2] WRITTEN = (z0, |z1 - z0|), z0 = max(z, eps) / max(w, eps), z1 = max(z + |dd[2]|, eps) / max(w + |dd[3]|, eps).  No gradient
+ *   (the reference computes it under no_grad).
+ * ---------------------------------------------------------------------------------- */
+int gs_depth_zgrad(const float* clip_pos, const float* clip_pos_deriv, int64_t n, float eps, float* out,
+                   gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Surface samples for the eikonal term   (stands in for kaolin.ops.mesh.sample_points, third party, called at
  *   geometry/gshell_tets_geometry.py:236; the samples are detached at :303, so no gradient is needed)
  *   gs_tri_area: area [T] WRITTEN = |(v1 - v0) x (v2 - v0)| (non-finite -> 0) + 1e-20 = the weights of the face draw;

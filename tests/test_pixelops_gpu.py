@@ -368,3 +368,30 @@ def test_surface_sampling_kernels_match_the_torch_formulation():
     pts_c, fid_c = sample_points(vf, tri_ok.long(), n, generator=gen_b)
     freq_c = torch.zeros(16, device="cuda").index_add_(0, grp[fid_c], torch.ones(n, device="cuda")) / n
     assert float(((freq_c - share).abs() / (share * (1 - share) / n).sqrt()).max()) < 5.0
+
+
+def test_depth_zgrad_equals_the_reference_expression_bit_for_bit():
+    """ru.depth_zgrad (one launch) against the reference's operator chain (render/render.py:276-279) on random values, values at and
+    below eps, negative w, infinities and NaN: bit-identical."""
+    from gshell_amd.render import renderutils as ru
+    g = torch.Generator().manual_seed(21)
+    n = 5000
+    c = torch.randn(2, 50, 50, 4, generator=g)
+    d = torch.randn(2, 50, 50, 8, generator=g) * 0.01
+    flat_c, flat_d = c.view(-1, 4), d.view(-1, 8)
+    flat_c[0] = torch.tensor([0.0, 0.0, 1e-6, 1e-6])
+    flat_c[1] = torch.tensor([0.0, 0.0, 0.0, 0.0])
+    flat_c[2] = torch.tensor([0.0, 0.0, float("nan"), 1.0])
+    flat_c[3] = torch.tensor([0.0, 0.0, 1.0, float("nan")])
+    flat_c[4] = torch.tensor([0.0, 0.0, float("inf"), 2.0])
+    flat_c[5] = torch.tensor([0.0, 0.0, 0.5, -3.0])
+    flat_d[6, 2:4] = torch.tensor([float("inf"), float("nan")])
+    c, d = c.to(DEV), d.to(DEV)
+    eps = 0.00001
+    z0 = torch.clamp(c[..., 2:3], min=eps) / torch.clamp(c[..., 3:4], min=eps)
+    z1 = torch.clamp(c[..., 2:3] + torch.abs(d[..., 2:3]), min=eps) / torch.clamp(c[..., 3:4] + torch.abs(d[..., 3:4]), min=eps)
+    ref = torch.cat((z0, torch.abs(z1 - z0)), dim=-1)
+    out = ru.depth_zgrad(c, d, eps)
+    assert out.shape == ref.shape
+    same = (out.view(torch.int32) == ref.view(torch.int32)) | (torch.isnan(out) & torch.isnan(ref))
+    assert bool(same.all()), int((~same).sum())
