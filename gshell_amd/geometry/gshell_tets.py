@@ -121,6 +121,7 @@ class _MarchingTetsFn(torch.autograd.Function):
         ctx.dims = (topo.N, V, M1, M2)
         ctx.in_shapes = (pos.shape, sdf.shape, msdf.shape)
         ctx.mark_non_differentiable(faces_wt, faces_aug, faces_i32, v_tng_aug, tet_id)
+        ctx.set_materialize_grads(False)      # outputs nobody differentiates (verts_wt in training) arrive as None, not as zero tensors
         return verts_aug, msdf_aug, verts_wt, faces_aug, faces_wt, faces_i32, v_tng_aug, tet_id
 
     @staticmethod
@@ -128,10 +129,9 @@ class _MarchingTetsFn(torch.autograd.Function):
         pos, sdf, msdf, verts_wt, msdf_aug, vert_ab, used_wt, poly, cut_code = ctx.saved_tensors
         N, V, M1, M2 = ctx.dims
         dev = pos.device
-        g_pos = torch.zeros((N, 3), dtype=torch.float32, device=dev)
-        g_sdf = torch.zeros((N,), dtype=torch.float32, device=dev)
-        g_msdf = torch.zeros((N,), dtype=torch.float32, device=dev)
-        if V > 0:
+        flat = torch.zeros((5 * N,), dtype=torch.float32, device=dev)          # one fill, three views
+        g_pos, g_sdf, g_msdf = flat[:3 * N].view(N, 3), flat[3 * N:4 * N], flat[4 * N:]
+        if V > 0 and not (g_verts_aug is None and g_msdf_aug is None and g_verts_wt is None):
             def prep(g):
                 return None if g is None else g.contiguous().float()
             ga, gm, gw = prep(g_verts_aug), prep(g_msdf_aug), prep(g_verts_wt)
