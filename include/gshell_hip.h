@@ -501,6 +501,20 @@ int gs_texmlp_bwd_rows(const float* x_level_major, const int32_t* rows, const in
                        float* g_w1, float* g_w2, float* g_w3, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Adam step over a list of fp32 parameter tensors in one launch   (the reference steps three torch.optim.Adam optimisers,
+ *   train_gshelltet_deepfashion.py:372-383, :446-452; amsgrad off, weight_decay 0, maximize off)
+ *   params / grads / exp_avg / exp_avg_sq / step_tensors: HOST arrays [n_tensors] of device pointers, numel / lr host arrays;
+ *   params, exp_avg, exp_avg_sq UPDATED in place; step_tensors[k] (device float32, may be NULL) WRITTEN = step_value (the state
+ *   layout of torch's fused optimiser, so state_dicts are interchangeable); step_value = this step's number, from 1.
+ *   Arithmetic: at::native's fused Adam (double scalars, fp32 operands, ATen/native/cuda/fused_adam_utils.cuh:61-76); `contract`
+ *   0 / 1 / 2 = how the two moment updates round (csrc/adam.hip): ATen is built with -ffp-contract=fast.
+ * ---------------------------------------------------------------------------------- */
+int gs_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                 float* const* exp_avg_sq, float* const* step_tensors, const int64_t* numel,
+                 const double* lr, double beta1, double beta2, double eps, double step_value,
+                 int contract, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Depth + depth-slope guide image of the denoiser   (render/render.py:273-279: clamp / add / abs / div on one-channel images)
  *   clip_pos [n,4] interpolated clip-space position, clip_pos_deriv [n,8] its screen-space derivatives (gs_interpolate_fwd's out_da);
  *   out [n,2] WRITTEN = (z0, |z1 - z0|), z0 = max(z, eps) / max(w, eps), z1 = max(z + |dd[2]|, eps) / max(w + |dd[3]|, eps).  No gradient
