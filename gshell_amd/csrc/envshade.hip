@@ -528,8 +528,8 @@ __global__ void __launch_bounds__(256, BWD ? 1 : GS_SAMPLES_WAVES) k_shade_sampl
             // k >= 0: its sign bit tells the trace kernel that the ray is dead (contribution exactly zero) without the 24-byte record
             const bool live = (od.x != 0.f) | (od.y != 0.f) | (od.z != 0.f) | (os.x != 0.f) | (os.y != 0.f) | (os.z != 0.f);
             A.ray_dk[r] = make_float4(dir.x, dir.y, dir.z, live ? kk : -kk);
-            float* rc = A.ray_contrib + 6 * r;
-            rc[0] = od.x; rc[1] = od.y; rc[2] = od.z; rc[3] = os.x; rc[4] = os.y; rc[5] = os.z;
+            float2* rc = reinterpret_cast<float2*>(A.ray_contrib + 6 * r);          // 24-byte records, 8-byte aligned
+            rc[0] = make_float2(od.x, od.y); rc[1] = make_float2(od.z, os.x); rc[2] = make_float2(os.y, os.z);
         }
         // BSDF sample
         int pb = perm_b[i];
@@ -543,8 +543,8 @@ __global__ void __launch_bounds__(256, BWD ? 1 : GS_SAMPLES_WAVES) k_shade_sampl
             // k >= 0: its sign bit tells the trace kernel that the ray is dead (contribution exactly zero) without the 24-byte record
             const bool live = (od.x != 0.f) | (od.y != 0.f) | (od.z != 0.f) | (os.x != 0.f) | (os.y != 0.f) | (os.z != 0.f);
             A.ray_dk[r] = make_float4(dir.x, dir.y, dir.z, live ? kk : -kk);
-            float* rc = A.ray_contrib + 6 * r;
-            rc[0] = od.x; rc[1] = od.y; rc[2] = od.z; rc[3] = os.x; rc[4] = os.y; rc[5] = os.z;
+            float2* rc = reinterpret_cast<float2*>(A.ray_contrib + 6 * r);          // 24-byte records, 8-byte aligned
+            rc[0] = make_float2(od.x, od.y); rc[1] = make_float2(od.z, os.x); rc[2] = make_float2(os.y, os.z);
         }
     }
     if (BWD) {
@@ -701,16 +701,73 @@ __global__ void __launch_bounds__(256) k_light_scatter(const float4* __restrict_
 #endif
 constexpr int LG_SLICES = GS_LG_SLICES;
 constexpr int LG_NT = 1024;
+// Accumulation in 64-bit FIXED POINT: ds_add_f32 costs 3 - 4 cycles per lane and CU on gfx950, ds_add_u64 0.36 - 0.65 (tools/micro/
+// lds_atomic.hip), and the kernel is nothing but 3 adds per record.  The workgroup first takes max |v| over its records (they come from
+// L2), then adds round(v * 2^e) with e such that n records of that size cannot overflow 2^61: the sum is exact to 2^-37 of the largest
+// record -- closer to the true sum than any order of float adds, and independent of the order.  Records that are not finite (a diverged
+// run) take the float path, which propagates them as before.
+// `partial` != NULL: the slice's sums are STORED to partial[slice][texel][3] (zeros included) and k_light_sum adds the slices to g_light
+// in slice order: no float atomics on global memory either.
+__device__ __forceinline__ double fixed_scale(float vmax, uint32_t n) {
+    // 2^e with |v| 2^e < 2^(61 - ceil(log2 n)) for every |v| <= vmax
+    const int ev = (int)((__float_as_uint(vmax) >> 23) & 0xffu) - 126;          // vmax < 2^ev (denormals: ev = -126, still an upper bound)
+    const int en = 32 - __clz((int)max(n, 1u) - 1 > 0 ? (int)max(n, 1u) - 1 : 0);           // ceil(log2 n), 0 for n = 1
+    return ldexp(1.0, 61 - ev - en);
+}
+
 __global__ void __launch_bounds__(LG_NT) k_light_reduce(const float4* __restrict__ sorted, const uint32_t* __restrict__ base, int64_t n_texels,
-                                                      float* __restrict__ g_light) {
-    __shared__ float s_acc[LG_TEXELS * 3];
+                                                      float* __restrict__ g_light, float* __restrict__ partial) {
+    __shared__ long long s_fix[LG_TEXELS * 3];
+    __shared__ float s_max[LG_NT / 64];
+    float* const s_acc = reinterpret_cast<float*>(s_fix);          // the float path uses the first half of the same block
     const int b = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x;
     const uint32_t lo = base[b], hi = base[b + 1];
     const uint32_t n = hi - lo, per = (n + LG_SLICES - 1) / LG_SLICES;
     const uint32_t s0 = lo + min(n, slice * per), s1 = lo + min(n, (slice + 1) * per);
-    if (s0 >= s1) return;
-    for (int t = tid; t < LG_TEXELS * 3; t += LG_NT) s_acc[t] = 0.f;
+    float* out = partial ? partial + ((int64_t)slice * gridDim.x + b) * (LG_TEXELS * 3) : nullptr;
+    if (s0 >= s1) {
+        if (out)
+            for (int t = tid; t < LG_TEXELS * 3; t += LG_NT) out[t] = 0.f;
+        return;
+    }
+    // pass 1: the largest magnitude (NaN and inf surface as a non-finite maximum: fmaxf would drop a NaN, so they are tested for)
+    float vmax = 0.f;
+    bool finite = true;
+    for (uint32_t q = s0 + tid; q < s1; q += LG_NT) {
+        const float4 v = sorted[q];
+        const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fabsf(v.z));
+        finite = finite && (v.x - v.x == 0.f) && (v.y - v.y == 0.f) && (v.z - v.z == 0.f);
+        vmax = fmaxf(vmax, m);
+    }
+    if (!finite) vmax = __builtin_inff();
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
+    if ((tid & 63) == 0) s_max[tid >> 6] = vmax;
+    for (int t = tid; t < LG_TEXELS * 3; t += LG_NT) s_fix[t] = 0ll;
     __syncthreads();
+    vmax = 0.f;
+    for (int w = 0; w < LG_NT / 64; ++w) vmax = fmaxf(vmax, s_max[w]);
+    const bool fixed = vmax - vmax == 0.f;                       // workgroup-uniform
+    if (fixed) {
+        const double scale = fixed_scale(vmax, s1 - s0);
+        for (uint32_t q = s0 + tid; q < s1; q += LG_NT) {
+            const float4 v = sorted[q];
+            const uint32_t t = (__float_as_uint(v.w) - (uint32_t)b * LG_TEXELS) * 3;
+            unsigned long long* a = reinterpret_cast<unsigned long long*>(s_fix) + t;
+            if (v.x != 0.f) atomicAdd(a, (unsigned long long)__double2ll_rn((double)v.x * scale));
+            if (v.y != 0.f) atomicAdd(a + 1, (unsigned long long)__double2ll_rn((double)v.y * scale));
+            if (v.z != 0.f) atomicAdd(a + 2, (unsigned long long)__double2ll_rn((double)v.z * scale));
+        }
+        __syncthreads();
+        const double inv = 1.0 / scale;
+        const int64_t f0 = (int64_t)b * LG_TEXELS * 3, f1 = min(n_texels * 3, f0 + LG_TEXELS * 3);
+        for (int t = tid; t < LG_TEXELS * 3; t += LG_NT) {
+            const float v = (float)((double)s_fix[t] * inv);
+            if (out) out[t] = v;
+            else if (v != 0.f && f0 + t < f1) atomicAdd(&g_light[f0 + t], v);
+        }
+        return;
+    }
     for (uint32_t q = s0 + tid; q < s1; q += LG_NT) {
         const float4 v = sorted[q];
         const uint32_t t = (__float_as_uint(v.w) - (uint32_t)b * LG_TEXELS) * 3;
@@ -722,8 +779,19 @@ __global__ void __launch_bounds__(LG_NT) k_light_reduce(const float4* __restrict
     const int64_t f0 = (int64_t)b * LG_TEXELS * 3, f1 = min(n_texels * 3, f0 + LG_TEXELS * 3);
     for (int t = tid; t < LG_TEXELS * 3; t += LG_NT) {
         const float v = s_acc[t];
-        if (v != 0.f && f0 + t < f1) atomicAdd(&g_light[f0 + t], v);
+        if (out) out[t] = v;
+        else if (v != 0.f && f0 + t < f1) atomicAdd(&g_light[f0 + t], v);
     }
+}
+
+// g_light[f] += sum over the slices of partial[slice][f], slices added in order (deterministic given the partials)
+__global__ void __launch_bounds__(256) k_light_sum(const float* __restrict__ partial, int64_t n_padded, int64_t n_floats, float* __restrict__ g_light) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_floats) return;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LG_SLICES; ++k) s += partial[(int64_t)k * n_padded + f];
+    if (s != 0.f) g_light[f] += s;
 }
 
 // Pass 2 (fwd): shadow rays through the implicit 4-ary BVH of bvh.hpp.
@@ -1195,6 +1263,8 @@ static int env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, c
         const int64_t n_texels = Hl * Wl, nbins = gs::cdiv(n_texels, LG_TEXELS);
         const int64_t tail_bytes = n_rays * 8, need = (n_wg * nbins + 2 * nbins + 2) * 4;
         const bool binned = GS_LIGHT_BINNED && nbins <= 1024 && need <= tail_bytes && n_rays < (1ll << 32);
+        const int64_t need_aligned = (need + 15) / 16 * 16, partial_bytes = (int64_t)LG_SLICES * nbins * LG_TEXELS * 3 * 4;
+        const bool partials = binned && need_aligned + partial_bytes <= tail_bytes;
         if (binned) {
             A.rec = (float4*)(A.ray_dk + n_rays);
             A.hist = (uint32_t*)(A.rec + n_rays);
@@ -1208,7 +1278,11 @@ static int env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, c
             hipLaunchKernelGGL(k_light_scan, dim3((unsigned)nbins), dim3(256), 0, stream, A.hist, n_wg, (int)nbins, totals);
             hipLaunchKernelGGL(k_light_base, dim3(1), dim3(64), 0, stream, totals, (int)nbins, base);
             hipLaunchKernelGGL(k_light_scatter, dim3((unsigned)n_wg), dim3(256), 0, stream, A.rec, n_rays, rays_per_wg, A.hist, base, (int)nbins, A.ray_dk);
-            hipLaunchKernelGGL(k_light_reduce, dim3((unsigned)nbins, LG_SLICES), dim3(LG_NT), 0, stream, A.ray_dk, base, n_texels, A.g_light);
+            float* partial = partials ? (float*)((char*)A.hist + need_aligned) : nullptr;
+            hipLaunchKernelGGL(k_light_reduce, dim3((unsigned)nbins, LG_SLICES), dim3(LG_NT), 0, stream, A.ray_dk, base, n_texels, A.g_light, partial);
+            if (partial)
+                hipLaunchKernelGGL(k_light_sum, dim3((unsigned)gs::cdiv(n_texels * 3, 256)), dim3(256), 0, stream, partial, nbins * (int64_t)LG_TEXELS * 3,
+                                   n_texels * 3, A.g_light);
         }
     } else {
         hipLaunchKernelGGL(k_shade_samples<true>, dim3((unsigned)gs::cdiv(n_cov * A.G, 256)), dim3(256), 0, stream, A);

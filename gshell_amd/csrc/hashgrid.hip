@@ -545,26 +545,58 @@ __global__ void __launch_bounds__(256, GS_HG_WAVES) k_encode_bwd(GridMeta M, Enc
 
 // One workgroup per bin: sum the bin's records per entry in LDS, add to the table gradient (plain read-modify-write: the bin is this
 // workgroup's alone and every atomic of k_encode_bwd has landed), reset the bin's counter for the next call.
+// The sums are taken in 64-bit FIXED POINT: ds_add_f32 costs 3 - 4 cycles per lane and CU on gfx950, ds_add_u64 0.36 - 0.65
+// (tools/micro/lds_atomic.hip).  Pass 1 finds max |v| of the bin's records, pass 2 (the records come back from L2 / Infinity Cache) adds
+// round(v * 2^e), e such that the bin's n records cannot overflow 2^61: exact to 2^-37 of the largest record, independent of the order.
+// A bin holding a non-finite record is summed with float adds, which propagate it.
 __global__ void __launch_bounds__(256) k_encode_bin_reduce(GridMeta M, EncArgs A) {
-    __shared__ float2 acc[BIN_ENTRIES];
+    __shared__ long long s_fix[BIN_ENTRIES * 2];
+    __shared__ float s_max[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = min(A.bin_count[b], A.bin_cap);
     if (n == 0u) return;                                    // (a counter that overflowed is > 0, so it is reset below)
     int l = 0;
     for (int k = 0; k < M.n_levels; ++k)
         if (A.bin_base[k] >= 0 && A.bin_base[k] <= b) l = k;
-    for (int e = tid; e < BIN_ENTRIES; e += 256) acc[e] = make_float2(0.f, 0.f);
-    __syncthreads();
     const BinRec* rec = A.bin_rec + (size_t)b * A.bin_cap;
+    float vmax = 0.f;
+    bool finite = true;
     for (uint32_t j0 = tid; j0 < n; j0 += 256 * 8) {            // eight record loads in flight per lane (clamped, not predicated: a branch
         BinRec r[8];                                            //  around a load makes the compiler wait for it at the join)
 #pragma unroll
         for (int u = 0; u < 8; ++u) r[u] = rec[min(j0 + 256u * u, n - 1u)];
 #pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            vmax = fmaxf(vmax, fmaxf(fabsf(r[u].a), fabsf(r[u].b)));
+            finite = finite && (r[u].a - r[u].a == 0.f) && (r[u].b - r[u].b == 0.f);
+        }
+    }
+    if (!finite) vmax = __builtin_inff();
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
+    if ((tid & 63) == 0) s_max[tid >> 6] = vmax;
+    for (int e = tid; e < BIN_ENTRIES * 2; e += 256) s_fix[e] = 0ll;
+    __syncthreads();
+    vmax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    const bool fixed = vmax - vmax == 0.f;                      // workgroup-uniform
+    const int ev = (int)((__float_as_uint(vmax) >> 23) & 0xffu) - 126, en = 32 - __clz((int)(n - 1u));       // vmax < 2^ev, n <= 2^en
+    const double scale = fixed ? ldexp(1.0, 61 - ev - en) : 1.0;
+    float* const s_acc = reinterpret_cast<float*>(s_fix);
+    for (uint32_t j0 = tid; j0 < n; j0 += 256 * 8) {
+        BinRec r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = rec[min(j0 + 256u * u, n - 1u)];
+#pragma unroll
         for (int u = 0; u < 8; ++u)
             if (j0 + 256u * u < n) {
-                atomicAdd(&acc[r[u].e].x, r[u].a);
-                atomicAdd(&acc[r[u].e].y, r[u].b);
+                if (fixed) {
+                    unsigned long long* a = reinterpret_cast<unsigned long long*>(s_fix) + 2 * r[u].e;
+                    atomicAdd(a, (unsigned long long)__double2ll_rn((double)r[u].a * scale));
+                    atomicAdd(a + 1, (unsigned long long)__double2ll_rn((double)r[u].b * scale));
+                } else {
+                    atomicAdd(&s_acc[2 * r[u].e], r[u].a);
+                    atomicAdd(&s_acc[2 * r[u].e + 1], r[u].b);
+                }
             }
     }
     __syncthreads();
@@ -572,8 +604,9 @@ __global__ void __launch_bounds__(256) k_encode_bin_reduce(GridMeta M, EncArgs A
     const uint32_t first = (uint32_t)(b - A.bin_base[l]) << BIN_LOG, size = M.offset[l + 1] - M.offset[l];
     float2* g = reinterpret_cast<float2*>(A.g_params) + M.offset[l] + first;
     const int ne = (int)min((uint32_t)BIN_ENTRIES, size - first);
+    const double inv = 1.0 / scale;
     for (int e = tid; e < ne; e += 256) {
-        const float2 v = acc[e];
+        const float2 v = fixed ? make_float2((float)((double)s_fix[2 * e] * inv), (float)((double)s_fix[2 * e + 1] * inv)) : make_float2(s_acc[2 * e], s_acc[2 * e + 1]);
         if (v.x != 0.f || v.y != 0.f) {
             float2 t = g[e];
             t.x += v.x;

@@ -5,7 +5,8 @@
 #include <cstdio>
 __device__ __forceinline__ uint32_t pcg(uint32_t v) { uint32_t s = v * 747796405u + 2891336453u; uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u; return (w >> 22u) ^ w; }
 // MODE 0: float add no return, 1: u32 add returning, 2: u32 add no return, 3: plain ds_write (no atomic) as the LDS-rate reference,
-//      4: float add, interleaved float2 layout (x at even dwords only)
+//      4: float add, interleaved float2 layout (x at even dwords only), 5: u64 add no return (fixed-point accumulation), 6: the same + the
+//      float -> fixed-point conversion through double
 template <int MODE>
 __global__ void __launch_bounds__(256) k(uint32_t n_entries, int per_thread, int share, float* out) {
     __shared__ uint32_t s[8192];
@@ -21,6 +22,8 @@ __global__ void __launch_bounds__(256) k(uint32_t n_entries, int per_thread, int
         if (MODE == 2) atomicAdd(s + e, 1u);
         if (MODE == 3) s[e] = r;
         if (MODE == 4) atomicAdd(reinterpret_cast<float*>(s) + 2 * (e % 4096), 1.0f);
+        if (MODE == 5) atomicAdd(reinterpret_cast<unsigned long long*>(s) + (e % 4096), (unsigned long long)r);
+        if (MODE == 6) atomicAdd(reinterpret_cast<unsigned long long*>(s) + (e % 4096), (unsigned long long)(long long)((double)__uint_as_float((r & 0x007fffffu) | 0x3f000000u) * 1.0e12));
     }
     __syncthreads();
     if (acc == 0xdeadbeef || s[threadIdx.x] == 0xdeadbeef) out[0] = 1.f;
@@ -28,10 +31,10 @@ __global__ void __launch_bounds__(256) k(uint32_t n_entries, int per_thread, int
 int main() {
     const int per_thread = 512, blocks = 256 * 8, threads = 256;
     float* out; hipMalloc(&out, 4);
-    const char* names[5] = {"ds_add_f32", "ds_add_rtn_u32", "ds_add_u32", "ds_write_b32", "ds_add_f32 (even dwords)"};
-    for (uint32_t n : {128u, 4096u, 8192u})
+    const char* names[7] = {"ds_add_f32", "ds_add_rtn_u32", "ds_add_u32", "ds_write_b32", "ds_add_f32 (even dwords)", "ds_add_u64", "ds_add_u64 + f32->fixed"};
+    for (uint32_t n : {4096u})
         for (int share : {1, 4, 16})
-            for (int mode = 0; mode < 5; ++mode) {
+            for (int mode = 0; mode < 7; ++mode) {
                 hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
                 for (int rep = 0; rep < 2; ++rep) {
                     if (rep == 1) hipEventRecord(e0);
@@ -40,6 +43,8 @@ int main() {
                     if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(threads), 0, 0, n, per_thread, share, out);
                     if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(threads), 0, 0, n, per_thread, share, out);
                     if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(threads), 0, 0, n, per_thread, share, out);
+                    if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(threads), 0, 0, n, per_thread, share, out);
+                    if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(threads), 0, 0, n, per_thread, share, out);
                 }
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
