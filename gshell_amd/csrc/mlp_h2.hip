@@ -462,24 +462,44 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
 // -- is then recomputed by k_h2_fwd<MODE_FIX>, which also MEASURES the error on those rows (ST_MAXDEV).  If the one-product error
 // is below tau everywhere, signs at all vertices and values at all crossing-edge end points equal the one-pass h2 result bit for bit
 // (argument in DESIGN.md 2.1; tests/test_fullsize_parity_gpu.py checks it on the res-256 grid).
-template <int STRIDE, int NSTEPS>
-__device__ __forceinline__ void gemm_seg1(v16f (&acc)[2], const _Float16* __restrict__ P1, const h8* __restrict__ wf, int blk, int nblk, int lane) {
-    constexpr int PD = 2 < NSTEPS ? 2 : NSTEPS - 1;
+#ifndef GS_H1_PD
+#define GS_H1_PD 2
+#endif
+// Operand traffic decides this kernel, not the epilogue (profiles/r03_h1_dissection.txt): a 32x32x16 MFMA takes 8 cycles of a CU's
+// four matrix pipes, in which LDS delivers 1 KB and the vector-memory path 0.5 KB.  A wave that owns NB feature blocks x RM row blocks
+// reads RM activation fragments (LDS) and NB weight fragments (L1 / L2) of 1 KB each per k-step for NB x RM MFMAs:
+//   NB 1, RM 2 (8 waves x 64 rows)   1 KB LDS + 0.5 KB L1 per MFMA: both pipes at their limit, the matrix pipe reaches ~50 %
+//   NB 2, RM 4 (4 waves x 128 rows)  0.5 KB LDS + 0.25 KB L1 per MFMA
+template <int STRIDE, int NSTEPS, int NB, int RM>
+__device__ __forceinline__ void gemm_seg1(v16f (&acc)[NB][RM], const _Float16* __restrict__ P1, const h8* __restrict__ wf, int blk0, int nblk, int lane) {
+    constexpr int PD = GS_H1_PD < NSTEPS ? GS_H1_PD : NSTEPS - 1;      // weight fragments in flight ahead of the MFMAs
     const int row = lane & 31, kq = lane >> 5;
     const _Float16* b1p = P1 + row * STRIDE + kq * 8;
-    const h8* wp = wf + blk * 128 + lane;       // the high pieces of the h2 fragment set: + step * nblk * 128
+#ifdef GS_H1_XW      // experiment (WRONG results): every wave streams block 0's weights -> L1 hits instead of L2 traffic
+    const h8* wp = wf + lane + 0 * blk0;
+#else
+    const h8* wp = wf + blk0 * 128 + lane;       // the high pieces of the h2 fragment set: + step * nblk * 128
+#endif
     const int sstride = nblk * 128;
-    h8 a1[PD + 1];
+    h8 a1[NB][PD + 1];
 #pragma unroll
-    for (int i = 0; i < PD; ++i) a1[i] = wp[i * sstride];
+    for (int i = 0; i < PD; ++i)
+#pragma unroll
+        for (int q = 0; q < NB; ++q) a1[q][i] = wp[i * sstride + q * 128];
 #pragma unroll
     for (int st = 0; st < NSTEPS; ++st) {
-        if (st + PD < NSTEPS) a1[(st + PD) % (PD + 1)] = wp[(st + PD) * sstride];
-        const h8 b10 = *reinterpret_cast<const h8*>(b1p + st * 16);
-        const h8 b11 = *reinterpret_cast<const h8*>(b1p + 32 * STRIDE + st * 16);
-        const h8 w1 = a1[st % (PD + 1)];
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b10, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b11, acc[1], 0, 0, 0);
+        if (st + PD < NSTEPS)
+#pragma unroll
+            for (int q = 0; q < NB; ++q) a1[q][(st + PD) % (PD + 1)] = wp[(st + PD) * sstride + q * 128];
+        h8 bf[RM];
+#pragma unroll
+        for (int r = 0; r < RM; ++r) bf[r] = *reinterpret_cast<const h8*>(b1p + 32 * r * STRIDE + st * 16);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const h8 w1 = a1[q][st % (PD + 1)];
+#pragma unroll
+            for (int r = 0; r < RM; ++r) acc[q][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, bf[r], acc[q][r], 0, 0, 0);
+        }
     }
 }
 
@@ -533,15 +553,27 @@ __device__ __forceinline__ f2 softplus100_pair_poly(f2 z) {
 }
 
 #ifndef GS_H1_WAVES
-#define GS_H1_WAVES 6     // waves per SIMD the register budget is sized for (3 workgroups of 8 waves per CU)
+#define GS_H1_WAVES 6     // NW = 8, RM = 2: waves per SIMD the register budget is sized for (3 workgroups of 8 waves per CU)
 #endif
-__global__ void __launch_bounds__(NT, GS_H1_WAVES) k_h1_fwd(H2Args A) {
+#ifndef GS_H1_NW
+#define GS_H1_NW 8        // waves per workgroup: 8 (one 32-feature block per wave) or 4 (two blocks per wave)
+#endif
+#ifndef GS_H1_RM
+#define GS_H1_RM 2        // 32-row blocks per workgroup tile: 2 (64 rows) or 4 (128 rows: 80 KB of LDS, two workgroups fill a CU's 160 KB)
+#endif
+#ifndef GS_H1_WAVES4
+#define GS_H1_WAVES4 (GS_H1_RM == 4 ? 2 : 3)    // NW = 4: waves per SIMD
+#endif
+template <int RM> constexpr size_t smem_h1_bytes() { return (size_t)(32 * RM * LDH + 32 * RM * LDEH) * sizeof(_Float16); }
+template <int NW, int RM>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? GS_H1_WAVES : GS_H1_WAVES4) k_h1_fwd(H2Args A) {
+    constexpr int NTW = 64 * NW, NB = 8 / NW, TMT = 32 * RM;
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
-    _Float16* H1 = smem_h;                   // [TM][LDH]
-    _Float16* E1 = H1 + TM * LDH;            // [TM][LDEH]   (the output reduction scratch is overlaid at the end)
+    _Float16* H1 = smem_h;                   // [TMT][LDH]
+    _Float16* E1 = H1 + TMT * LDH;           // [TMT][LDEH]   (the output reduction scratch is overlaid at the end)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t tile = blockIdx.x, r0 = tile * TM;
-    for (int idx = tid; idx < TM * 24; idx += NT) {
+    const int64_t tile = blockIdx.x, r0 = tile * TMT;
+    for (int idx = tid; idx < TMT * 24; idx += NTW) {
         const int row = idx / 24, slot = idx - row * 24;
         const int64_t src = r0 + row;
         const bool valid = src < A.N;
@@ -560,69 +592,104 @@ __global__ void __launch_bounds__(NT, GS_H1_WAVES) k_h1_fwd(H2Args A) {
             for (int j = 0; j < 3; ++j) e[39 + 3 * (slot - 21) + j] = (_Float16)0.0f;
         }
     }
-    __syncthreads();
-    const int n_base = wave * 32 + 4 * (lane >> 5);
+    const int blk0 = wave * NB;
     const int m_lane = lane & 31;
+    // the bias is the accumulators' initial value (no add in the epilogue); the NEXT layer's is requested before this layer's epilogue,
+    // so that its L2 round trip (one per layer otherwise: 0.18 ms per launch) hides behind the activation function
+    float4 bnext[NB][4];
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bnext[q][g] = *reinterpret_cast<const float4*>(A.bias[0] + (blk0 + q) * 32 + 4 * (lane >> 5) + 8 * g);
+    __syncthreads();
     for (int l = 0; l < A.n_layers; ++l) {
-        // the bias is the accumulators' initial value (no add in the epilogue); output weights of the last layer requested early
-        const float* bl = A.bias[l] + n_base;
         const bool last = l + 1 == A.n_layers;
-        v16f acc[2];
-        float4 w4v[4];
+        v16f acc[NB][RM];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 b4 = *reinterpret_cast<const float4*>(bl + 8 * g);
-            w4v[g] = last ? *reinterpret_cast<const float4*>(A.w_out + n_base + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < NB; ++q)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                acc[s][4 * g] = b4.x; acc[s][4 * g + 1] = b4.y; acc[s][4 * g + 2] = b4.z; acc[s][4 * g + 3] = b4.w;
+            for (int g = 0; g < 4; ++g) {
+                const float4 b4 = bnext[q][g];
+#pragma unroll
+                for (int r = 0; r < RM; ++r) {
+                    acc[q][r][4 * g] = b4.x; acc[q][r][4 * g + 1] = b4.y; acc[q][r][4 * g + 2] = b4.z; acc[q][r][4 * g + 3] = b4.w;
+                }
             }
+        {   // next layer's bias, or the output weights after the last hidden layer (consumed by the epilogue of the last layer)
+            const float* nb = last ? A.w_out : A.bias[l + 1];
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bnext[q][g] = *reinterpret_cast<const float4*>(nb + (blk0 + q) * 32 + 4 * (lane >> 5) + 8 * g);
         }
+#ifdef GS_H1_XG      // experiment (WRONG results): no GEMM -> the epilogue phases alone
+        if (A.n_layers > 100) {
+#else
         if (l == 0) {
-            gemm_seg1<LDEH, EK / 16>(acc, E1, A.wfrag[0], wave, 8, lane);
+#endif
+            gemm_seg1<LDEH, EK / 16, NB, RM>(acc, E1, A.wfrag[0], blk0, 8, lane);
+#ifdef GS_H1_XG
+        } else if (A.n_layers > 100) {
+#else
         } else {
-            gemm_seg1<LDH, D / 16>(acc, H1, A.wfrag[l], wave, 8, lane);
-            if (l == A.skip_layer) gemm_seg1<LDEH, EK / 16>(acc, E1, A.wfrag[l] + (D / 16) * 1024, wave, 8, lane);
+#endif
+            gemm_seg1<LDH, D / 16, NB, RM>(acc, H1, A.wfrag[l], blk0, 8, lane);
+            if (l == A.skip_layer) gemm_seg1<LDEH, EK / 16, NB, RM>(acc, E1, A.wfrag[l] + (D / 16) * 1024, blk0, 8, lane);
         }
+#ifndef GS_H1_XB      // experiment (WRONG results): no barriers inside the layer loop
         __syncthreads();     // every wave is done reading the plane: it is overwritten in place
-        f2 part[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
+#endif
+        f2 part[RM];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f2 wj[2] = {f2{w4v[g].x, w4v[g].y}, f2{w4v[g].z, w4v[g].w}};
+        for (int r = 0; r < RM; ++r) part[r] = f2{0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const f2 v0 = softplus100_pair_poly(f2{acc[s][4 * g], acc[s][4 * g + 1]});
-                const f2 v1 = softplus100_pair_poly(f2{acc[s][4 * g + 2], acc[s][4 * g + 3]});
-                if (last) {
-                    part[s] = part[s] + v0 * wj[0] + v1 * wj[1];
-                } else {
-                    const h2 a0 = __builtin_convertvector(v0, h2), a1 = __builtin_convertvector(v1, h2);
-                    *reinterpret_cast<h4*>(H1 + (32 * s + m_lane) * LDH + n_base + 8 * g) = h4{a0.x, a0.y, a1.x, a1.y};
+        for (int q = 0; q < NB; ++q) {
+            const int n_base = (blk0 + q) * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f2 wj[2] = {f2{bnext[q][g].x, bnext[q][g].y}, f2{bnext[q][g].z, bnext[q][g].w}};       // (last layer: the output weights)
+#pragma unroll
+                for (int r = 0; r < RM; ++r) {
+#ifdef GS_H1_XE      // experiment (WRONG results): no activation function -> the GEMM phases alone
+                    const f2 v0 = f2{acc[q][r][4 * g], acc[q][r][4 * g + 1]}, v1 = f2{acc[q][r][4 * g + 2], acc[q][r][4 * g + 3]};
+#else
+                    const f2 v0 = softplus100_pair_poly(f2{acc[q][r][4 * g], acc[q][r][4 * g + 1]});
+                    const f2 v1 = softplus100_pair_poly(f2{acc[q][r][4 * g + 2], acc[q][r][4 * g + 3]});
+#endif
+                    if (last) {
+                        part[r] = part[r] + v0 * wj[0] + v1 * wj[1];
+                    } else {
+                        const h2 a0 = __builtin_convertvector(v0, h2), a1 = __builtin_convertvector(v1, h2);
+                        *reinterpret_cast<h4*>(H1 + (32 * r + m_lane) * LDH + n_base + 8 * g) = h4{a0.x, a0.y, a1.x, a1.y};
+                    }
                 }
             }
         }
         if (last) {
-            float* red = reinterpret_cast<float*>(E1);       // [8 waves][64 rows] fp32 = 2 KB (the encoding plane is dead now)
+            float* red = reinterpret_cast<float*>(E1);       // [NW waves][TMT rows] fp32 (the encoding plane is dead now)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float p = part[s].x + part[s].y;
+            for (int r = 0; r < RM; ++r) {
+                float p = part[r].x + part[r].y;
                 p += __shfl_xor(p, 32, 64);
-                if (lane < 32) red[wave * TM + 32 * s + lane] = p;
+                if (lane < 32) red[wave * TMT + 32 * r + lane] = p;
             }
         }
+#ifdef GS_H1_XB
+        if (last)
+#endif
         __syncthreads();
     }
-    if (tid < TM) {
+    if (tid < TMT) {
         const float* red = reinterpret_cast<const float*>(E1);
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) s += red[w * TM + tid];
+        for (int w = 0; w < NW; ++w) s += red[w * TMT + tid];
         s += A.w_out[D];
         const int64_t r = r0 + tid;
         if (r < A.N) A.out[r] = s;
-        const uint64_t m = __ballot(r < A.N && s > 0.0f);
-        if (A.occ && tid == 0) A.occ[tile] = m;
-        if (A.status && __ballot(r < A.N && !(fabsf(s) < 3.0e38f)) != 0ull && tid == 0) atomicOr(&A.status[ST_NONFINITE], 1u);
+        const uint64_t m = __ballot(r < A.N && s > 0.0f);                       // one 64-row sign word per wave
+        if (A.occ && lane == 0 && r < A.N) A.occ[tile * (TMT / 64) + wave] = m;
+        if (A.status && __ballot(r < A.N && !(fabsf(s) < 3.0e38f)) != 0ull && lane == 0) atomicOr(&A.status[ST_NONFINITE], 1u);
     }
 }
 
@@ -1462,8 +1529,9 @@ extern "C" int gs_sdf_mlp_fwd_h1(const float* x, int64_t N, const void* packed, 
     H2Args A{};
     A.x = x; A.out = out; A.occ = occ_bits; A.status = status; A.N = N; A.n_freq = n_freq;
     fill_fwd_args(A, packed, make_layout(n_freq, n_hidden, skip_layer));
-    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h1_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_H1_BYTES));
-    hipLaunchKernelGGL(k_h1_fwd, dim3((unsigned)gs::cdiv(N, TM)), dim3(NT), SMEM_H1_BYTES, (hipStream_t)stream, A);
+    constexpr size_t smem = smem_h1_bytes<GS_H1_RM>();
+    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h1_fwd<GS_H1_NW, GS_H1_RM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((k_h1_fwd<GS_H1_NW, GS_H1_RM>), dim3((unsigned)gs::cdiv(N, 32 * GS_H1_RM)), dim3(64 * GS_H1_NW), smem, (hipStream_t)stream, A);
     GS_LAUNCH_CHECK();
     return 0;
 }

@@ -4,7 +4,7 @@
 root="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 out=$(mktemp -d /tmp/kt.XXXX)
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o r -- python "$root/tools/shade_time.py" > "$out/run.log" 2>&1 </dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o r -- python "$root/tools/${GS_KT_SCRIPT:-shade_time.py}" ${GS_KT_ARGS:-} > "$out/run.log" 2>&1 </dev/null
 python - "$out" "$1" <<'PY'
 import csv, glob, re, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
