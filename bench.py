@@ -221,6 +221,7 @@ def algorithmic_bytes(N, Ftets, V_aug, T, B, H, W):
         "gs_mtets_count": 16 * Ftets + 20 * N, "gs_mtets_fill": 16 * Ftets + 20 * N + 20 * V_aug + 12 * T,
         "gs_bilateral_fwd_masked": npix * (12 + 12 + 8 + 16), "gs_bilateral_bwd_masked": npix * (12 + 8 + 16 + 12),
         "gs_hashgrid_encode_fwd": 2 * npix * (12 + 4 + 128), "gs_hashgrid_encode_bwd": 2 * npix * (12 + 4 + 128 + 12),
+        "gs_hashgrid_encode_bwd_binned": 2 * npix * (12 + 4 + 128 + 12),
         "gs_rasterize_fwd": B * (16 * V_aug + 12 * T) + npix * 40, "gs_aa_apply_fwd": npix * 8 * 45, "gs_aa_apply_bwd": npix * 12 * 45,
         "gs_sdf_reg_fwd": 8 * int(1.19 * Ftets) + 4 * N, "gs_texmlp_fwd_level_major": 2 * npix * 152, "gs_texmlp_bwd_level_major": 2 * npix * (152 + 128 + 24),
         "gs_frame_sums_fwd": npix * 4 * 49, "gs_frame_sums_bwd": npix * 8 * 49,
@@ -307,11 +308,11 @@ def roofline_of(name, rec, op_times, N, Ftets, V_aug, T, B, H, W, n, trainer):
         return out
     alg = algorithmic_bytes(N, Ftets, V_aug, T, B, H, W).get(name)
     if alg is None:
-        return {"kernel": name, "bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
+        return {"kernel": name, "bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": pmc_traffic(name) if N == 2282489 else None,
                 "avg_launch_ms": round(rec["ms"], 4)}
     gbps = alg / (rec["ms"] * 1e-3) / 1e9
-    return {"kernel": name, "bound": "hbm", "achieved": round(gbps, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 5), "traffic": None,
-            "avg_launch_ms": round(rec["ms"], 4), "algorithmic_bytes": int(alg)}
+    return {"kernel": name, "bound": "hbm", "achieved": round(gbps, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 5),
+            "traffic": pmc_traffic(name) if N == 2282489 else None, "avg_launch_ms": round(rec["ms"], 4), "algorithmic_bytes": int(alg)}
 
 
 def cpu_baseline(res=256):
