@@ -645,30 +645,30 @@ __global__ void __launch_bounds__(256, GS_GRAD_WAVES) k_shade_grad(ShadeArgs A) 
 //   k_light_base  : exclusive scan of the bin totals                 k_light_scatter: records -> bin-sorted order
 //   k_light_reduce: LDS accumulation per (bin, slice), a few float atomics per texel and slice to finish
 __global__ void __launch_bounds__(256) k_light_scan(uint32_t* __restrict__ hist, int64_t n_wg, int nbins, uint32_t* __restrict__ totals) {
+    // one workgroup per bin: every thread owns a contiguous stretch of the bin's per-workgroup counts (sum, then one scan of the 256
+    // sums, then the stretch again) -- two barriers, where a chunk-by-chunk scan took three per 256 counts (36 chunks at 4 x 512^2)
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* h = hist + (int64_t)blockIdx.x * n_wg;
-    if (tid == 0) s_carry = 0u;
-    __syncthreads();
-    for (int64_t base = 0; base < n_wg; base += 256) {
-        const int64_t w = base + tid;
-        const uint32_t v = w < n_wg ? h[w] : 0u;
-        uint32_t inc = v;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += o;
-        }
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        uint32_t before = s_carry;
-        for (int q = 0; q < wave; ++q) before += s_wave[q];
-        if (w < n_wg) h[w] = before + inc - v;          // in place: count -> offset inside the bin
-        __syncthreads();
-        if (tid == 255) s_carry = before + inc;
-        __syncthreads();
+    const int64_t per = (n_wg + 255) / 256, w0 = min(n_wg, tid * per), w1 = min(n_wg, w0 + per);
+    uint32_t sum = 0u;
+    for (int64_t w = w0; w < w1; ++w) sum += h[w];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
     }
-    if (tid == 0) totals[blockIdx.x] = s_carry;
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int q = 0; q < wave; ++q) run += s_wave[q];
+    for (int64_t w = w0; w < w1; ++w) {          // in place: count -> offset inside the bin
+        const uint32_t v = h[w];
+        h[w] = run;
+        run += v;
+    }
+    if (tid == 255) totals[blockIdx.x] = run;    // (the last thread's stretch may be empty: run is then the bin's total all the same)
 }
 
 __global__ void k_light_base(const uint32_t* __restrict__ totals, int nbins, uint32_t* __restrict__ base) {

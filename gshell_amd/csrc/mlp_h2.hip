@@ -465,13 +465,27 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
 #ifndef GS_H1_PD
 #define GS_H1_PD 2
 #endif
+#ifndef GS_H1_PRE
+#define GS_H1_PRE 0       // 1: the next layer's first weight fragments requested before the epilogue -- measured SLOWER (2.74 vs 2.59 ms: the 8 live VGPRs cost a wave of occupancy)
+#endif
 // Operand traffic decides this kernel, not the epilogue (profiles/r03_h1_dissection.txt): a 32x32x16 MFMA takes 8 cycles of a CU's
 // four matrix pipes, in which LDS delivers 1 KB and the vector-memory path 0.5 KB.  A wave that owns NB feature blocks x RM row blocks
 // reads RM activation fragments (LDS) and NB weight fragments (L1 / L2) of 1 KB each per k-step for NB x RM MFMAs:
 //   NB 1, RM 2 (8 waves x 64 rows)   1 KB LDS + 0.5 KB L1 per MFMA: both pipes at their limit, the matrix pipe reaches ~50 %
 //   NB 2, RM 4 (4 waves x 128 rows)  0.5 KB LDS + 0.25 KB L1 per MFMA
+template <int NB>
+struct H1Pre { h8 w[NB][GS_H1_PD]; };        // the first GS_H1_PD weight fragments of a layer, requested one epilogue ahead (GS_H1_PRE)
+template <int NB>
+__device__ __forceinline__ void h1_preload(H1Pre<NB>& pre, const h8* __restrict__ wf, int blk0, int nblk, int lane) {
+    const h8* wp = wf + blk0 * 128 + lane;
+#pragma unroll
+    for (int i = 0; i < GS_H1_PD; ++i)
+#pragma unroll
+        for (int q = 0; q < NB; ++q) pre.w[q][i] = wp[i * nblk * 128 + q * 128];
+}
 template <int STRIDE, int NSTEPS, int NB, int RM>
-__device__ __forceinline__ void gemm_seg1(v16f (&acc)[NB][RM], const _Float16* __restrict__ P1, const h8* __restrict__ wf, int blk0, int nblk, int lane) {
+__device__ __forceinline__ void gemm_seg1(v16f (&acc)[NB][RM], const _Float16* __restrict__ P1, const h8* __restrict__ wf, int blk0, int nblk, int lane,
+                                          const H1Pre<NB>* pre = nullptr) {
     constexpr int PD = GS_H1_PD < NSTEPS ? GS_H1_PD : NSTEPS - 1;      // weight fragments in flight ahead of the MFMAs
     const int row = lane & 31, kq = lane >> 5;
     const _Float16* b1p = P1 + row * STRIDE + kq * 8;
@@ -485,7 +499,7 @@ __device__ __forceinline__ void gemm_seg1(v16f (&acc)[NB][RM], const _Float16* _
 #pragma unroll
     for (int i = 0; i < PD; ++i)
 #pragma unroll
-        for (int q = 0; q < NB; ++q) a1[q][i] = wp[i * sstride + q * 128];
+        for (int q = 0; q < NB; ++q) a1[q][i] = pre ? pre->w[q][i] : wp[i * sstride + q * 128];
 #pragma unroll
     for (int st = 0; st < NSTEPS; ++st) {
         if (st + PD < NSTEPS)
@@ -601,6 +615,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? GS_H1_WAVES : GS_H1_WAVES4)
     for (int q = 0; q < NB; ++q)
 #pragma unroll
         for (int g = 0; g < 4; ++g) bnext[q][g] = *reinterpret_cast<const float4*>(A.bias[0] + (blk0 + q) * 32 + 4 * (lane >> 5) + 8 * g);
+    H1Pre<NB> wpre;
     __syncthreads();
     for (int l = 0; l < A.n_layers; ++l) {
         const bool last = l + 1 == A.n_layers;
@@ -633,9 +648,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? GS_H1_WAVES : GS_H1_WAVES4)
 #else
         } else {
 #endif
-            gemm_seg1<LDH, D / 16, NB, RM>(acc, H1, A.wfrag[l], blk0, 8, lane);
+            gemm_seg1<LDH, D / 16, NB, RM>(acc, H1, A.wfrag[l], blk0, 8, lane, GS_H1_PRE ? &wpre : nullptr);
             if (l == A.skip_layer) gemm_seg1<LDEH, EK / 16, NB, RM>(acc, E1, A.wfrag[l] + (D / 16) * 1024, blk0, 8, lane);
         }
+        // the next layer's first weight fragments: requested here, they land while the activation function runs (each layer's GEMM
+        // otherwise opens with an exposed L2 round trip)
+        if (GS_H1_PRE && !last) h1_preload<NB>(wpre, A.wfrag[l + 1], blk0, 8, lane);
 #ifndef GS_H1_XB      // experiment (WRONG results): no barriers inside the layer loop
         __syncthreads();     // every wave is done reading the plane: it is overwritten in place
 #endif
