@@ -465,6 +465,10 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
 #ifndef GS_H1_PD
 #define GS_H1_PD 2
 #endif
+#ifndef GS_H1_ASM
+#define GS_H1_ASM 0       // 1: activation fragments requested two k-steps ahead with volatile-asm ds_reads and counted waits.  Bit-identical results;
+                           // measured 5.85 ms against 2.66 with 8 waves per workgroup, 2.67 (no change) with 4: more LDS requests in flight per wave HURT
+#endif
 #ifndef GS_H1_PRE
 #define GS_H1_PRE 0       // 1: the next layer's first weight fragments requested before the epilogue -- measured SLOWER (2.74 vs 2.59 ms: the 8 live VGPRs cost a wave of occupancy)
 #endif
@@ -500,6 +504,46 @@ __device__ __forceinline__ void gemm_seg1(v16f (&acc)[NB][RM], const _Float16* _
     for (int i = 0; i < PD; ++i)
 #pragma unroll
         for (int q = 0; q < NB; ++q) a1[q][i] = pre ? pre->w[q][i] : wp[i * sstride + q * 128];
+#if GS_H1_ASM
+    // The activation fragments of step st + 2 are requested BEFORE the MFMAs of step st, and stay there: the ds_reads and the counted
+    // s_waitcnt are volatile asm (hipcc sinks plain loads back to their uses and then waits out the LDS latency in front of every MFMA
+    // pair).  The wait statement names the fragments it releases as in / out operands, so no MFMA can be scheduled above it.
+    static_assert(RM == 2 || RM == 4, "counted waits are written out for 2 and 4 row blocks");
+    constexpr int LA = 2 < NSTEPS ? 2 : NSTEPS - 1;
+    const uint32_t la = (uint32_t)(uintptr_t)b1p;
+    h8 bq[LA + 1][RM];
+    auto request = [&](int st) {
+#pragma unroll
+        for (int r = 0; r < RM; ++r) asm volatile("ds_read_b128 %0, %1" : "=v"(bq[st % (LA + 1)][r]) : "v"(la + 2u * (uint32_t)(32 * r * STRIDE + st * 16)) : "memory");
+    };
+#pragma unroll
+    for (int i = 0; i < LA; ++i) request(i);
+#pragma unroll
+    for (int st = 0; st < NSTEPS; ++st) {
+        if (st + PD < NSTEPS)
+#pragma unroll
+            for (int q = 0; q < NB; ++q) a1[q][(st + PD) % (PD + 1)] = wp[(st + PD) * sstride + q * 128];
+        if (st + LA < NSTEPS) request(st + LA);
+        const int ahead = (NSTEPS - 1 - st) < LA ? (NSTEPS - 1 - st) : LA;          // steps requested beyond this one
+        h8(&cur)[RM] = bq[st % (LA + 1)];
+        if (RM == 2) {
+            if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]));
+            else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(cur[0]), "+v"(cur[1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]));
+        } else {
+            if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2 % RM]), "+v"(cur[3 % RM]));
+            else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2 % RM]), "+v"(cur[3 % RM]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2 % RM]), "+v"(cur[3 % RM]));
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const h8 w1 = a1[q][st % (PD + 1)];
+#pragma unroll
+            for (int r = 0; r < RM; ++r) acc[q][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, cur[r], acc[q][r], 0, 0, 0);
+        }
+    }
+    return;
+#endif
 #pragma unroll
     for (int st = 0; st < NSTEPS; ++st) {
         if (st + PD < NSTEPS)
