@@ -61,7 +61,7 @@ __device__ __forceinline__ bool tri_hit(float4 v0, float4 e1, float4 e2, float o
     float px = dy * e2.z - dz * e2.y, py = dz * e2.x - dx * e2.z, pz = dx * e2.y - dy * e2.x;
     float det = e1.x * px + e1.y * py + e1.z * pz;
     if (!(fabsf(det) > 1e-20f)) return false;
-    float inv = 1.0f / det;
+    float inv = __fdiv_rn(1.0f, det);          // IEEE whatever the file's divide mode: hits are compared bit for bit with the host oracle
     float tx = ox - v0.x, ty = oy - v0.y, tz = oz - v0.z;
     float u = (tx * px + ty * py + tz * pz) * inv;
     if (!(u >= 0.0f && u <= 1.0f)) return false;
@@ -100,9 +100,9 @@ __device__ __forceinline__ bool bvh_ray_init(BvhRay& r, float ox, float oy, floa
     if (!(dx == dx && dy == dy && dz == dz) || (dx == 0.f && dy == 0.f && dz == 0.f)) return false;
     r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
     // finite reciprocals: a zero component would turn the fma slab test into inf - inf
-    r.ix = fabsf(dx) > 1e-18f ? 1.0f / dx : copysignf(1e18f, dx);
-    r.iy = fabsf(dy) > 1e-18f ? 1.0f / dy : copysignf(1e18f, dy);
-    r.iz = fabsf(dz) > 1e-18f ? 1.0f / dz : copysignf(1e18f, dz);
+    r.ix = fabsf(dx) > 1e-18f ? __fdiv_rn(1.0f, dx) : copysignf(1e18f, dx);
+    r.iy = fabsf(dy) > 1e-18f ? __fdiv_rn(1.0f, dy) : copysignf(1e18f, dy);
+    r.iz = fabsf(dz) > 1e-18f ? __fdiv_rn(1.0f, dz) : copysignf(1e18f, dz);
     r.nox = -ox * r.ix; r.noy = -oy * r.iy; r.noz = -oz * r.iz;
     r.sel = (r.ix < 0.f ? 1u : 0u) | (r.iy < 0.f ? 2u : 0u) | (r.iz < 0.f ? 4u : 0u);
     r.node = -1;
