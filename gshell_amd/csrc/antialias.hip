@@ -239,6 +239,108 @@ __global__ void __launch_bounds__(256) k_aa_apply_bwd(const float* __restrict__ 
     if (g_color) g_color[i] = acc;
 }
 
+// ---- in-place apply: only silhouette pixels are touched ---------------------------------------------------------------------------
+// k_aa_apply_fwd / bwd stream the whole [B,H,W,C] frame through (2 x 190 MB each way at 4 x 512^2 x 45) although ~1 % of its pixels change.
+// When the caller owns the frame (render_mesh: the composite is consumed by the antialias only) it is updated in place, in two launches so
+// that every blend reads UNMODIFIED colours: phase 1 writes the new value of every target pixel to a scratch tensor of the frame's shape (only
+// those entries are ever touched), phase 2 swaps them in -- the scratch then holds the ORIGINAL colours of the modified pixels, which is what
+// the backward pass needs.  Same expressions in the same order as the streaming kernels: bit-identical values and gradients.
+struct AaWeights { float ar, al, ad, au; };
+__device__ __forceinline__ bool aa_target(const float2* __restrict__ alpha, int64_t pix, int px, int py, int W, AaWeights& w) {
+    const float2 a = alpha[pix];
+    w.ar = a.x > 0.f ? a.x : 0.f;
+    w.ad = a.y > 0.f ? a.y : 0.f;
+    w.al = (px > 0) ? alpha[pix - 1].x : 0.f;
+    w.au = (py > 0) ? alpha[pix - W].y : 0.f;
+    w.al = w.al < 0.f ? w.al : 0.f;
+    w.au = w.au < 0.f ? w.au : 0.f;
+    return w.ar != 0.f || w.al != 0.f || w.ad != 0.f || w.au != 0.f;
+}
+
+template <int PHASE>
+__global__ void __launch_bounds__(256) k_aa_inplace_fwd(float* __restrict__ color, const float2* __restrict__ alpha, int64_t B, int H, int W, int C,
+                                                        float* __restrict__ scratch) {
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= B * (int64_t)H * W) return;
+    const int rem = (int)(pix % ((int64_t)H * W));
+    const int py = rem / W, px = rem - py * W;
+    AaWeights w;
+    if (!aa_target(alpha, pix, px, py, W, w)) return;
+    const int64_t i0 = pix * C, dn = (int64_t)W * C;
+    for (int c = 0; c < C; ++c) {
+        const int64_t i = i0 + c;
+        if (PHASE == 1) {
+            const float v = color[i];
+            float acc = v;
+            if (w.ar != 0.f) acc += w.ar * (color[i + C] - v);
+            if (w.al != 0.f) acc += w.al * (v - color[i - C]);
+            if (w.ad != 0.f) acc += w.ad * (color[i + dn] - v);
+            if (w.au != 0.f) acc += w.au * (v - color[i - dn]);
+            scratch[i] = acc;
+        } else {
+            const float t = color[i];
+            color[i] = scratch[i];
+            scratch[i] = t;
+        }
+    }
+}
+
+// original colour of (pixel q, channel): the saved one where the forward pass modified q
+__device__ __forceinline__ bool aa_is_target(const float2* __restrict__ alpha, int64_t q, int qx, int qy, int W) {
+    AaWeights w;
+    return aa_target(alpha, q, qx, qy, W, w);
+}
+
+template <int PHASE>
+__global__ void __launch_bounds__(256) k_aa_inplace_bwd(const float* __restrict__ out_color, const float* __restrict__ orig, const float2* __restrict__ alpha,
+                                                        int64_t B, int H, int W, int C, float* __restrict__ g, float* __restrict__ g_scratch,
+                                                        float* __restrict__ g_alpha) {
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= B * (int64_t)H * W) return;
+    const int rem = (int)(pix % ((int64_t)H * W));
+    const int py = rem / W, px = rem - py * W;
+    const float2 a = alpha[pix];
+    const float al = (px > 0) ? alpha[pix - 1].x : 0.f;
+    const float au = (py > 0) ? alpha[pix - W].y : 0.f;
+    if (a.x == 0.f && a.y == 0.f && al == 0.f && au == 0.f) return;         // the gradient of this pixel passes through unchanged
+    const int64_t i0 = pix * C, dn = (int64_t)W * C;
+    if (PHASE == 2) {
+        for (int c = 0; c < C; ++c) g[i0 + c] = g_scratch[i0 + c];
+        return;
+    }
+    const bool t0 = aa_is_target(alpha, pix, px, py, W);
+    const bool tr = a.x != 0.f && aa_is_target(alpha, pix + 1, px + 1, py, W);
+    const bool td = a.y != 0.f && aa_is_target(alpha, pix + W, px, py + 1, W);
+    float dax = 0.f, day = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const int64_t i = i0 + c;
+        const float gv = g[i];
+        float acc = gv;
+        const float c0 = t0 ? orig[i] : out_color[i];
+        if (a.x != 0.f) {   // pair (p, right): tau = a.x > 0 ? p : right ; c0 = c[p], c1 = c[right]
+            const float gt = a.x > 0.f ? gv : g[i + C];
+            acc -= a.x * gt;
+            const float c1 = tr ? orig[i + C] : out_color[i + C];
+            const float d = gt * (c1 - c0);
+            if (d != 0.f) dax += d;
+        }
+        if (a.y != 0.f) {
+            const float gt = a.y > 0.f ? gv : g[i + dn];
+            acc -= a.y * gt;
+            const float c1 = td ? orig[i + dn] : out_color[i + dn];
+            const float d = gt * (c1 - c0);
+            if (d != 0.f) day += d;
+        }
+        if (al != 0.f) acc += al * (al > 0.f ? g[i - C] : gv);
+        if (au != 0.f) acc += au * (au > 0.f ? g[i - dn] : gv);
+        g_scratch[i] = acc;
+    }
+    if (g_alpha) {          // this pixel owns its two pairs: plain stores (the streaming kernel adds the channels with atomics, in any order)
+        g_alpha[2 * pix] = dax;
+        g_alpha[2 * pix + 1] = day;
+    }
+}
+
 __device__ __forceinline__ void pair_bwd(const float4* __restrict__ pv, float* __restrict__ gp, const PairGeom& g, float g_alpha, int d,
                                          int H, int W) {
     if (g.alpha == 0.f || g_alpha == 0.f) return;
@@ -361,6 +463,32 @@ extern "C" int gs_aa_apply_bwd(const float* color, const float* alpha, int64_t B
     if (g_alpha) GS_HIP_CHECK(hipMemsetAsync(g_alpha, 0, (size_t)npix * 8, (hipStream_t)stream));
     hipLaunchKernelGGL(k_aa_apply_bwd, dim3((unsigned)gs::cdiv(npix * C, 256)), dim3(256), 0, (hipStream_t)stream, color, (const float2*)alpha, B,
                        (int)H, (int)W, (int)C, g_out, g_color, g_alpha);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_aa_apply_fwd_inplace(float* color, const float* alpha, int64_t B, int64_t H, int64_t W, int64_t C, float* scratch, gs_stream_t stream) {
+    int64_t npix = B * H * W;
+    if (npix == 0 || C == 0) return 0;
+    GS_REQUIRE(color && alpha && scratch && color != scratch, "gs_aa_apply_fwd_inplace: null or aliased pointer");
+    const dim3 grid((unsigned)gs::cdiv(npix, 256)), block(256);
+    hipLaunchKernelGGL(k_aa_inplace_fwd<1>, grid, block, 0, (hipStream_t)stream, color, (const float2*)alpha, B, (int)H, (int)W, (int)C, scratch);
+    hipLaunchKernelGGL(k_aa_inplace_fwd<2>, grid, block, 0, (hipStream_t)stream, color, (const float2*)alpha, B, (int)H, (int)W, (int)C, scratch);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gs_aa_apply_bwd_inplace(const float* out_color, const float* saved, const float* alpha, int64_t B, int64_t H, int64_t W, int64_t C,
+                                       float* g, float* g_scratch, float* g_alpha, gs_stream_t stream) {
+    int64_t npix = B * H * W;
+    if (npix == 0 || C == 0) return 0;
+    GS_REQUIRE(out_color && saved && alpha && g && g_scratch && g != g_scratch, "gs_aa_apply_bwd_inplace: null or aliased pointer");
+    if (g_alpha) GS_HIP_CHECK(hipMemsetAsync(g_alpha, 0, (size_t)npix * 8, (hipStream_t)stream));
+    const dim3 grid((unsigned)gs::cdiv(npix, 256)), block(256);
+    hipLaunchKernelGGL(k_aa_inplace_bwd<1>, grid, block, 0, (hipStream_t)stream, out_color, saved, (const float2*)alpha, B, (int)H, (int)W, (int)C, g,
+                       g_scratch, g_alpha);
+    hipLaunchKernelGGL(k_aa_inplace_bwd<2>, grid, block, 0, (hipStream_t)stream, out_color, saved, (const float2*)alpha, B, (int)H, (int)W, (int)C, g,
+                       g_scratch, (float*)nullptr);
     GS_LAUNCH_CHECK();
     return 0;
 }

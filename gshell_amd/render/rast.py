@@ -318,6 +318,47 @@ class _AntialiasFn(torch.autograd.Function):
         return g_color, g_pos, None, None, None, None
 
 
+class _AntialiasInplaceFn(torch.autograd.Function):
+    """antialias of a frame the caller OWNS, in place (gs_aa_apply_*_inplace): only the silhouette pixels are read and written instead of two
+    passes over the whole [B,H,W,C] frame each way.  Bit-identical to _AntialiasFn.  The incoming gradient is updated in place as well: it has
+    exactly this node as its consumer (the engine hands a node either its single producer's tensor or its own accumulation buffer)."""
+
+    @staticmethod
+    def forward(ctx, color, pos, rast, tri, topo):
+        L = _lib.lib()
+        if not (color.is_cuda and color.dtype == torch.float32 and color.is_contiguous()):
+            raise _lib.GShellHipError("in-place antialias needs a contiguous fp32 frame in HBM")
+        B, H, W, C = color.shape
+        alpha = aa_analyze(rast, pos, tri, topo)
+        saved = torch.empty_like(color)          # only the entries of modified pixels are ever touched
+        with torch.cuda.device(color.device):
+            check(L.gs_aa_apply_fwd_inplace(ptr(color), ptr(alpha), c_int64(B), c_int64(H), c_int64(W), c_int64(C), ptr(saved), stream()),
+                  "gs_aa_apply_fwd_inplace")
+        ctx.mark_dirty(color)
+        ctx.save_for_backward(color, saved, alpha, pos.detach().contiguous().float(), rast.detach().contiguous().float(), tri, topo.opp)
+        return color
+
+    @staticmethod
+    def backward(ctx, g_out):
+        out, saved, alpha, pos_c, rast_c, tri, opp = ctx.saved_tensors
+        L = _lib.lib()
+        B, H, W, C = out.shape
+        need_pos = ctx.needs_input_grad[1]
+        g = g_out if (g_out.is_contiguous() and g_out.dtype == torch.float32) else g_out.contiguous().float()
+        g_scratch = torch.empty_like(g)
+        g_alpha = torch.empty_like(alpha) if need_pos else None
+        g_pos = None
+        with torch.cuda.device(out.device):
+            check(L.gs_aa_apply_bwd_inplace(ptr(out), ptr(saved), ptr(alpha), c_int64(B), c_int64(H), c_int64(W), c_int64(C), ptr(g), ptr(g_scratch),
+                                            ptr(g_alpha), stream()), "gs_aa_apply_bwd_inplace")
+            if need_pos:
+                g_pos = torch.zeros_like(pos_c)
+                check(L.gs_aa_analyze_bwd(ptr(pos_c), c_int64(pos_c.shape[0]), c_int64(pos_c.shape[1]), ptr(tri), c_int64(tri.shape[0]), ptr(opp),
+                                          ptr(rast_c), c_int64(H), c_int64(W), ptr(alpha), ptr(g_alpha), ptr(g_pos), stream()),
+                      "gs_aa_analyze_bwd")
+        return g, g_pos, None, None, None
+
+
 _aa_cache = {"key": None, "refs": None, "topo": None, "alpha": None}
 
 
@@ -343,14 +384,18 @@ def antialias_cache_clear():
     _aa_cache.update(key=None, refs=None, topo=None, alpha=None)
 
 
-def antialias_stacked(colors, rast, pos, tri, topo=None):
-    """Antialias several [B,H,W,Ci] buffers with ONE analysis and ONE apply launch (channels stacked)."""
+def antialias_stacked(colors, rast, pos, tri, topo=None, inplace=False):
+    """Antialias several [B,H,W,Ci] buffers with ONE analysis and ONE apply launch (channels stacked).  `inplace` (a single buffer that the
+    caller owns and hands over): the frame is updated in place, only its silhouette pixels are touched."""
     if tri.shape[0] == 0:
         return list(colors)
     if topo is None:
         topo = AATopology(tri, pos.shape[1])
     if len(colors) == 1:          # (torch.cat / torch.split of ONE tensor still copy it, forward and backward: 2 x 190 MB at 4 x 512^2 x 45)
-        return [_AntialiasFn.apply(colors[0], pos, rast, tri, topo, None)]
+        c = colors[0]
+        if inplace and c.is_cuda and c.dtype == torch.float32 and c.is_contiguous() and not c.is_leaf:
+            return [_AntialiasInplaceFn.apply(c, pos, rast, tri, topo)]
+        return [_AntialiasFn.apply(c, pos, rast, tri, topo, None)]
     sizes = [c.shape[-1] for c in colors]
     out = _AntialiasFn.apply(torch.cat(colors, dim=-1), pos, rast, tri, topo, None)
     return list(torch.split(out, sizes, dim=-1))

@@ -439,7 +439,7 @@ def render_mesh(FLAGS, ctx, mesh, mtx_in, view_pos, lgt, resolution, spp=1, num_
         sizes = [4] * 11 + ([1] if pf.msdf_image is not None else [])
         comp = _ShadeAssembleFn.apply(rast, pf.tex, pf.texj, pf.n_in, pf.n_jit, pf.mask_tap, pf.n_shade, pf.n_geo, pf.depth, pf.dif, pf.spc,
                                       pf.msdf_image, background[..., 0:3])
-        aa = dr.antialias_stacked([comp], rast, v_pos_clip, tri)[0]
+        aa = dr.antialias_stacked([comp], rast, v_pos_clip, tri, inplace=True)[0]        # comp is this function's own: updated in place
         out_list = list(torch.split(aa, sizes, dim=-1))
         buffers = None
     else:

@@ -211,6 +211,17 @@ int gs_aa_apply_fwd(const float* color, const float* alpha, int64_t B, int64_t H
 int gs_aa_apply_bwd(const float* color, const float* alpha, int64_t B, int64_t H, int64_t W,
                     int64_t C, const float* g_out, float* g_color, float* g_alpha,
                     gs_stream_t stream);
+/* The same apply IN PLACE, for a frame the caller owns (only silhouette pixels are touched: ~1 % of the frame instead of two full passes each way):
+ *   fwd: color [B,H,W,C] UPDATED; scratch = a tensor of the same shape (uninitialised) that afterwards holds the ORIGINAL colours of the
+ *        modified pixels (keep it for the backward pass);
+ *   bwd: out_color = the updated frame, saved = that scratch, g [B,H,W,C] = d loss / d out on entry and d loss / d color on exit,
+ *        g_scratch = another tensor of that shape (uninitialised), g_alpha [B,H,W,2] WRITTEN or NULL.  Values and gradients are
+ *        bit-identical to gs_aa_apply_fwd / bwd (g_alpha up to the order in which the streaming kernel adds its channels). */
+int gs_aa_apply_fwd_inplace(float* color, const float* alpha, int64_t B, int64_t H, int64_t W,
+                            int64_t C, float* scratch, gs_stream_t stream);
+int gs_aa_apply_bwd_inplace(const float* out_color, const float* saved, const float* alpha,
+                            int64_t B, int64_t H, int64_t W, int64_t C, float* g, float* g_scratch,
+                            float* g_alpha, gs_stream_t stream);
 int gs_aa_analyze_bwd(const float* pos_clip, int64_t B, int64_t V, const int32_t* tri, int64_t T,
                       const int32_t* opp, const float* rast, int64_t H, int64_t W,
                       const float* alpha, const float* g_alpha, float* g_pos, gs_stream_t stream);

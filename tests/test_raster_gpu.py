@@ -262,3 +262,34 @@ def test_interpolate_groups_equals_the_stacked_interpolation(channels, skip):
             assert y.grad is None and float(x.grad.abs().max()) == 0
         else:
             assert float((x.grad - y.grad).abs().max()) <= 1e-5 * float(x.grad.abs().max())
+
+
+@pytest.mark.parametrize("kind,C", [("soup", 5), ("sheet", 45), ("big", 3)])
+def test_inplace_antialias_equals_the_streaming_one_bit_for_bit(kind, C):
+    """dr.antialias_stacked([frame], inplace=True) (two sparse launches over the silhouette pixels, the frame and the incoming gradient updated
+    in place) against the out-of-place kernels: output, colour gradient and position gradient... the first two bit-identical, the position
+    gradient up to the float atomics' order (the in-place kernel sums a pixel's channels in one lane, the streaming one with atomics)."""
+    from gshell_amd.render import rast as dr
+    verts, tri = _scene(kind, 4)
+    pos, _, _ = _clip(verts, 2, first=1)
+    H, W = 80, 80
+    tri_d = torch.tensor(tri, device=DEV)
+    rast_d, _ = dr.rasterize(None, pos.to(DEV), tri_d, (H, W))
+    g = torch.Generator().manual_seed(17)
+    color = torch.rand(2, H, W, C, generator=g)
+    wgt = torch.rand(2, H, W, C, generator=g).to(DEV)
+    res = []
+    for inplace in (False, True):
+        c = color.to(DEV).requires_grad_(True)
+        p = pos.to(DEV).requires_grad_(True)
+        frame = c * 1.0                                   # a non-leaf the caller owns
+        keep = frame.detach().clone()
+        out = dr.antialias_stacked([frame], rast_d.detach(), p, tri_d, inplace=inplace)[0]
+        assert (out.data_ptr() == frame.data_ptr()) == inplace
+        (out * wgt).sum().backward()
+        res.append((out.detach().clone(), c.grad.clone(), p.grad.clone(), keep))
+    assert float((res[0][0] - res[0][3]).abs().max()) > 0, "the scene has no silhouette pixel: nothing tested"
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    scale = float(res[0][2].abs().max())
+    assert scale > 0 and float((res[0][2] - res[1][2]).abs().max()) <= 1e-5 * scale
