@@ -83,8 +83,7 @@ class _TexMlpFn(torch.autograd.Function):
 
 
 BINNED_TABLE_GRAD = True   # _FieldFn backward: hashed levels' table gradient through per-bin record arrays (gs_hashgrid_encode_bwd_binned), no atomics
-import os as _os
-BIN_COVERAGE = float(_os.environ.get('GS_BIN_COVERAGE', 0.2))         # bin capacity is sized for this fraction of the rows having mask > 0 (x1.25 slack); fuller frames spill to the atomic path
+BIN_COVERAGE = 0.2         # bin capacity is sized for this fraction of the rows having mask > 0 (x1.25 slack); fuller frames spill to the atomic path
 _bin_scratch = {}
 
 
@@ -94,7 +93,7 @@ def _bins(cfg, N, device):
     if nb <= 0:
         return None
     per_level = max(1, (1 << cfg[2]) // int(_lib.lib().gs_hashgrid_bin_entries()))      # bins of a full-size (hashed) level
-    cap = int(1.25 * BIN_COVERAGE * N * 8 / per_level) + 1024 + int(_os.environ.get('GS_BIN_SKEW', 0))
+    cap = int(1.25 * BIN_COVERAGE * N * 8 / per_level) + 1024
     key = (str(device), nb, cap)
     if key not in _bin_scratch:
         _bin_scratch.clear()
