@@ -760,6 +760,14 @@ extern "C" int gs_mtets_flag_refine_rows(const gs_mtets_topo* t, const float* sd
     return 0;
 }
 
+extern "C" int gs_flag_refine_rows_edges(const int32_t* edges, int64_t E, const float* sdf, float tau, float* flags, gs_stream_t stream) {
+    if (E == 0) return 0;
+    GS_REQUIRE(edges && sdf && flags, "gs_flag_refine_rows_edges: null argument");
+    k_flag_refine<<<(unsigned)gs::cdiv(E, 256), 256, 0, (hipStream_t)stream>>>((const int2*)edges, E, sdf, tau, flags);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int gs_mtets_occ_bits(gs_mtets_topo* t, uint64_t** bits_dev, int64_t* n_words) {
     GS_REQUIRE(t && bits_dev && n_words, "gs_mtets_occ_bits: null argument");
     *bits_dev = t->occ_bits;

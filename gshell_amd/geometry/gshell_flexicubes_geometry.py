@@ -6,7 +6,7 @@ import torch
 from ..render import mesh, optixutils as ou, render, util
 from .gshell_flexicubes import GShellFlexiCubes
 from .gshell_tets_geometry import GShellTetsGeometry, compute_sdf_reg_loss, sample_points   # noqa: F401  (same losses)
-from .mlp import MLP, forward_row_sharded, forward_row_sparse_backward
+from .mlp import MLP, EdgeList, check_forward_status, forward_row_sharded, forward_row_sparse_backward
 
 
 class GShellFlexiCubesGeometry(GShellTetsGeometry):
@@ -51,11 +51,28 @@ class GShellFlexiCubesGeometry(GShellTetsGeometry):
         self._all_edges = torch.sort(e, dim=1).values.int().contiguous()     # unique (min,max) grid edges (reference :124-127); read through the base class property `all_edges`
         self.max_displacement = util.length(self.verts[e[:, 0]] - self.verts[e[:, 1]]).mean() / 4
 
+    def _refine_edges(self):
+        # the extraction consumes SDF signs at every grid vertex and values only at the end points of sign-changing cube edges
+        # (gshell_flexicubes.py:387-485: u_e of the surface edges), the sign regulariser runs over the same edges (:124-127): the
+        # two-pass forward's selection rule over the unique cube edges
+        el = getattr(self, "_edge_list", None)
+        if el is None or el.edges.data_ptr() != self.all_edges.data_ptr():
+            el = self._edge_list = EdgeList(self.all_edges, self.verts.shape[0])
+        return el
+
     def getMesh(self, material, _training=False):
         v_deformed = self.verts + self.max_displacement * self.deform
         sdf = self._sdf_values(v_deformed)
         w = self.per_cube_weights
         out = self.gflexicubes(v_deformed, sdf, self.msdf, self.indices, self.grid_res, w[:, :12], w[:, 12:20], w[:, 20], training=_training)
+        if self.FLAGS.use_sdf_mlp:
+            # status words of the (two-pass) forward; the extraction has just synchronised the stream for its counts
+            todo = check_forward_status(self.sdf_net)
+            if todo is not None:
+                self._recover_forward(todo)
+                sdf = self._sdf_values(v_deformed)
+                out = self.gflexicubes(v_deformed, sdf, self.msdf, self.indices, self.grid_res, w[:, :12], w[:, 12:20], w[:, 20], training=_training)
+                check_forward_status(self.sdf_net)
         if len(out) == 3:
             raise RuntimeError("FlexiCubes produced an empty surface (the reference fails here too: its 3-tuple cannot be unpacked, :179)")
         verts, faces, reg_loss, extra = out

@@ -263,8 +263,24 @@ class GShellTetsGeometry(torch.nn.Module):
         if shard is not None and shard.world > 1 and getattr(self.FLAGS, "shard_mlp_rows", False):
             return forward_row_sharded(self.sdf_net, v_deformed, shard)
         # single GPU: the kernel's epilogue also writes the extraction's occupancy bits (fused geometry front end)
-        sink = self.gshell_tets.topology(self.indices, self.verts.shape[0]) if hasattr(self, 'gshell_tets') else None
+        sink = self.gshell_tets.topology(self.indices, self.verts.shape[0]) if hasattr(self, 'gshell_tets') else self._refine_edges()
         return forward_row_sparse_backward(self.sdf_net, v_deformed, sign_sink=sink)
+
+    def _refine_edges(self):
+        """Edge set of the two-pass SDF forward for a geometry without a TetTopology (overridden by G-FlexiCubes); None = one pass."""
+        return None
+
+    def _recover_forward(self, todo):
+        """What check_forward_status asked for after an extraction's host sync: switch this network's evaluation mode (reference fp32
+        GEMMs, geometry/mlp.py:32-40, have neither the fp16 range limit nor a one-product pass); the caller then re-evaluates."""
+        import warnings
+        if todo == "fp32":
+            warnings.warn("SDF network: fp16-pair arithmetic overflowed; switching this network to torch fp32 ops")
+            self.sdf_net._gs_precision = "torch"
+        else:
+            warnings.warn(f"SDF network: one-product pass off by {self.sdf_net.__dict__.get('_gs_two_pass_maxdev'):.3e} on the refined rows "
+                          "(more than tau / 4): this network is evaluated in one pass from now on")
+            self.sdf_net._gs_one_pass = True
 
     def getMesh(self, material):
         v_deformed = self.verts + self.max_displacement * self.deform
@@ -277,16 +293,9 @@ class GShellTetsGeometry(torch.nn.Module):
             # status words of the fused forward pass; the extraction's count has just synchronised the stream, so this costs no stall
             todo = check_forward_status(self.sdf_net)
             if todo is not None:
-                import warnings
-                if todo == "fp32":
-                    # an activation or weight beyond the fp16 range (the reference's fp32 GEMMs, geometry/mlp.py:32-40, have no such
-                    # limit): from now on plain torch fp32 ops evaluate this network and carry its gradients (counted in mlp.FALLBACKS)
-                    warnings.warn("SDF network: fp16-pair arithmetic overflowed; switching this network to torch fp32 ops")
-                    self.sdf_net._gs_precision = "torch"
-                else:
-                    warnings.warn(f"SDF network: one-product pass off by {self.sdf_net.__dict__.get('_gs_two_pass_maxdev'):.3e} on the refined rows "
-                                  "(more than tau / 4): this network is evaluated in one pass from now on")
-                    self.sdf_net._gs_one_pass = True
+                # an activation or weight beyond the fp16 range, or a one-product pass that is off by too much: from now on this network is
+                # evaluated by plain torch fp32 ops (counted in mlp.FALLBACKS) / in one pass
+                self._recover_forward(todo)
                 sdf = self._sdf_values(v_deformed - self.offset)
                 verts, faces, uvs, uv_idx, v_tng, extra = self.gshell_tets(v_deformed, sdf, msdf, self.indices)
                 check_forward_status(self.sdf_net)

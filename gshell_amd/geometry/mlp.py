@@ -317,6 +317,15 @@ def check_forward_status(net, wait=True):
     return None
 
 
+class EdgeList:
+    """The static edges over which a consumer of the SDF looks for sign changes, for the two-pass forward when there is no TetTopology
+    (G-FlexiCubes: the unique cube edges).  edges [E,2] int32 on the device, N = number of grid vertices."""
+
+    def __init__(self, edges, N):
+        self.edges = edges.detach().int().contiguous()
+        self.N = int(N)
+
+
 def fused_forward(net, x, precision=None, occ_bits_ptr=None, refine_topo=None, defer_status=False):
     """sdf = net(x) through the fused MFMA kernel (no autograd).  `occ_bits_ptr`: device address of a [ceil(N/64)] uint64
     array that receives the sign bits (h2 only; the extraction's occupancy bits).  `refine_topo` (a TetTopology
@@ -343,7 +352,11 @@ def fused_forward(net, x, precision=None, occ_bits_ptr=None, refine_topo=None, d
                 check(L.gs_sdf_mlp_fwd_h1(ptr(xc, torch.float32, "x"), c_int64(N), ptr(packed), c_int(nf), c_int(n_hidden), c_int(skip),
                                           ptr(out), occ, ptr(st.dev), stream()), "gs_sdf_mlp_fwd_h1")
                 flags = torch.zeros(N, dtype=torch.float32, device=xc.device)
-                check(L.gs_mtets_flag_refine_rows(refine_topo.handle, ptr(out), _lib.c_float(st.tau), ptr(flags), stream()), "gs_mtets_flag_refine_rows")
+                if isinstance(refine_topo, EdgeList):
+                    check(L.gs_flag_refine_rows_edges(ptr(refine_topo.edges, torch.int32, "edges"), c_int64(refine_topo.edges.shape[0]), ptr(out),
+                                                      _lib.c_float(st.tau), ptr(flags), stream()), "gs_flag_refine_rows_edges")
+                else:
+                    check(L.gs_mtets_flag_refine_rows(refine_topo.handle, ptr(out), _lib.c_float(st.tau), ptr(flags), stream()), "gs_mtets_flag_refine_rows")
                 rows = torch.empty(N, dtype=torch.int32, device=xc.device)
                 st.n_rows = torch.empty(2, dtype=torch.int64, device=xc.device)
                 scratch = torch.empty(int(L.gs_compact_rows_scratch_bytes(c_int64(N))) // 4 + 4, dtype=torch.int32, device=xc.device)
@@ -433,7 +446,8 @@ class _RowSparseBackward(torch.autograd.Function):
     def forward(ctx, x, net, sign_sink, gate):
         with torch.no_grad():
             presign = sign_sink is not None and SDF_MLP_PRECISION == "h2" and _fusable(net, x) and sign_sink.N == x.shape[0]
-            y = (fused_forward(net, x, occ_bits_ptr=sign_sink.occ_bits_ptr() if presign else None, refine_topo=sign_sink if presign else None,
+            bits = sign_sink.occ_bits_ptr() if (presign and not isinstance(sign_sink, EdgeList)) else None      # an EdgeList only selects the refined rows
+            y = (fused_forward(net, x, occ_bits_ptr=bits, refine_topo=sign_sink if presign else None,
                                defer_status=presign) if _fusable(net, x, "forward") else net(x))
         ctx.net = net
         ctx.presigned = presign
@@ -662,9 +676,10 @@ def forward_row_sharded(net, x, shard):
 def forward_row_sparse_backward(net, x, sign_sink=None):
     """net(x) with the row-sparse backward described above (first-order gradients only).  `sign_sink` (a TetTopology): the
     kernel's epilogue also writes the sign bits of the result straight into the extractor's occupancy array; the returned
-    tensor is tagged (`_gs_presigned`) so that GShell_Tets skips its own sign pass."""
+    tensor is tagged (`_gs_presigned`) so that GShell_Tets skips its own sign pass.  `sign_sink` (an EdgeList): two-pass evaluation
+    over that edge set, no sign bits.  Either way the caller must call check_forward_status(net) after its next host sync."""
     y = _RowSparseBackward.apply(x, net, sign_sink, param_gate(net))
-    if sign_sink is not None and SDF_MLP_PRECISION == "h2" and _fusable(net, x) and sign_sink.N == x.shape[0]:
+    if sign_sink is not None and not isinstance(sign_sink, EdgeList) and SDF_MLP_PRECISION == "h2" and _fusable(net, x) and sign_sink.N == x.shape[0]:
         sign_sink.sign_epoch += 1
         y._gs_presigned = (sign_sink, sign_sink.sign_epoch, y._version)
     return y

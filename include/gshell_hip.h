@@ -71,6 +71,10 @@ int gs_mtets_count_presigned(gs_mtets_topo* topo, const float* sdf_n, const floa
  * |sdf| < tau at either end. */
 int gs_mtets_flag_refine_rows(const gs_mtets_topo* topo, const float* sdf_n, float tau, float* flags,
                               gs_stream_t stream);
+/* The same rule over an explicit edge list [E,2] i32 (the unique cube edges of a G-FlexiCubes grid, gshell_flexicubes_geometry.py:124-127:
+ * its extraction consumes signs everywhere and values only at the end points of sign-changing cube edges, gshell_flexicubes.py:387-485). */
+int gs_flag_refine_rows_edges(const int32_t* edges, int64_t E, const float* sdf_n, float tau, float* flags,
+                              gs_stream_t stream);
 
 /* Fill phase; must follow gs_mtets_count on the same topo/stream with the same inputs.
  *   verts_aug [V_aug,3] f32, msdf_aug [V_aug] f32 (stop-gradient mSDF, ref :386-390),
