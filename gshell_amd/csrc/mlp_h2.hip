@@ -493,11 +493,7 @@ __device__ __forceinline__ void gemm_seg1(v16f (&acc)[NB][RM], const _Float16* _
     constexpr int PD = GS_H1_PD < NSTEPS ? GS_H1_PD : NSTEPS - 1;      // weight fragments in flight ahead of the MFMAs
     const int row = lane & 31, kq = lane >> 5;
     const _Float16* b1p = P1 + row * STRIDE + kq * 8;
-#ifdef GS_H1_XW      // experiment (WRONG results): every wave streams block 0's weights -> L1 hits instead of L2 traffic
-    const h8* wp = wf + lane + 0 * blk0;
-#else
     const h8* wp = wf + blk0 * 128 + lane;       // the high pieces of the h2 fragment set: + step * nblk * 128
-#endif
     const int sstride = nblk * 128;
     h8 a1[NB][PD + 1];
 #pragma unroll
@@ -681,26 +677,16 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? GS_H1_WAVES : GS_H1_WAVES4)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) bnext[q][g] = *reinterpret_cast<const float4*>(nb + (blk0 + q) * 32 + 4 * (lane >> 5) + 8 * g);
         }
-#ifdef GS_H1_XG      // experiment (WRONG results): no GEMM -> the epilogue phases alone
-        if (A.n_layers > 100) {
-#else
         if (l == 0) {
-#endif
             gemm_seg1<LDEH, EK / 16, NB, RM>(acc, E1, A.wfrag[0], blk0, 8, lane);
-#ifdef GS_H1_XG
-        } else if (A.n_layers > 100) {
-#else
         } else {
-#endif
             gemm_seg1<LDH, D / 16, NB, RM>(acc, H1, A.wfrag[l], blk0, 8, lane, GS_H1_PRE ? &wpre : nullptr);
             if (l == A.skip_layer) gemm_seg1<LDEH, EK / 16, NB, RM>(acc, E1, A.wfrag[l] + (D / 16) * 1024, blk0, 8, lane);
         }
         // the next layer's first weight fragments: requested here, they land while the activation function runs (each layer's GEMM
         // otherwise opens with an exposed L2 round trip)
         if (GS_H1_PRE && !last) h1_preload<NB>(wpre, A.wfrag[l + 1], blk0, 8, lane);
-#ifndef GS_H1_XB      // experiment (WRONG results): no barriers inside the layer loop
         __syncthreads();     // every wave is done reading the plane: it is overwritten in place
-#endif
         f2 part[RM];
 #pragma unroll
         for (int r = 0; r < RM; ++r) part[r] = f2{0.f, 0.f};
@@ -712,12 +698,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? GS_H1_WAVES : GS_H1_WAVES4)
                 const f2 wj[2] = {f2{bnext[q][g].x, bnext[q][g].y}, f2{bnext[q][g].z, bnext[q][g].w}};       // (last layer: the output weights)
 #pragma unroll
                 for (int r = 0; r < RM; ++r) {
-#ifdef GS_H1_XE      // experiment (WRONG results): no activation function -> the GEMM phases alone
-                    const f2 v0 = f2{acc[q][r][4 * g], acc[q][r][4 * g + 1]}, v1 = f2{acc[q][r][4 * g + 2], acc[q][r][4 * g + 3]};
-#else
                     const f2 v0 = softplus100_pair_poly(f2{acc[q][r][4 * g], acc[q][r][4 * g + 1]});
                     const f2 v1 = softplus100_pair_poly(f2{acc[q][r][4 * g + 2], acc[q][r][4 * g + 3]});
-#endif
                     if (last) {
                         part[r] = part[r] + v0 * wj[0] + v1 * wj[1];
                     } else {
@@ -736,9 +718,6 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? GS_H1_WAVES : GS_H1_WAVES4)
                 if (lane < 32) red[wave * TMT + 32 * r + lane] = p;
             }
         }
-#ifdef GS_H1_XB
-        if (last)
-#endif
         __syncthreads();
     }
     if (tid < TMT) {
