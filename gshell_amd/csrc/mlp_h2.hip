@@ -1680,7 +1680,11 @@ extern "C" int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, cons
         W.db[l] = db[l];
     }
     const int64_t nslabs = W.Rpad / WS;
-    int strips = (int)std::min<int64_t>(nslabs, 40);           // ~ (CUs / layers): every CU owns one (strip, layer) pair
+#ifndef GS_WG_STRIPS
+#define GS_WG_STRIPS 80      // row strips per layer (x 7 layers = workgroups, one per CU at a time: 92 KB of LDS).  Measured per iteration (both passes):
+                            // 36: 1.33, 40: 1.47, 60: 1.26, 80: 1.23, 120: 1.28 ms -- the strips' final atomics are free (no change when removed)
+#endif
+    int strips = (int)std::min<int64_t>(nslabs, GS_WG_STRIPS);
     W.slabs_per_strip = (int)gs::cdiv(nslabs, strips);
     strips = (int)gs::cdiv(nslabs, W.slabs_per_strip);
     GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_WGRAD_BYTES));
