@@ -149,6 +149,41 @@ def rasterize_ids(pos, tri, H, W):
     return ids
 
 
+_C_LIB = None
+
+
+def _c_lib():
+    """oracle/_c/raster_c.so: the C restatement of `rasterize_ids` (oracle/raster_c.c, built by oracle/Makefile)."""
+    global _C_LIB
+    if _C_LIB is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_c", "raster_c.so")
+        if not os.path.isfile(path):
+            raise RuntimeError(f"{path} is missing: run `make -C oracle` (or __graft_entry__.build())")
+        L = ctypes.CDLL(path)
+        L.ro_rasterize_ids.restype = ctypes.c_int
+        L.ro_rasterize_ids.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        _C_LIB = L
+    return _C_LIB
+
+
+def rasterize_ids_c(pos, tri, H, W):
+    """`rasterize_ids` evaluated by oracle/raster_c.c -- the same statements in C (float32, no contraction), pinned to the python
+    loop above bit for bit by tests/test_raster_oracle.py; this is what the config-size parity tests use (10^5+ triangles at 512^2)."""
+    pos = np.ascontiguousarray(pos, dtype=f32)
+    tri = np.ascontiguousarray(tri, dtype=np.int32).reshape(-1, 3)
+    B, V = pos.shape[0], pos.shape[1]
+    assert tri.size == 0 or (tri.min() >= 0 and tri.max() < V)
+    ids = np.empty((B, H, W), np.int64)
+    zbuf = np.empty((B, H, W), np.uint64)
+    fix = np.empty((max(V, 1), 3), np.int64)
+    rc = _c_lib().ro_rasterize_ids(pos.ctypes.data, B, V, tri.ctypes.data, tri.shape[0], H, W, ids.ctypes.data, zbuf.ctypes.data, fix.ctypes.data)
+    assert rc == 0
+    return ids
+
+
 def rast_from_ids(pos, tri, ids):
     """Differentiable (torch) rast / rast_db given the integer winners.
     pos [B,V,4] float tensor, tri [T,3] long, ids [B,H,W] long (-1 empty) -> rast [B,H,W,4], rast_db [B,H,W,4]."""
@@ -228,6 +263,29 @@ def tri_adjacency(tri):
             (t0, e0), (t1, e1) = members
             opp[t0, e0] = tri[t1, e1]
             opp[t1, e1] = tri[t0, e0]
+    return opp
+
+
+def tri_adjacency_sorted(tri):
+    """`tri_adjacency` without the python dictionary: half-edges sorted by their (min, max) vertex pair; an edge is manifold when its
+    key occurs exactly twice.  Pinned to `tri_adjacency` by tests/test_raster_oracle.py."""
+    tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
+    T = tri.shape[0]
+    opp = np.full((T, 3), -1, dtype=np.int64)
+    if T == 0:
+        return opp
+    a, b = tri[:, [1, 2, 0]].reshape(-1), tri[:, [2, 0, 1]].reshape(-1)          # edge e = (v[e+1], v[e+2]), opposite vertex e
+    key = np.minimum(a, b) * (tri.max() + 1) + np.maximum(a, b)
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    first = np.r_[True, ks[1:] != ks[:-1]]
+    start = np.flatnonzero(first)
+    count = np.diff(np.r_[start, ks.size])
+    two = start[count == 2]
+    h0, h1 = order[two], order[two + 1]
+    flat_tri = tri.reshape(-1)
+    opp.reshape(-1)[h0] = flat_tri[h1]
+    opp.reshape(-1)[h1] = flat_tri[h0]
     return opp
 
 

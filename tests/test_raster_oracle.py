@@ -156,3 +156,53 @@ def test_near_plane_clipping_known_answer():
     # the near plane (z_eye = -0.1) hides everything between the cut and the eye in both renderings -> identical coverage
     assert (cov != cov_cut).sum() <= 2, int((cov != cov_cut).sum())
     assert cov[:24].sum() == 0 or cov[24:].sum() == 0            # the floor occupies one half of the image only
+
+
+# ---- the C restatement (oracle/raster_c.c) and the sorted adjacency are pinned to the python loops above ------------------------------------
+
+def _pin_scenes():
+    """(name, clip-space positions [B,V,4], triangles) -- small enough for the python loop, chosen to reach every branch of it:
+    micro triangles, screen-filling triangles, depth ties, degenerate / zero-area triangles, vertices behind the eye (near-clip
+    path), vertices far outside the 2^24 fixed-point range, NaN positions, an empty mesh."""
+    out = []
+    for kind, seed, first, radius in (("soup", 1, 0, 3.0), ("sheet", 2, 3, 3.0), ("sheet", 5, 1, 0.45), ("soup", 7, 2, 0.7)):
+        verts, tri = scenes.random_soup(300, seed) if kind == "soup" else scenes.grid_sheet(12, seed)
+        mvp, _ = scenes.orbit_views(2, radius=radius, first=first)
+        out.append((f"{kind}-r{radius}", ro.xfm_points(torch.tensor(verts)[None], torch.tensor(mvp)).numpy(), tri))
+    # two screen-filling quads at the SAME depth (ties -> lower id), one degenerate triangle, one zero-area triangle
+    v = np.array([[-4, -4, -0.6], [4, -4, -0.6], [4, 4, -0.6], [-4, 4, -0.6], [0, 0, 0], [0.1, 0.1, 0]], np.float32)
+    tri = np.array([[0, 1, 2], [0, 2, 3], [0, 1, 2], [4, 4, 5], [4, 5, 4], [1, 0, 2]], np.int32)
+    mvp, _ = scenes.orbit_views(2, first=4)
+    out.append(("ties", ro.xfm_points(torch.tensor(v)[None], torch.tensor(mvp)).numpy(), tri))
+    pos = out[1][1].copy()
+    pos[0, 5, 0] = 3e9
+    pos[0, 17, 3] = 1e-9
+    pos[1, 40, 1] = np.nan
+    pos[1, 41, 3] = -0.3
+    out.append(("overflow-nan", pos, out[1][2]))
+    out.append(("empty", np.zeros((1, 3, 4), np.float32), np.zeros((0, 3), np.int32)))
+    return out
+
+
+def test_c_restatement_equals_the_python_rasteriser_bit_for_bit():
+    fired = dict(near_clip=0, covered=0)
+    for name, pos, tri in _pin_scenes():
+        for (H, W) in ((40, 56), (64, 64)):
+            a = ro.rasterize_ids(pos, tri, H, W)
+            b = ro.rasterize_ids_c(pos, tri, H, W)
+            np.testing.assert_array_equal(a, b, err_msg=name)
+            fired["covered"] += int((a >= 0).sum())
+        if tri.shape[0]:
+            front = pos[:, tri.reshape(-1), 3].reshape(pos.shape[0], -1, 3) > 1e-6
+            fired["near_clip"] += int((front.any(-1) & ~front.all(-1)).sum())
+    assert fired["near_clip"] > 20 and fired["covered"] > 10000, fired
+
+
+def test_sorted_adjacency_equals_the_dictionary_version():
+    for kind, seed in (("soup", 1), ("sheet", 2)):
+        verts, tri = scenes.random_soup(200, seed) if kind == "soup" else scenes.grid_sheet(9, seed)
+        np.testing.assert_array_equal(ro.tri_adjacency_sorted(tri), ro.tri_adjacency(tri))
+    # non-manifold edge (three triangles on one edge) and a duplicated triangle: neither is "exactly two"
+    tri = np.array([[0, 1, 2], [1, 0, 3], [0, 1, 4], [5, 6, 7], [5, 6, 7], [7, 8, 5]], np.int64)
+    np.testing.assert_array_equal(ro.tri_adjacency_sorted(tri), ro.tri_adjacency(tri))
+    assert ro.tri_adjacency_sorted(np.zeros((0, 3), np.int64)).shape == (0, 3)
