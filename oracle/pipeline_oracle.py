@@ -57,7 +57,7 @@ def render_mesh(v_pos, faces, v_nrm, msdf, mvp, campos, light, background, noise
     tri_np = faces.numpy().astype(np.int32)
     v_pos_clip = ro.xfm_points(v_pos[None], mvp)
     # discrete decisions (coverage, sample placement) are always made from float32 values, whatever dtype the floats run in
-    ids = torch.tensor(ro.rasterize_ids(ro.xfm_points(v_pos.detach().float()[None], mvp.float()).numpy(), tri_np, H, W))
+    ids = torch.tensor(ro.rasterize_ids_c(ro.xfm_points(v_pos.detach().float()[None], mvp.float()).numpy(), tri_np, H, W))     # oracle/raster_c.c
     rast, rast_db = ro.rast_from_ids(v_pos_clip, faces, ids)
     visible = torch.unique(ids[ids >= 0])
     gb_pos = ro.interpolate(v_pos[None], rast, faces)
@@ -107,7 +107,7 @@ def render_mesh(v_pos, faces, v_nrm, msdf, mvp, campos, light, background, noise
     if msdf is not None:
         buffers['msdf_image'] = ro.interpolate(msdf.reshape(1, -1, 1), rast, faces)
     bg4 = torch.cat((background, torch.zeros_like(background[..., 0:1])), -1)
-    opp = torch.as_tensor(ro.tri_adjacency(tri_np)) if faces.shape[0] else None
+    opp = torch.as_tensor(ro.tri_adjacency_sorted(tri_np)) if faces.shape[0] else None
     aa_alpha = ro.aa_alpha(rast.detach(), v_pos_clip, faces, opp) if faces.shape[0] else None
     out = {'visible_triangles': visible}
     for key, buf in buffers.items():
