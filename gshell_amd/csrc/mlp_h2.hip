@@ -73,7 +73,7 @@ enum { MODE_GRID = 0, MODE_ROWS = 1, MODE_EIK = 2, MODE_FIX = 3 };
 // status words of the forward kernels (device, zeroed by the caller): [0] != 0: a non-finite value left the network (an activation
 // or weight beyond the fp16 range -- the caller re-runs the exact-fp32 kernel); [1]: bits of max |three-product - one-product| over
 // the rows the second pass recomputed (the a-posteriori check of the one-product pass's error bound)
-enum { ST_NONFINITE = 0, ST_MAXDEV = 1 };
+enum { ST_NONFINITE = 0, ST_MAXDEV = 1, ST_MAXREL = 2 };
 
 struct H2Args {
     const float* x;       // [N,3] points
@@ -92,6 +92,7 @@ struct H2Args {
     const h8* wfrag[MAX_LAYERS];    // fragment-major weights: [k-step][wave 8][piece 2][lane 64] x 16 B
     const float* bias[MAX_LAYERS];  // [256] fp32
     const float* w_out;             // [256] fp32 followed by the output bias
+    float tau;                      // MODE_FIX: > 0 = also record status[ST_MAXREL] = max |new - old| / max(tau, |new|)  (status then has 3 words)
 };
 
 __device__ __forceinline__ void split_h2(float v, _Float16& hi, _Float16& lo) {
@@ -435,17 +436,23 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
             if (A.status && __ballot(r < A.N && !(fabsf(s) < 3.0e38f)) != 0ull && tid == 0) atomicOr(&A.status[ST_NONFINITE], 1u);
         } else if (MODE == MODE_FIX) {
             s += A.w_out[D];
-            float dev = 0.f;
+            float dev = 0.f, rel = 0.f;
             if (r < n_act) {
                 const int64_t g = A.rows[r];
                 const float old = A.out[g];
                 dev = fabsf(s - old);
+                // the one-product value decides a SIGN correctly iff its error is below |value|; below tau the row is re-evaluated anyway,
+                // so the margin that matters is max(tau, |value|): rows far from the surface (the audit sample) may be off by more than tau
+                rel = dev / fmaxf(A.tau, fabsf(s));
                 A.out[g] = s;
                 if (A.occ && ((s > 0.0f) != (old > 0.0f))) atomicXor((unsigned long long*)&A.occ[g >> 6], 1ull << (g & 63));
-                if (!(fabsf(s) < 3.0e38f)) { dev = 0.f; if (A.status) atomicOr(&A.status[ST_NONFINITE], 1u); }
+                if (!(fabsf(s) < 3.0e38f)) { dev = 0.f; rel = 0.f; if (A.status) atomicOr(&A.status[ST_NONFINITE], 1u); }
             }
-            for (int o = 32; o > 0; o >>= 1) dev = fmaxf(dev, __shfl_xor(dev, o, 64));
-            if (A.status && tid == 0 && dev > 0.f) atomicMax(&A.status[ST_MAXDEV], __float_as_uint(dev));
+            for (int o = 32; o > 0; o >>= 1) { dev = fmaxf(dev, __shfl_xor(dev, o, 64)); rel = fmaxf(rel, __shfl_xor(rel, o, 64)); }
+            if (A.status && tid == 0 && dev > 0.f) {
+                atomicMax(&A.status[ST_MAXDEV], __float_as_uint(dev));
+                if (A.tau > 0.f) atomicMax(&A.status[ST_MAXREL], __float_as_uint(rel));
+            }
         } else {
             A.out[r] = s;                                    // virtual rows: value rows lack b_out (unused), tangent rows = df/dx_d
         }
@@ -1579,14 +1586,15 @@ extern "C" int gs_sdf_mlp_fwd_h1(const float* x, int64_t N, const void* packed, 
 
 // Second pass: rows[0 .. min(*count_dev, cap)) of x are recomputed with the three-product arithmetic of gs_sdf_mlp_fwd_h2 (bit
 // identical values: a row's arithmetic does not depend on its tile), written over out[rows[r]]; the rows' sign bits in occ_bits
-// are corrected; status[ST_MAXDEV] = bits of max |new - old| over the rows (atomicMax: zero it first).
+// are corrected; status[ST_MAXDEV] = bits of max |new - old| over the rows (atomicMax: zero it first); tau > 0: status has a third
+// word, status[ST_MAXREL] = bits of max |new - old| / max(tau, |new|) -- the fraction of its sign margin a row's first-pass error used up.
 extern "C" int gs_sdf_mlp_h2_refine_rows(const float* x, const int32_t* rows, int64_t cap, const int64_t* count_dev, const void* packed, int n_freq,
-                                         int n_hidden, int skip_layer, float* out, uint64_t* occ_bits, uint32_t* status, gs_stream_t stream) {
+                                         int n_hidden, int skip_layer, float* out, uint64_t* occ_bits, uint32_t* status, float tau, gs_stream_t stream) {
     if (cap == 0) return 0;
     GS_REQUIRE(x && rows && packed && out, "gs_sdf_mlp_h2_refine_rows: null pointer");
     if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
     H2Args A{};
-    A.x = x; A.rows = rows; A.out = out; A.occ = occ_bits; A.status = status; A.N = cap; A.n_dev = count_dev; A.n_freq = n_freq;
+    A.x = x; A.rows = rows; A.out = out; A.occ = occ_bits; A.status = status; A.N = cap; A.n_dev = count_dev; A.n_freq = n_freq; A.tau = tau;
     fill_fwd_args(A, packed, make_layout(n_freq, n_hidden, skip_layer));
     return launch_fwd<MODE_FIX>(A, gs::cdiv(cap, TM), (hipStream_t)stream);
 }

@@ -278,14 +278,16 @@ class GShellTetsGeometry(torch.nn.Module):
             warnings.warn("SDF network: fp16-pair arithmetic overflowed; switching this network to torch fp32 ops")
             self.sdf_net._gs_precision = "torch"
         else:
-            warnings.warn(f"SDF network: one-product pass off by {self.sdf_net.__dict__.get('_gs_two_pass_maxdev'):.3e} on the refined rows "
-                          "(more than tau / 4): this network is evaluated in one pass from now on")
+            warnings.warn(f"SDF network: the one-product pass used up {self.sdf_net.__dict__.get('_gs_two_pass_margin_used'):.3f} of the sign margin of a "
+                          f"re-evaluated row (max deviation {self.sdf_net.__dict__.get('_gs_two_pass_maxdev'):.3e}; refined rows + audit sample of all "
+                          "rows), more than 1 / 4: this network is evaluated in one pass from now on")
             self.sdf_net._gs_one_pass = True
 
     def getMesh(self, material):
         v_deformed = self.verts + self.max_displacement * self.deform
         # SDF of every grid vertex; backward only through the rows that receive gradient (see geometry/mlp.py)
-        sdf = self._sdf_values(v_deformed)
+        v_grid = v_deformed                       # the network's input (before the offset): a re-evaluation must see the identical tensor
+        sdf = self._sdf_values(v_grid)
         msdf = self.msdf
         v_deformed = v_deformed + self.offset
         verts, faces, uvs, uv_idx, v_tng, extra = self.gshell_tets(v_deformed, sdf, msdf, self.indices)
@@ -296,7 +298,7 @@ class GShellTetsGeometry(torch.nn.Module):
                 # an activation or weight beyond the fp16 range, or a one-product pass that is off by too much: from now on this network is
                 # evaluated by plain torch fp32 ops (counted in mlp.FALLBACKS) / in one pass
                 self._recover_forward(todo)
-                sdf = self._sdf_values(v_deformed - self.offset)
+                sdf = self._sdf_values(v_grid)
                 verts, faces, uvs, uv_idx, v_tng, extra = self.gshell_tets(v_deformed, sdf, msdf, self.indices)
                 check_forward_status(self.sdf_net)
         if self.FLAGS.use_sdf_mlp and getattr(self.FLAGS, "sync_free_rows", False):

@@ -235,6 +235,13 @@ SDF_MLP_WGRAD_FP32 = False
 SDF_TWO_PASS = True
 SDF_TWO_PASS_TAU = 2e-3
 SDF_TWO_PASS_SAFETY = 4.0
+# AUDIT of the rows the second pass would NOT touch: the proof needs "first-pass error < |sdf|" at every
+# UNREFINED row, and the refined rows are by construction the near-surface ones.  Every call therefore also re-evaluates a rotating
+# sample of ALL rows -- every k-th row, k = N / SDF_TWO_PASS_AUDIT_ROWS, another residue class each call, so that every row of the grid
+# is audited once per k calls -- and the kernel records, beside max |new - old|, the largest FRACTION OF ITS SIGN MARGIN any re-evaluated
+# row used up: |new - old| / max(tau, |new|).  check_forward_status demands fraction * safety <= 1 (for near-surface rows that is the old
+# rule max |dev| * safety <= tau).  Cost: ~16 k rows beside the ~90 k of the bench grid, +0.04 ms.  0 = no audit.
+SDF_TWO_PASS_AUDIT_ROWS = 16384
 
 
 def _layer_structure(net):
@@ -271,8 +278,8 @@ class ForwardStatus:
     """Device status words of one fused forward call + their asynchronous copy in pinned host memory."""
 
     def __init__(self, device, tau=None):
-        self.dev = torch.zeros(2, dtype=torch.int32, device=device)
-        self.host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        self.dev = torch.zeros(3, dtype=torch.int32, device=device)        # csrc/mlp_h2.hip ST_NONFINITE, ST_MAXDEV, ST_MAXREL
+        self.host = torch.empty(3, dtype=torch.int32, pin_memory=True)
         self.event = None
         self.tau = tau
         self.n_rows = None          # device int64 [2]: rows the second pass recomputed
@@ -283,14 +290,15 @@ class ForwardStatus:
         self.event.record()
 
     def result(self, wait=True):
-        """-> (non-finite flag, max |three-product - one-product| on the refined rows) or None if not ready and wait=False"""
+        """-> (non-finite flag, max |three-product - one-product| on the re-evaluated rows, the largest fraction of its sign margin
+        max(tau, |sdf|) such a row's first-pass error used up) or None if not ready and wait=False"""
         if self.event is None:
             self.fetch()
         if not self.event.query():
             if not wait:
                 return None
             self.event.synchronize()
-        return bool(self.host[0].item()), float(self.host[1:2].view(torch.float32).item())
+        return bool(self.host[0].item()), float(self.host[1:2].view(torch.float32).item()), float(self.host[2:3].view(torch.float32).item())
 
 
 def check_forward_status(net, wait=True):
@@ -306,14 +314,14 @@ def check_forward_status(net, wait=True):
     if r is None:
         return None
     net.__dict__["_gs_fwd_status"] = None
-    nonfinite, maxdev = r
+    nonfinite, maxdev, maxrel = r
     if nonfinite:
         return "fp32"
-    if st.tau is not None and maxdev * SDF_TWO_PASS_SAFETY > st.tau:
-        net.__dict__["_gs_two_pass_maxdev"] = maxdev
-        return "one_pass"
     if st.tau is not None:
         net.__dict__["_gs_two_pass_maxdev"] = maxdev
+        net.__dict__["_gs_two_pass_margin_used"] = maxrel        # over the refined rows AND the audit sample of unrefined rows
+        if maxrel * SDF_TWO_PASS_SAFETY > 1.0:
+            return "one_pass"
     return None
 
 
@@ -357,12 +365,18 @@ def fused_forward(net, x, precision=None, occ_bits_ptr=None, refine_topo=None, d
                                                       _lib.c_float(st.tau), ptr(flags), stream()), "gs_flag_refine_rows_edges")
                 else:
                     check(L.gs_mtets_flag_refine_rows(refine_topo.handle, ptr(out), _lib.c_float(st.tau), ptr(flags), stream()), "gs_mtets_flag_refine_rows")
+                if SDF_TWO_PASS_AUDIT_ROWS > 0:
+                    # the audit sample: one residue class of the row index, rotating with the calls (plain strided fill: one launch)
+                    k = max(1, N // SDF_TWO_PASS_AUDIT_ROWS)
+                    phase = net.__dict__.get("_gs_audit_phase", 0)
+                    net.__dict__["_gs_audit_phase"] = phase + 1
+                    flags[(phase * 7919) % k::k] = 1.0
                 rows = torch.empty(N, dtype=torch.int32, device=xc.device)
                 st.n_rows = torch.empty(2, dtype=torch.int64, device=xc.device)
                 scratch = torch.empty(int(L.gs_compact_rows_scratch_bytes(c_int64(N))) // 4 + 4, dtype=torch.int32, device=xc.device)
                 check(L.gs_compact_rows(ptr(flags), c_int64(N), c_int64(N), ptr(scratch), ptr(rows), _lib.c_void_p(0), ptr(st.n_rows), stream()), "gs_compact_rows")
                 check(L.gs_sdf_mlp_h2_refine_rows(ptr(xc), ptr(rows), c_int64(N), ptr(st.n_rows), ptr(packed), c_int(nf), c_int(n_hidden), c_int(skip),
-                                                  ptr(out), occ, ptr(st.dev), stream()), "gs_sdf_mlp_h2_refine_rows")
+                                                  ptr(out), occ, ptr(st.dev), _lib.c_float(st.tau), stream()), "gs_sdf_mlp_h2_refine_rows")
         st.fetch()
         net.__dict__["_gs_fwd_status"] = st
         if not defer_status:
@@ -371,8 +385,9 @@ def fused_forward(net, x, precision=None, occ_bits_ptr=None, refine_topo=None, d
                 raise _lib.GShellHipError("SDF network: a value beyond the fp16 range (activation >= 65 504 or |weight| > 60 000) overflowed the "
                                           "fp16-pair arithmetic; evaluate with precision='fp32' (gs_sdf_mlp_fwd)")
             if todo == "one_pass":
-                raise _lib.GShellHipError(f"SDF network, two-pass forward: the one-product pass is off by {net.__dict__.get('_gs_two_pass_maxdev')} on the refined "
-                                          f"rows, more than tau / {SDF_TWO_PASS_SAFETY} = {st.tau / SDF_TWO_PASS_SAFETY}; raise SDF_TWO_PASS_TAU or evaluate in one pass")
+                raise _lib.GShellHipError(f"SDF network, two-pass forward: the one-product pass used up {net.__dict__.get('_gs_two_pass_margin_used'):.3f} of a row's "
+                                          f"sign margin max(tau, |sdf|) (max deviation {net.__dict__.get('_gs_two_pass_maxdev')}, tau {st.tau}); more than 1 / "
+                                          f"{SDF_TWO_PASS_SAFETY}: raise SDF_TWO_PASS_TAU or evaluate in one pass")
         return out[:, None]
     if precision != "fp32":
         raise ValueError(f"unknown SDF-MLP precision {precision!r} (h2 | fp32)")

@@ -656,7 +656,10 @@ int gs_sdf_mlp_h2_pack(const float* const* weights, const float* const* biases, 
  *   [0] != 0  a non-finite signed distance left the network, or a weight lies beyond the fp16 range: the fp16-pair arithmetic
  *             has overflowed (activations >= 65 504 become inf in the split) -- the caller must fall back to gs_sdf_mlp_fwd
  *             (exact fp32; reference geometry/mlp.py:32-40 has no range limit);
- *   [1]       bits of max |three-product value - one-product value| over the rows of gs_sdf_mlp_h2_refine_rows. */
+ *   [1]       bits of max |three-product value - one-product value| over the rows of gs_sdf_mlp_h2_refine_rows;
+ *   [2]       (gs_sdf_mlp_h2_refine_rows with tau > 0 only: the array then has THREE words) bits of
+ *             max |new - old| / max(tau, |new|): the largest fraction of its sign margin that the first pass's error used up on
+ *             any re-evaluated row -- near-surface rows (margin tau) and the audit sample of far rows (margin |sdf|) alike. */
 int gs_sdf_mlp_fwd_h2(const float* x, int64_t N, const void* packed, int n_freq, int n_hidden,
                       int skip_layer, float* out, uint64_t* occ_bits /* [ceil(N/64)] sign bits WRITTEN, or NULL */,
                       uint32_t* status, gs_stream_t stream);
@@ -667,13 +670,17 @@ int gs_sdf_mlp_fwd_h2(const float* x, int64_t N, const void* packed, int n_freq,
  *   3. gs_sdf_mlp_h2_refine_rows: those rows again with the three-product arithmetic of gs_sdf_mlp_fwd_h2 -- bit-identical
  *      values (a row's arithmetic does not depend on its tile) --, written over out, sign bits corrected, status[1] =
  *      max |new - old| (the measured error of pass 1 on the rows that matter; the caller checks it against tau).
+ *      AUDIT: the caller also flags a rotating pseudo-random sample of ALL rows (every k-th row, another residue class each call), so
+ *      rows that were NOT selected are measured too: status[2] (see above) must stay below 1 / safety for the proof's hypothesis
+ *      "error below the sign margin at every row" to be an observed fact on the unrefined rows as well, not an extrapolation.
  *   If the pass-1 error is below tau at every vertex, the result equals gs_sdf_mlp_fwd_h2's in every sign and at both end
  *   points of every sign-crossing edge -- all the reference consumes (gshell_tets.py:250, :277-290; gshell_tets_geometry.py:33-39). */
 int gs_sdf_mlp_fwd_h1(const float* x, int64_t N, const void* packed, int n_freq, int n_hidden,
                       int skip_layer, float* out, uint64_t* occ_bits, uint32_t* status, gs_stream_t stream);
 int gs_sdf_mlp_h2_refine_rows(const float* x, const int32_t* rows, int64_t cap, const int64_t* count_dev,
                               const void* packed, int n_freq, int n_hidden, int skip_layer, float* out,
-                              uint64_t* occ_bits, uint32_t* status, gs_stream_t stream);
+                              uint64_t* occ_bits, uint32_t* status /* [2], or [3] when tau > 0 */, float tau,
+                              gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * SDF network, gradients   (replaces autograd through geometry/mlp.py:32-40 as used by

@@ -46,7 +46,7 @@ def compare(net, verts, topo, tau):
         y2 = fused_forward(net, verts, "h2", occ_bits_ptr=topo.occ_bits_ptr(), refine_topo=topo, defer_status=True)[:, 0]
         st = net.__dict__["_gs_fwd_status"]
         occ2 = occ_words(topo)
-        nonfinite, maxdev = st.result()
+        nonfinite, maxdev, margin_used = st.result()
         n_ref = int(st.n_rows[0])
         e = topo.edges().long()
         cross = (y1[e[:, 0]] > 0) != (y1[e[:, 1]] > 0)
@@ -56,6 +56,10 @@ def compare(net, verts, topo, tau):
         "rows": int(verts.shape[0]), "tau": tau, "refined_rows": n_ref, "refined_fraction": n_ref / verts.shape[0],
         "crossing_edges": int(cross.sum()), "crossing_edge_end_points": int(ends.numel()),
         "max_abs_dev_one_product_on_refined_rows": maxdev, "nonfinite": nonfinite,
+        # fraction of its sign margin max(tau, |sdf|) the first pass's error used up: as MEASURED by the kernel on the refined rows + the audit
+        # sample, and the TRUTH over every row the second pass left alone (y2 = first-pass value there, y1 = the one-pass kernel's)
+        "margin_used_measured": margin_used,
+        "margin_used_all_unrefined_rows": float(((y1 - y2).abs() / torch.clamp(y1.abs(), min=tau)).max()),
         "sign_disagreements": int(((y1 > 0) != (y2 > 0)).sum()), "occupancy_words_equal": bool(torch.equal(occ1, occ2)),
         "sign_bits_match_values": bool(torch.equal(bits, y2 > 0)),
         "end_point_values_bit_identical": bool(torch.equal(y1[ends], y2[ends])),
