@@ -35,7 +35,7 @@ def test_goldens_are_what_the_reference_build_produces():
             np.testing.assert_array_equal(np.asarray(v), g[k], err_msg=f"{name}:{k}")
 
 
-@pytest.mark.parametrize("bsdf,n,suffix", [(b, n, "") for b, n in mg.ENVSHADE_CASES] + [("pbr", 8, "_64x64")])
+@pytest.mark.parametrize("bsdf,n,suffix", [(b, n, "") for b, n in mg.ENVSHADE_CASES] + [("pbr", 8, "_64x64"), ("pbr", 4, "_occluder")])
 def test_env_shade_restatement_equals_the_reference_kernel(bsdf, n, suffix):
     """oracle/shade_oracle.env_shade (numpy sampling + torch autograd) vs kernel.cu compiled for the host: EVERY pixel of the
     forward outputs and of the five gradients within 1e-4 of the tensor's maximum.  The two sides share libm / numpy float

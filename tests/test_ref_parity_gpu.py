@@ -48,6 +48,24 @@ def test_env_shade_equals_the_reference_kernel_at_64x64_n8():
     _compare_env_shade(_load("ref_envshade_pbr_n8_64x64.npz"), "pbr_n8_64x64")
 
 
+def test_env_shade_equals_the_reference_kernel_under_an_occluder():
+    """Half of the covered pixels lie under a plate: most of their shadow rays HIT (the sheet scenes above occlude almost nothing, so
+    `shadow_ray: 0` there says little).  The per-sample visibility of every live sample must equal the reference's any-hit."""
+    g = _load("ref_envshade_pbr_n4_occluder.npz")
+    vis = g["samples"][..., 5] > 0
+    x = g["gb_pos"].reshape(-1, 3)[np.flatnonzero(g["mask"].reshape(-1) > 0)][:, 0]
+    assert vis[x < 0].mean() < 0.4 < 0.55 < vis[x > 0].mean()              # the golden itself: the covered half is mostly in shadow
+    _compare_env_shade(g, "pbr_n4_occluder")
+    assert REPORT["pbr_n4_occluder"]["occluded_live_samples"] > 5000
+
+
+# flagged samples per golden, measured on MI355X (profiles/r03_ref_parity_envshade.json, r04_*): decision flips = a sample placed in another
+# CDF cell / lobe / stratum, another pdf branch, another shadow-ray outcome, another probe texel; border = the REFERENCE's direction lies
+# within 2e-4 texels of a probe-texel border (a property of the golden, flagged conservatively: none has moved an output so far).
+MEASURED_FLAGS = {"pbr_n1": (0, 0), "pbr_n4": (0, 2), "pbr_n8": (0, 3), "diffuse_n1": (0, 0), "diffuse_n4": (0, 4), "diffuse_n8": (0, 4),
+                  "white_n1": (0, 0), "white_n4": (0, 1), "white_n8": (0, 6), "pbr_n8_64x64": (25, 27), "pbr_n4_occluder": (2, 5)}
+
+
 def _compare_env_shade(g, tag):
     from gshell_amd.render import optixutils as ou
     bsdf, n = BSDFS[int(g["bsdf"])], int(g["n"])
@@ -77,11 +95,16 @@ def _compare_env_shade(g, tag):
     vis_off = ~moved & live & (vis != r_vis)                                # same direction (to 1e-4), the shadow ray decided differently
     tex_r, border = _texel(r_dir, Hl, Wl)
     tex_h, _ = _texel(dirs, Hl, Wl)
-    tex_off = ~moved & ((tex_r != tex_h) | (border < 2e-4))                 # the radiance fetch may land in the neighbouring probe texel
+    tex_flip = ~moved & (tex_r != tex_h)                                    # the radiance fetch landed in the neighbouring probe texel
+    tex_near = ~moved & ~tex_flip & (border < 2e-4)                         # ... or could have: the reference's own direction sits on a border
+    tex_off = tex_flip | tex_near
     flagged = moved | k_off | vis_off | tex_off
     pix_flag = flagged.reshape(len(pix), -1).any(-1)
     n_samples = flagged.size
-    causes = dict(sample_moved=int(moved.sum()), pdf_branch_or_texel=int(k_off.sum()), shadow_ray=int(vis_off.sum()), probe_texel_border=int(tex_off.sum()))
+    causes = dict(sample_moved=int(moved.sum()), pdf_branch_or_texel=int(k_off.sum()), shadow_ray=int(vis_off.sum()), probe_texel_flip=int(tex_flip.sum()),
+                  probe_texel_border=int(tex_near.sum()))
+    n_flip = int((moved | k_off | vis_off | tex_flip).sum())
+    n_border = int((tex_near & ~(k_off | vis_off)).sum())
 
     # ---- clean pixels: strict ------------------------------------------------------------------------------------------
     clean = np.zeros(B * H * W, bool)
@@ -120,16 +143,22 @@ def _compare_env_shade(g, tag):
     frac = float(flagged.sum()) / n_samples
     listing = []
     for (kk, w, i) in np.argwhere(flagged)[:200]:
-        cause = "sample_moved" if moved[kk, w, i] else "pdf_branch_or_texel" if k_off[kk, w, i] else "shadow_ray" if vis_off[kk, w, i] else "probe_texel_border"
+        cause = ("sample_moved" if moved[kk, w, i] else "pdf_branch_or_texel" if k_off[kk, w, i] else "shadow_ray" if vis_off[kk, w, i] else
+                 "probe_texel_flip" if tex_flip[kk, w, i] else "probe_texel_border")
         listing.append(dict(pixel=int(pix[kk]), kind="light" if w == 0 else "bsdf", sample=int(i), cause=cause, dir_diff=float(dd[kk, w, i]),
                             k=float(k[kk, w, i]), k_ref=float(r_k[kk, w, i]), border_texels=float(border[kk, w, i])))
     REPORT[tag] = dict(covered_pixels=int(len(pix)), samples=int(n_samples), flagged_samples=int(flagged.sum()), flagged_fraction=frac,
+                                  decision_flips=n_flip, border_flags=n_border, live_samples=int(live.sum()), occluded_live_samples=int((live & ~r_vis).sum()),
                                   pixels_with_flagged_sample=int(pix_flag.sum()), causes=causes, pixels_outside_tolerance=outside, flagged=listing)
     print(f"{bsdf} n={n}: {len(pix)} px, {n_samples} samples, flagged {int(flagged.sum())} ({frac:.2e}) {causes}; outside tol (all in flagged px): {outside}")
-    assert frac <= 5e-3, (frac, causes)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/ref_parity_envshade.json", "w") as f:
         json.dump(REPORT, f, indent=1)
+    # caps = 2 x what was measured for this golden; a golden measured at zero decision flips may show ONE
+    # (a last-ulp difference of sin / cos / atan2 / acos between two ROCm releases), never more
+    m_flip, m_border = MEASURED_FLAGS[tag]
+    assert n_flip <= max(2 * m_flip, 1), (tag, n_flip, causes)
+    assert n_border <= 2 * m_border + (1 if m_border == 0 else 0), (tag, n_border, causes)
 
 
 @pytest.mark.parametrize("loss", ["l1", "mse", "smape", "relmse"])
