@@ -56,7 +56,8 @@ def test_env_shade_equals_the_reference_kernel_under_an_occluder():
     x = g["gb_pos"].reshape(-1, 3)[np.flatnonzero(g["mask"].reshape(-1) > 0)][:, 0]
     assert vis[x < 0].mean() < 0.4 < 0.55 < vis[x > 0].mean()              # the golden itself: the covered half is mostly in shadow
     _compare_env_shade(g, "pbr_n4_occluder")
-    assert REPORT["pbr_n4_occluder"]["occluded_live_samples"] > 5000
+    r = REPORT["pbr_n4_occluder"]
+    assert r["occluded_live_samples"] > 1500 and r["occluded_live_samples"] > 0.3 * r["live_samples"]       # sheet-only goldens: ~5 %
 
 
 # flagged samples per golden, measured on MI355X (profiles/r03_ref_parity_envshade.json, r04_*): decision flips = a sample placed in another
