@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=None, help="fixed global batch dealt over the ranks (strong scaling); --gpus 8 --global-batch 8 = configs[3]")
     ap.add_argument("--schedule-it", type=int, default=1000, help="iteration counter at the start of the warm-up (1000 = steady-state schedule)")
     ap.add_argument("--early-steps", type=int, default=5, help="timed steps of the extra it=0 measurement (0 = skip)")
+    ap.add_argument("--extra-steps", type=int, default=5, help="timed steps of each side measurement printed inside the same JSON line: the conservative "
+                    "one-pass SDF forward, a close camera (35-40 %% coverage), and at 8 ranks BASELINE configs[3] (global batch 8); 0 = skip")
+    ap.add_argument("--camera-radius", type=float, default=2.2, help="orbit radius of the synthetic cameras (2.2: the garment covers ~14 %% of the frame)")
     ap.add_argument("--train-res", type=int, default=512)
     ap.add_argument("--n-samples", type=int, default=8)
     ap.add_argument("--fit-steps", type=int, default=400)
@@ -111,7 +114,8 @@ def main():
                              state_file=a.state_file, **overrides)
     # this rank's views of every global batch: ids [it*B + r, it*B + r + world, ...]
     n_iters = a.warmup + a.steps
-    targets = [workload.make_targets(trainer, [(it * B_global + v) % 72 for v in shard.local_views(B_global)], (H, W)) for it in range(min(n_iters, 4))]
+    targets = [workload.make_targets(trainer, [(it * B_global + v) % 72 for v in shard.local_views(B_global)], (H, W), radius=a.camera_radius)
+               for it in range(min(n_iters, 4))]
     # HIP events on the launch stream around the C-ABI calls: by default only around the candidates for the dominant kernel
     # (~10 event pairs per step); --op-times brackets every entry point (~250 pairs per step, taxes the headline slightly)
     _lib.enable_op_timing(True, only=None if a.op_times else ROOFLINE_CANDIDATES)
@@ -122,16 +126,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(schedule_it, warmup, steps):
+    def timed(schedule_it, warmup, steps, tgts=None, gb=None):
         """`warmup` untimed + `steps` timed iterations with the schedule counter starting at `schedule_it`; max over ranks."""
+        tgts, gb = tgts or targets, gb or B_global
         trainer.it = schedule_it
         for it in range(warmup):
-            trainer.step(targets[it % len(targets)], global_batch=B_global)
+            trainer.step(tgts[it % len(tgts)], global_batch=gb)
         barrier()
         _lib.reset_op_timing()
         t0 = time.perf_counter()
         for it in range(steps):
-            trainer.step(targets[(warmup + it) % len(targets)], global_batch=B_global)
+            trainer.step(tgts[(warmup + it) % len(tgts)], global_batch=gb)
         barrier()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
         if world > 1:
@@ -145,6 +150,33 @@ def main():
                  "value": round(B_global * H * W * a.early_steps / dt0 / 1e6, 4), "bilateral_radius": 2 * math.ceil(2.5 * trainer.denoiser.sigma) + 1 if trainer.denoiser else None}
     dt, op_times = timed(a.schedule_it, a.warmup, a.steps)
     from gshell_amd.geometry import mlp as _mlp
+    from gshell_amd.render import optixutils as _ou
+    covered_main = _ou.last_covered_pixels
+    rows_main = dict(_mlp.LAST_CHAIN_ROWS)
+    two_pass_ran = "gs_sdf_mlp_fwd_h1" in op_times
+    margin_used = getattr(trainer.geometry, "sdf_net", None) and trainer.geometry.sdf_net.__dict__.get("_gs_two_pass_margin_used")
+    side = {}
+    if a.extra_steps > 0:
+        # (1) the conservative figure: the SDF network's full-grid forward in ONE pass of the fp16-pair arithmetic (no one-product pass)
+        if two_pass_ran:
+            _mlp.SDF_TWO_PASS = False
+            dt1, _ = timed(a.schedule_it, 2, a.extra_steps)
+            _mlp.SDF_TWO_PASS = True
+            side["one_pass"] = {"ms_per_step": round(dt1 / a.extra_steps * 1e3, 3), "value": round(B_global * H * W * a.extra_steps / dt1 / 1e6, 4), "steps": a.extra_steps,
+                                "what": "same iteration with SDF_TWO_PASS = False: every grid row through the three-product fp16-pair kernel (k_h2_fwd<GRID>)"}
+        # (2) coverage sensitivity: S2 / R5 / S3 scale with the covered pixels; the headline camera leaves 86 % of the frame empty
+        near = [workload.make_targets(trainer, [(it * B_global + v) % 72 for v in shard.local_views(B_global)], (H, W), radius=1.4) for it in range(2)]
+        dt2, _ = timed(a.schedule_it, 2, a.extra_steps, tgts=near)
+        cov2 = _ou.last_covered_pixels
+        side["coverage_sensitivity"] = {"camera_radius": 1.4, "ms_per_step": round(dt2 / a.extra_steps * 1e3, 3), "value": round(B_global * H * W * a.extra_steps / dt2 / 1e6, 4),
+                                        "covered_pixels_per_rank": cov2, "coverage": None if cov2 is None else round(cov2 / (B_local * H * W), 4), "steps": a.extra_steps}
+        # (3) BASELINE.json configs[3] (8 GPUs x 1 view = global batch 8) beside the weak-scaling line of a plain `--gpus 8`
+        if world == 8 and a.global_batch is None:
+            one = [workload.make_targets(trainer, [(it * 8 + v) % 72 for v in shard.local_views(8)], (H, W), radius=a.camera_radius) for it in range(2)]
+            dt3, _ = timed(a.schedule_it, 2, a.extra_steps, tgts=one, gb=8)
+            side["configs3_global_batch_8"] = {"ms_per_step": round(dt3 / a.extra_steps * 1e3, 3), "value": round(8 * H * W * a.extra_steps / dt3 / 1e6, 4),
+                                               "iters_per_sec": round(a.extra_steps / dt3, 4), "scaling": "strong", "global_batch": 8, "views_per_gpu": 1, "steps": a.extra_steps,
+                                               "what": "BASELINE.json configs[3]: tet-res256, global batch 8 over 8 GPUs, 1 view of 512^2 per GPU"}
     if _mlp.FALLBACKS:
         raise SystemExit(f"bench.py: the SDF network left the HIP kernels during the run ({_mlp.FALLBACKS}); no number is reported for a torch path")
     if rank == 0:
@@ -160,8 +192,11 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "strong" if a.global_batch is not None else "weak",
             "vs_baseline": None,
-            "dtype": "f32 (SDF-network GEMMs: fp16-pair operands = 2^-22, fp32 accumulate; its full-grid forward first as a one-product fp16 pass, "
-                     "rows near the surface re-evaluated with the pair arithmetic)" if a.geometry == "tets" else "f32",
+            # what the run actually computed in (from the entry points that were timed), not what the geometry's name suggests
+            "dtype": ("f32 (SDF-network GEMMs: fp16-pair operands = 2^-22, fp32 accumulate" +
+                      ("; its full-grid forward first as a ONE-product fp16 pass, the rows whose value can matter + an audit sample of all rows re-evaluated "
+                       f"with the pair arithmetic; sign margin used by the first pass {margin_used}" if two_pass_ran else "; one pass over every row") + ")")
+                     if ("gs_sdf_mlp_fwd_h1" in op_times or "gs_sdf_mlp_fwd_h2" in op_times) else "f32",
             "data": "synthetic",
             "config": {"workload": f"{'G-FlexiCubes res' if a.geometry == 'flexicubes' else 'tet-res'}{a.res} ({'voxel grid' if a.geometry == 'flexicubes' else 'BCC'} {N} verts / {Ftets} cells), {B_local} views/GPU x {H}x{W}, n_samples={a.n_samples} "
                                    f"({2 * a.n_samples ** 2} shadow rays/px/pass), full train iteration fwd+bwd+3xAdam",
@@ -172,10 +207,17 @@ def main():
         }
         if early is not None:
             out["early_schedule"] = early
+        out.update(side)
+        out["config"]["covered_pixels_per_rank"] = covered_main
+        out["config"]["coverage"] = None if covered_main is None else round(covered_main / (B_local * H * W), 4)
+        out["config"]["camera_radius"] = a.camera_radius
         if same_device and world > 1:
             out["data"] = "synthetic; PLUMBING TEST: all ranks share one device over gloo (GSHELL_BENCH_SAME_DEVICE=1) -- not a performance number"
         # rows THIS rank pushes through the SDF-network kernel (the grid rows are sharded over the ranks of a multi-GPU job)
         N_mlp = -(-N // world) if (world > 1 and getattr(trainer.FLAGS, 'shard_mlp_rows', False)) else N
+        _ou.last_covered_pixels = covered_main          # the side measurements above ran other frames: the records describe the timed region
+        _mlp.LAST_CHAIN_ROWS.clear()
+        _mlp.LAST_CHAIN_ROWS.update(rows_main)
         roofs = rooflines(op_times, N_mlp, Ftets, V_aug, T, B_local, H, W, a.n_samples, trainer)
         if roofs:
             out["roofline"] = roofs[0]                      # the dominant hand-written kernel family by HIP-event time
@@ -196,7 +238,8 @@ def main():
 
 
 ROOFLINE_CANDIDATES = {"gs_env_shade_fwd", "gs_sdf_mlp_fwd_h1", "gs_sdf_mlp_fwd_h2", "gs_sdf_mlp_fwd", "gs_sdf_mlp_h2_refine_rows", "gs_mtets_flag_refine_rows",
-                       "gs_env_shade_bwd_saved", "gs_hashgrid_encode_bwd", "gs_hashgrid_encode_bwd_binned", "gs_sdf_mlp_h2_wgrad", "gs_sdf_mlp_h2_bwd", "gs_flexi_vd_bwd", "gs_flexi_vd_fwd"}
+                       "gs_env_shade_bwd_saved", "gs_hashgrid_encode_bwd", "gs_hashgrid_encode_bwd_binned", "gs_sdf_mlp_h2_wgrad", "gs_sdf_mlp_h2_bwd",
+                       "gs_sdf_mlp_h2_save_fwd", "gs_flexi_vd_bwd", "gs_flexi_vd_fwd"}
 
 
 def pmc_traffic(kernel):
@@ -216,8 +259,8 @@ def algorithmic_bytes(N, Ftets, V_aug, T, B, H, W):
     written once; E = 16 M edges at res 256 is folded into the per-tet / per-vertex figures of the extraction)."""
     npix = B * H * W
     return {
-        "gs_env_shade_fwd": npix * (4 + 6 * 12 + 24),
-        "gs_env_shade_bwd": npix * (4 + 6 * 12 + 24 + 48),
+        "gs_env_shade_fwd": npix * 92, "gs_env_shade_bwd": npix * 140,          # SURVEY.md 8d: 68 in + 24 out; 92 in + 48 out
+        "gs_flexi_vd_fwd": 116 * Ftets + 20 * N, "gs_flexi_vd_bwd": 116 * Ftets + 20 * N,      # SURVEY.md 8d: 32 B/cube + 84 B/cube weights + 20 B/vertex
         "gs_mtets_count": 16 * Ftets + 20 * N, "gs_mtets_fill": 16 * Ftets + 20 * N + 20 * V_aug + 12 * T,
         "gs_bilateral_fwd_masked": npix * (12 + 12 + 8 + 16), "gs_bilateral_bwd_masked": npix * (12 + 8 + 16 + 12),
         "gs_hashgrid_encode_fwd": 2 * npix * (12 + 4 + 128), "gs_hashgrid_encode_bwd": 2 * npix * (12 + 4 + 128 + 12),
@@ -255,64 +298,105 @@ def rooflines(op_times, N, Ftets, V_aug, T, B, H, W, n, trainer):
         return []
     fams = sorted(op_times.items(), key=lambda kv: -kv[1]["ms"] * kv[1]["n"])
     recs = []
-    for name, rec in fams[:4]:
+    for name, rec in fams[:5]:
         r = roofline_of(name, rec, op_times, N, Ftets, V_aug, T, B, H, W, n, trainer)
         if r:
             recs.append(r)
     return recs
 
 
+def binding_metric(key):
+    """What the rocprofv3 --pmc passes committed under profiles/ say binds a kernel family: the resource and its
+    measured utilisation.  profiles/r04_binding.json is written by tools/pmc_binding.py from the round's PMC runs."""
+    for name in ("r04_binding.json",):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f).get(key)
+        except Exception:
+            continue
+    return None
+
+
 def roofline_of(name, rec, op_times, N, Ftets, V_aug, T, B, H, W, n, trainer):
+    """One record per kernel family.  `achieved` = ALGORITHMIC work per launch exactly as SURVEY.md 8(d) defines it (no implementation
+    buffers) / the HIP-event average of the launch; `bound` / `peak` = the contract's roofline for that work; `binding` = the resource the
+    PMC counters show the family is actually limited by, with its measured utilisation (a ray traversal is VALU-issue bound: its HBM
+    fraction is reported because the contract has no third kind, and is not the figure of merit)."""
+    from gshell_amd.geometry import mlp as _mlp
+    from gshell_amd.render import optixutils as _ou
     npix = B * H * W
+    ms = rec["ms"]
+    t = ms * 1e-3
+
+    def hbm(kernel, alg_bytes, pmc_key=None, **extra):
+        gbps = alg_bytes / t / 1e9
+        out = {"kernel": kernel, "bound": "hbm", "achieved": round(gbps, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 5),
+               "traffic": pmc_traffic(pmc_key or name) if N == 2282489 else None, "avg_launch_ms": round(ms, 4), "algorithmic_bytes": int(alg_bytes)}
+        out.update(extra)
+        b = binding_metric(name)
+        if b:
+            out["binding"] = b
+        return out
+
+    def mfma(kernel, flops, peak, pmc_key=None, **extra):
+        tf = flops / t / 1e12
+        out = {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+               "traffic": pmc_traffic(pmc_key or name) if N == 2282489 else None, "avg_launch_ms": round(ms, 4), "algorithmic_flops": flops}
+        out.update(extra)
+        b = binding_metric(name)
+        if b:
+            out["binding"] = b
+        return out
+
     if name == "gs_sdf_mlp_fwd":
-        # fp32 MFMA roofline: 2 * (39*256 + 5*256*256 + 295*256 + 256) = 826 880 flop per grid vertex
-        flops = 826880.0 * N
-        tf = flops / (rec["ms"] * 1e-3) / 1e12
-        return {"kernel": "k_sdf_mlp_fwd (gs_sdf_mlp_fwd)", "bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
-                "frac": round(tf / 157.3, 4), "traffic": pmc_traffic("k_sdf_mlp_fwd") if N == 2282489 else None, "avg_launch_ms": round(rec["ms"], 4), "algorithmic_flops": flops,
-                "note": "fp32-in/fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32); HBM traffic is 16 B/vertex by construction"}
+        # fp32 MFMA roofline: 2 * (39*256 + 5*256*256 + 295*256 + 256) = 826 880 flop per grid vertex (SURVEY.md 8d)
+        return mfma("k_sdf_mlp_fwd (gs_sdf_mlp_fwd)", 826880.0 * N, 157.3, "k_sdf_mlp_fwd",
+                    note="fp32-in/fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32); HBM traffic is 16 B/vertex by construction")
     if name in ("gs_sdf_mlp_fwd_h2", "gs_sdf_mlp_fwd_h1"):
         # 826 880 ALGORITHMIC flop per grid vertex (what the network defines) over K padded to 16 (48 + 5 x 256 + 304 input columns x
         # 256 outputs); h2 executes 3 MFMA products per algorithmic product, h1 (first pass of the two-pass forward) one
         prods = 3 if name.endswith("h2") else 1
         flops = 826880.0 * N
         executed = 2.0 * 256 * (48 + 5 * 256 + 304) * prods * N
-        tf = flops / (rec["ms"] * 1e-3) / 1e12
-        out = {"kernel": "k_h2_fwd<GRID> (gs_sdf_mlp_fwd_h2)" if prods == 3 else "k_h1_fwd (gs_sdf_mlp_fwd_h1)", "bound": "mfma", "achieved": round(tf, 2),
-               "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": pmc_traffic("k_h2_fwd" if prods == 3 else "k_h1_fwd") if N == 2282489 else None,
-               "rows_per_launch": int(N), "avg_launch_ms": round(rec["ms"], 4), "algorithmic_flops": flops, "executed_mfma_flops": executed,
-               "executed_TFLOPs": round(executed / (rec["ms"] * 1e-3) / 1e12, 1), "executed_frac_of_f16_peak": round(executed / (rec["ms"] * 1e-3) / 1e12 / 2500.0, 4),
-               "note": "v_mfma_f32_32x32x16_f16, fp32 accumulate; " + ("operands = fp16 pairs (2^-22): three products per algorithmic product" if prods == 3 else
-                       "ONE fp16 product per algorithmic product over every grid row; the rows whose value can matter are re-evaluated by gs_sdf_mlp_h2_refine_rows")}
+        out = mfma("k_h2_fwd<GRID> (gs_sdf_mlp_fwd_h2)" if prods == 3 else "k_h1_fwd (gs_sdf_mlp_fwd_h1)", flops, 2500.0, "k_h2_fwd" if prods == 3 else "k_h1_fwd",
+                   rows_per_launch=int(N), executed_mfma_flops=executed, executed_TFLOPs=round(executed / t / 1e12, 1),
+                   executed_frac_of_f16_peak=round(executed / t / 1e12 / 2500.0, 4),
+                   note="v_mfma_f32_32x32x16_f16, fp32 accumulate; " + ("operands = fp16 pairs (2^-22): three products per algorithmic product" if prods == 3 else
+                        "ONE fp16 product per algorithmic product over every grid row; the rows whose value can matter are re-evaluated by gs_sdf_mlp_h2_refine_rows"))
         if prods == 1:
             ref = op_times.get("gs_sdf_mlp_h2_refine_rows", {"ms": 0.0})["ms"] + op_times.get("gs_mtets_flag_refine_rows", {"ms": 0.0})["ms"]
             net = trainer.geometry.sdf_net if hasattr(trainer.geometry, "sdf_net") else None
-            out["two_pass"] = {"refine_ms": round(ref, 4), "whole_forward_ms": round(rec["ms"] + ref, 4),
-                               "whole_forward_algorithmic_TFLOPs": round(flops / ((rec["ms"] + ref) * 1e-3) / 1e12, 1),
-                               "max_dev_one_product_on_refined_rows": None if net is None else net.__dict__.get("_gs_two_pass_maxdev")}
+            out["two_pass"] = {"refine_ms": round(ref, 4), "whole_forward_ms": round(ms + ref, 4),
+                               "whole_forward_algorithmic_TFLOPs": round(flops / ((ms + ref) * 1e-3) / 1e12, 1),
+                               "max_dev_one_product_on_reevaluated_rows": None if net is None else net.__dict__.get("_gs_two_pass_maxdev"),
+                               "sign_margin_used_incl_audit_rows": None if net is None else net.__dict__.get("_gs_two_pass_margin_used")}
         return out
+    if name in ("gs_sdf_mlp_h2_bwd", "gs_sdf_mlp_h2_wgrad", "gs_sdf_mlp_h2_save_fwd"):
+        # SURVEY.md 8d: dense backward = 2 x forward: 826 880 flop per (virtual) row for the reverse chain G = W^T D and the same again for
+        # the weight gradient D^T X; the saved forward = one forward.  Per LAUNCH: the mean over the grid pass (rows with gradient) and the
+        # eikonal pass (4 virtual rows per surface sample), which are the two launches of each kernel in an iteration.
+        rows = _mlp.LAST_CHAIN_ROWS
+        per_launch = 0.5 * (rows.get(1, 0) + 4 * rows.get(2, 0))
+        flops = 826880.0 * per_launch
+        kern = {"gs_sdf_mlp_h2_bwd": "k_h2_bwd<ROWS|EIK> reverse chain", "gs_sdf_mlp_h2_wgrad": "k_h2_wgrad16 (+ k_h2_wgrad for the output layer)",
+                "gs_sdf_mlp_h2_save_fwd": "k_h2_fwd<ROWS|EIK> recompute + saved planes"}[name]
+        return mfma(kern, flops, 2500.0, rows_with_gradient=int(rows.get(1, 0)), eikonal_samples=int(rows.get(2, 0)), mean_virtual_rows_per_launch=int(per_launch),
+                    hbm_plane_bytes_per_launch=int(per_launch * 7 * 256 * 4),
+                    note="fp16-pair (reverse chain, saved forward) / bf16-pair (weight gradient) operands: three products per algorithmic product")
     if name == "gs_env_shade_fwd":
-        # Monte-Carlo environment shading forward = k_shade_samples + k_shade_trace + k_shade_accumulate; the shadow-ray traversal is
-        # latency / issue bound (no RT units on CDNA4): the HBM figure is reported for the record, rays/s is the figure of merit
-        from gshell_amd.render import optixutils as _ou
+        # SURVEY.md 8d: 68 B/px in + 24 B/px out; 2 n^2 shadow rays per covered pixel are the work that binds it
         n_cov = _ou.last_covered_pixels
         rays = None if n_cov is None else n_cov * 2 * n * n
-        alg = npix * (4 + 6 * 12 + 24) + (rays or 0) * 40
-        gbps = alg / (rec["ms"] * 1e-3) / 1e9
-        out = {"kernel": "gs_env_shade_fwd (k_shade_samples + k_shade_trace + k_shade_accumulate)", "bound": "hbm", "achieved": round(gbps, 2), "peak": 8000.0,
-               "unit": "GB/s", "frac": round(gbps / 8000.0, 5), "traffic": pmc_traffic("gs_env_shade_fwd"), "avg_launch_ms": round(rec["ms"], 4),
-               "algorithmic_bytes": int(alg), "covered_pixels": n_cov, "shadow_rays": rays,
-               "rays_per_s": None if not rays else round(rays / (rec["ms"] * 1e-3) / 1e9, 3),
-               "note": "software BVH any-hit traversal: latency / instruction-issue bound, not an HBM stream; G rays/s over the whole family "
-                       "(sampling + traversal + accumulation); node / triangle visits per ray: profiles/r03_bvh_stats.json"}
-        return out
+        return hbm("gs_env_shade_fwd (k_shade_samples + k_shade_trace + k_shade_accumulate)", npix * 92.0, covered_pixels=n_cov, shadow_rays=rays,
+                   rays_per_s=None if not rays else round(rays / t / 1e9, 3),
+                   note="software BVH any-hit traversal: VALU-issue bound, not an HBM stream (`binding`); G rays/s over the whole family")
+    if name in ("gs_env_shade_bwd_saved", "gs_env_shade_bwd"):
+        return hbm("gs_env_shade_bwd_saved (k_shade_grad + light-gradient counting sort)", npix * 140.0, covered_pixels=_ou.last_covered_pixels,
+                   note="SURVEY.md 8d: 92 B/px in + 48 B/px out; streams the forward pass's saved 16 B/ray records")
     alg = algorithmic_bytes(N, Ftets, V_aug, T, B, H, W).get(name)
     if alg is None:
-        return {"kernel": name, "bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": pmc_traffic(name) if N == 2282489 else None,
-                "avg_launch_ms": round(rec["ms"], 4)}
-    gbps = alg / (rec["ms"] * 1e-3) / 1e9
-    return {"kernel": name, "bound": "hbm", "achieved": round(gbps, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 5),
-            "traffic": pmc_traffic(name) if N == 2282489 else None, "avg_launch_ms": round(rec["ms"], 4), "algorithmic_bytes": int(alg)}
+        return None
+    return hbm(name, alg)
 
 
 def cpu_baseline(res=256):

@@ -499,6 +499,9 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+LAST_CHAIN_ROWS = {}      # mode (1 = grid rows with gradient, 2 = eikonal samples) -> rows of the last saved pass (bench.py: flops per launch)
+
+
 class _SavedChain:
     """Saved planes of one pass of the h2 chain kernels over n (virtual) rows: A [layers, Rpad, 256], EMB [Rpad, 48]."""
 
@@ -506,6 +509,7 @@ class _SavedChain:
         """n = number of (virtual) rows, or their CAPACITY when `n_dev` (device int64 tensor, [0] = the count) is given."""
         L = _lib.lib()
         self.net, self.mode, self.n, self.n_dev = net, mode, int(n), n_dev
+        LAST_CHAIN_ROWS[mode] = int(n)
         self.lin, self.n_hidden, self.skip = _layer_structure(net)
         self.nf = net.emb.N_freqs
         self.packed, _, _ = pack_weights_h2(net)

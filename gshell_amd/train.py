@@ -203,7 +203,8 @@ class Trainer:
         w = self.shard.world
         if w == 1:
             return "single GPU"
-        rows = "SDF-MLP rows + eikonal samples sharded (all-gather sdf[N])" if getattr(self.FLAGS, "shard_mlp_rows", False) else "geometry replicated"
+        rows = ("SDF-MLP rows + eikonal samples sharded (each rank: ONE-pass fp16-pair forward over its N / G rows, all-gather sdf[N])"
+                if getattr(self.FLAGS, "shard_mlp_rows", False) else "geometry replicated")
         return f"view-shard dp{w}, {rows}, one flat RCCL all-reduce of the gradient"
 
     def all_params(self):

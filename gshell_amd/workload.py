@@ -77,11 +77,11 @@ def set_mid_training_state(geometry, seed=0):
         geometry.deform.copy_((torch.rand(v.shape, device=v.device, generator=g) * 2 - 1) * 0.3)
 
 
-def make_targets(trainer, view_ids, res, seed=1):
+def make_targets(trainer, view_ids, res, seed=1, radius=2.2):
     """Reference images for the given views: this renderer's own output from a perturbed light, used as a fixed target."""
     dev = trainer.geometry.verts.device
     H, W = res
-    mvp, campos = views(view_ids, dev)
+    mvp, campos = views(view_ids, dev, radius)
     B = len(view_ids)
     g = torch.Generator(device=dev)
     # background colour = function of the VIEW id (not of its position in this rank's shard)
