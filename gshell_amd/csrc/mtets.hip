@@ -592,8 +592,8 @@ __global__ void k_bwd_vertices(int64_t V, const float* __restrict__ pos, const f
                                const float* __restrict__ msdf, const int32_t* __restrict__ vert_ab,
                                const uint8_t* __restrict__ used_wt, const float* __restrict__ g_verts_aug,
                                const float* __restrict__ g_msdf_aug, const float* __restrict__ g_verts_wt,
-                               const float* __restrict__ acc, float* __restrict__ g_pos, float* __restrict__ g_sdf,
-                               float* __restrict__ g_msdf) {
+                               const float* __restrict__ g_mv_full, const float* __restrict__ acc, float* __restrict__ g_pos,
+                               float* __restrict__ g_sdf, float* __restrict__ g_msdf) {
     int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
     const int a = vert_ab[2 * v], b = vert_ab[2 * v + 1];
@@ -605,7 +605,7 @@ __global__ void k_bwd_vertices(int64_t V, const float* __restrict__ pos, const f
         if (u && g_verts_aug) gv[d] += g_verts_aug[v * 3 + d];
         if (g_verts_wt) gv[d] += g_verts_wt[v * 3 + d];
     }
-    const float gm = acc[v * 5 + 3];                                          // d/d msdf_vert (full gradient copy)
+    const float gm = acc[v * 5 + 3] + (g_mv_full ? g_mv_full[v] : 0.0f);      // d/d msdf_vert (full gradient copy; + the tangents' boundary weights)
     const float gs = acc[v * 5 + 4] + (g_msdf_aug ? g_msdf_aug[v] : 0.0f);    // d/d msdf_vert_stopvgd
     const float sa = sdf[a], sb = sdf[b], ma = msdf[a], mb = msdf[b];
     const float x0 = sa, x1 = -sb, d0 = x0 + x1;
@@ -712,6 +712,124 @@ __global__ void k_tng_boundary(int64_t V, int64_t M1, int64_t M2, const float* _
     else msdf_weights(msdf_aug[a], msdf_aug[b], wa, wb);
 #pragma unroll
     for (int d = 0; d < 3; ++d) tng[(V + j) * 3 + d] = tng[(int64_t)a * 3 + d] * wa + tng[(int64_t)b * 3 + d] * wb;
+}
+
+
+// ---- backward of the tangents (ref gshell_tets.py:40-78 through :318-319, :375-380) -----------------------------------------------------
+// x / sqrt(max(|x|^2, 1e-20)): adjoint
+__device__ __forceinline__ void safe_nz_bwd(const float* x, const float* g, float* gx) {
+    const float l2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+    if (l2 > 1e-20f) {
+        const float il = 1.0f / sqrtf(l2);
+        const float xg = (x[0] * g[0] + x[1] * g[1] + x[2] * g[2]) * il * il;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gx[d] = (g[d] - x[d] * xg) * il;
+    } else {            // the clamp is active: the denominator is the constant 1e-10
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gx[d] = g[d] * 1e10f;
+    }
+}
+
+// boundary vertex j = tng[a] wa + tng[b] wb with the mSDF weights of its polygon edge (full gradient: ref :375-380 does not detach them)
+__global__ void k_tng_bwd_boundary(int64_t V, int64_t M1, int64_t M2, const float* __restrict__ msdf_aug, const int32_t* __restrict__ poly,
+                                   const float* __restrict__ tng, const float* __restrict__ g_tng, float* __restrict__ g_tw /*[V,3] +=*/,
+                                   float* __restrict__ g_mv /*[V] +=*/) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 3 * M1 + 4 * M2) return;
+    int n, k;
+    int64_t p0;
+    if (j < 3 * M1) { n = 3; p0 = (j / 3) * 3; k = (int)(j - p0); }
+    else { int64_t q = j - 3 * M1; n = 4; p0 = 3 * M1 + (q / 4) * 4; k = (int)(q & 3); }
+    const int a = poly[p0 + k], b = poly[p0 + ((k + 1 == n) ? 0 : k + 1)];
+    const float ma = msdf_aug[a], mb = msdf_aug[b];
+    float wa, wb;
+    const bool nz = msdf_weights(ma, mb, wa, wb);
+    float gwa = 0.f, gwb = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float g = g_tng[(V + j) * 3 + d];
+        gwa += g * tng[(int64_t)a * 3 + d];
+        gwb += g * tng[(int64_t)b * 3 + d];
+        if (g != 0.f) {
+            atomicAdd(&g_tw[(int64_t)a * 3 + d], g * wa);
+            atomicAdd(&g_tw[(int64_t)b * 3 + d], g * wb);
+        }
+    }
+    if (nz && (gwa != 0.f || gwb != 0.f)) {       // w_a = x1 / den, w_b = x0 / den, x0 = m_a, x1 = -m_b, den = x0 + x1 (as k_bwd_boundary)
+        const float x0 = ma, x1 = -mb, den = x0 + x1;
+        const float gden = -(gwa * x1 + gwb * x0) / (den * den);
+        const float gx1 = gwa / den + gden, gx0 = gwb / den + gden;
+        atomicAdd(&g_mv[a], gx0);
+        atomicAdd(&g_mv[b], -gx1);
+    }
+}
+
+// per watertight vertex: out = nz(t1 - (t1.n) n), t1 = nz(Ts / cnt), n = nz(N or (0,0,1))  ->  adjoints of the two face sums N, Ts
+__global__ void k_tng_bwd_verts(int64_t V, const float* __restrict__ acc /*[V,7] of the forward pass*/, const float* __restrict__ g_tw,
+                                float* __restrict__ g_acc /*[V,6]: g_N, g_Ts*/) {
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    float N[3] = {acc[v * 7], acc[v * 7 + 1], acc[v * 7 + 2]};
+    const bool n_const = !(N[0] * N[0] + N[1] * N[1] + N[2] * N[2] > 1e-20f);
+    float n[3] = {N[0], N[1], N[2]};
+    if (n_const) { n[0] = 0.f; n[1] = 0.f; n[2] = 1.f; }
+    safe_nz(n);
+    const float cnt = acc[v * 7 + 6];
+    float t0[3] = {acc[v * 7 + 3] / cnt, acc[v * 7 + 4] / cnt, acc[v * 7 + 5] / cnt};
+    float t1[3] = {t0[0], t0[1], t0[2]};
+    safe_nz(t1);
+    const float dp = t1[0] * n[0] + t1[1] * n[1] + t1[2] * n[2];
+    float u[3], G[3], gu[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { u[d] = t1[d] - dp * n[d]; G[d] = g_tw[v * 3 + d]; }
+    safe_nz_bwd(u, G, gu);
+    const float gun = gu[0] * n[0] + gu[1] * n[1] + gu[2] * n[2];
+    float gt1[3], gn[3], gt0[3], gN[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gt1[d] = gu[d] - gun * n[d]; gn[d] = -(dp * gu[d] + gun * t1[d]); }
+    safe_nz_bwd(t0, gt1, gt0);
+    if (n_const) { gN[0] = gN[1] = gN[2] = 0.f; }
+    else safe_nz_bwd(N, gn, gN);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { g_acc[v * 6 + d] = gN[d]; g_acc[v * 6 + 3 + d] = gt0[d] / cnt; }
+}
+
+// per face: fn = q1 x q2 and tang = (q1 e2y - q2 e1y) / den were added to its three vertices
+__global__ void k_tng_bwd_faces(int64_t nf, const float* __restrict__ verts, const int64_t* __restrict__ faces, const float* __restrict__ lin,
+                                int Nuv, float pad, const float* __restrict__ g_acc, float* __restrict__ g_verts /*[V,3] +=*/) {
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    int i[3];
+    float p[3][3], uv[3][2];
+    float gfn[3] = {0.f, 0.f, 0.f}, gtg[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        i[c] = (int)faces[f * 3 + c];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            p[c][d] = verts[(int64_t)i[c] * 3 + d];
+            gfn[d] += g_acc[(int64_t)i[c] * 6 + d];
+            gtg[d] += g_acc[(int64_t)i[c] * 6 + 3 + d];
+        }
+        atlas_uv(i[c], lin, Nuv, pad, uv[c][0], uv[c][1]);
+    }
+    float q1[3], q2[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { q1[d] = p[1][d] - p[0][d]; q2[d] = p[2][d] - p[0][d]; }
+    const float e1x = uv[1][0] - uv[0][0], e1y = uv[1][1] - uv[0][1], e2x = uv[2][0] - uv[0][0], e2y = uv[2][1] - uv[0][1];
+    float den = e1x * e2y - e1y * e2x;
+    den = den > 0.0f ? fmaxf(den, 1e-6f) : fminf(den, -1e-6f);
+    // d (q1 x q2) . g:  g_q1 = q2 x g,  g_q2 = g x q1
+    float gq1[3] = {q2[1] * gfn[2] - q2[2] * gfn[1], q2[2] * gfn[0] - q2[0] * gfn[2], q2[0] * gfn[1] - q2[1] * gfn[0]};
+    float gq2[3] = {gfn[1] * q1[2] - gfn[2] * q1[1], gfn[2] * q1[0] - gfn[0] * q1[2], gfn[0] * q1[1] - gfn[1] * q1[0]};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        gq1[d] += gtg[d] * e2y / den;
+        gq2[d] -= gtg[d] * e1y / den;
+        atomicAdd(&g_verts[(int64_t)i[1] * 3 + d], gq1[d]);
+        atomicAdd(&g_verts[(int64_t)i[2] * 3 + d], gq2[d]);
+        atomicAdd(&g_verts[(int64_t)i[0] * 3 + d], -(gq1[d] + gq2[d]));
+    }
 }
 
 }  // namespace
@@ -849,7 +967,7 @@ extern "C" int gs_mtets_aug_fill(gs_mtets_topo* t, const float* pos, const float
 extern "C" int gs_mtets_bwd(int64_t N, int64_t V, int64_t M1, int64_t M2, const float* pos, const float* sdf, const float* msdf,
                             const float* verts_wt, const float* msdf_aug, const int32_t* vert_ab, const uint8_t* used_wt,
                             const int32_t* poly, const uint8_t* cut_code, const float* g_verts_aug, const float* g_msdf_aug,
-                            const float* g_verts_wt, float* scratch, float* g_pos, float* g_sdf, float* g_msdf,
+                            const float* g_verts_wt, const float* g_mv_full, float* scratch, float* g_pos, float* g_sdf, float* g_msdf,
                             gs_stream_t stream_) {
     (void)N;
     if (V == 0) return 0;
@@ -860,7 +978,7 @@ extern "C" int gs_mtets_bwd(int64_t N, int64_t V, int64_t M1, int64_t M2, const 
     const int64_t nb = 3 * M1 + 4 * M2;
     if (nb > 0 && (g_verts_aug || g_msdf_aug))
         k_bwd_boundary<<<gs::cdiv(nb, 256), 256, 0, stream>>>(V, M1, M2, verts_wt, msdf_aug, poly, cut_code, g_verts_aug, g_msdf_aug, scratch);
-    k_bwd_vertices<<<gs::cdiv(V, 256), 256, 0, stream>>>(V, pos, sdf, msdf, vert_ab, used_wt, g_verts_aug, g_msdf_aug, g_verts_wt,
+    k_bwd_vertices<<<gs::cdiv(V, 256), 256, 0, stream>>>(V, pos, sdf, msdf, vert_ab, used_wt, g_verts_aug, g_msdf_aug, g_verts_wt, g_mv_full,
                                                         scratch, g_pos, g_sdf, g_msdf);
     GS_LAUNCH_CHECK();
     return 0;
@@ -888,6 +1006,30 @@ extern "C" int gs_mtets_tangents(int64_t V, int64_t M1, int64_t M2, int64_t F, c
                                  float* v_tng_aug, gs_stream_t stream_) {
     (void)F;
     return tangents_impl(V, M1, M2, verts_wt, faces_wt, msdf_aug, nullptr, poly, lin, Nuv, scratch, v_tng_aug, stream_);
+}
+
+// Adjoint of gs_mtets_tangents.  acc = the forward call's scratch [V,7] (face-normal sum, face-tangent sum, count per vertex), v_tng_aug its
+// output; g_tng_aug [V + 3 M1 + 4 M2, 3] upstream.  OUT (overwritten): g_verts_wt [V,3] = d loss / d verts_wt through the tangents,
+// g_mv [V] = d loss / d (watertight mSDF values) through the boundary weights (hand both to gs_mtets_bwd).  work [V,9] f32 scratch.
+extern "C" int gs_mtets_tangents_bwd(int64_t V, int64_t M1, int64_t M2, const float* verts_wt, const int64_t* faces_wt, const float* msdf_aug,
+                                     const int32_t* poly, const float* lin, int64_t Nuv, const float* acc, const float* v_tng_aug,
+                                     const float* g_tng_aug, float* work, float* g_verts_wt, float* g_mv, gs_stream_t stream_) {
+    if (V == 0) return 0;
+    GS_REQUIRE(verts_wt && faces_wt && msdf_aug && poly && lin && acc && v_tng_aug && g_tng_aug && work && g_verts_wt && g_mv,
+               "gs_mtets_tangents_bwd: null argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t nf = M1 + 2 * M2, nb = 3 * M1 + 4 * M2;
+    const float pad = (float)(0.9 / (double)Nuv);
+    float* g_tw = work;               // [V,3] gradient of the watertight tangents: own rows + what the boundary vertices hand down
+    float* g_acc = work + 3 * V;      // [V,6]
+    GS_HIP_CHECK(hipMemcpyAsync(g_tw, g_tng_aug, sizeof(float) * 3 * (size_t)V, hipMemcpyDeviceToDevice, stream));
+    GS_HIP_CHECK(hipMemsetAsync(g_mv, 0, sizeof(float) * (size_t)V, stream));
+    GS_HIP_CHECK(hipMemsetAsync(g_verts_wt, 0, sizeof(float) * 3 * (size_t)V, stream));
+    if (nb > 0) k_tng_bwd_boundary<<<gs::cdiv(nb, 256), 256, 0, stream>>>(V, M1, M2, msdf_aug, poly, v_tng_aug, g_tng_aug, g_tw, g_mv);
+    k_tng_bwd_verts<<<gs::cdiv(V, 256), 256, 0, stream>>>(V, acc, g_tw, g_acc);
+    if (nf > 0) k_tng_bwd_faces<<<gs::cdiv(nf, 256), 256, 0, stream>>>(nf, verts_wt, faces_wt, lin, (int)Nuv, pad, g_acc, g_verts_wt);
+    GS_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int gs_mtets_aug_tangents(int64_t V, int64_t M1, int64_t M2, const float* verts_wt, const int64_t* faces_wt,

@@ -7,10 +7,9 @@ return tuple (gshell_tets.py:245, :426-443) but runs as hand-written HIP kernels
     (verts_aug, faces_aug, None, None, v_tng_aug, extra)
 
 Differences that are deliberate (documented in DESIGN.md):
-  * v_tng_aug / extra['v_tng_watertight'] are computed (forward parity); their gradient
-    (compute_tangents, gshell_tets.py:40-78) is NOT implemented and back-propagating through
-    them RAISES (_TangentGradGuard) instead of silently dropping it.  The reference's training
-    path discards the tangents (gshell_tets_geometry.py:206-208, render.py:264-267).
+  * v_tng_aug / extra['v_tng_watertight'] back-propagate (gs_mtets_tangents_bwd: compute_tangents + auto_normals + the boundary
+    interpolation, gshell_tets.py:9-78, :318-319, :375-380), although the reference's training path discards the tangents
+    (gshell_tets_geometry.py:206-208, render.py:264-267).
   * faces are additionally available as int32 (`extra['faces_i32']`) for the rasteriser.
 """
 import ctypes
@@ -112,51 +111,56 @@ class _MarchingTetsFn(torch.autograd.Function):
                                   ptr(faces_wt), ptr(faces_aug), ptr(faces_i32), ptr(vert_ab), ptr(used_wt), ptr(poly),
                                   ptr(cut_code), ptr(tet_id), ptr(sign_code), ptr(grp_rank), stream()), "gs_mtets_fill")
             v_tng_aug = torch.zeros((V_aug, 3), **f32)
+            scratch = None
             if want_tangents and V > 0:
-                scratch = torch.empty((V, 7), **f32)
+                scratch = torch.empty((V, 7), **f32)          # per-vertex face-normal sum, face-tangent sum, face count: kept for the backward
                 check(L.gs_mtets_tangents(c_int64(V), c_int64(M1), c_int64(M2), c_int64(topo.F), ptr(verts_wt), ptr(faces_wt),
                                           ptr(msdf_aug), ptr(poly), ptr(topo.uv_lin), c_int64(topo.Nuv), ptr(scratch),
                                           ptr(v_tng_aug), stream()), "gs_mtets_tangents")
         ctx.save_for_backward(pos_c, sdf_c, msdf_c, verts_wt, msdf_aug, vert_ab, used_wt, poly, cut_code)
         ctx.dims = (topo.N, V, M1, M2)
         ctx.in_shapes = (pos.shape, sdf.shape, msdf.shape)
-        ctx.mark_non_differentiable(faces_wt, faces_aug, faces_i32, v_tng_aug, tet_id)
+        # tangents: differentiable (compute_tangents + auto_normals + boundary interpolation, gshell_tets.py:9-78, :318-319, :375-380)
+        ctx.tng = (faces_wt, scratch, v_tng_aug, topo.uv_lin, topo.Nuv) if scratch is not None else None
+        ctx.mark_non_differentiable(faces_wt, faces_aug, faces_i32, tet_id)
+        if scratch is None:
+            ctx.mark_non_differentiable(v_tng_aug)
         ctx.set_materialize_grads(False)      # outputs nobody differentiates (verts_wt in training) arrive as None, not as zero tensors
         return verts_aug, msdf_aug, verts_wt, faces_aug, faces_wt, faces_i32, v_tng_aug, tet_id
 
     @staticmethod
-    def backward(ctx, g_verts_aug, g_msdf_aug, g_verts_wt, *_unused):
+    def backward(ctx, g_verts_aug, g_msdf_aug, g_verts_wt, g_faces_aug=None, g_faces_wt=None, g_faces_i32=None, g_tng_aug=None, *_unused):
         pos, sdf, msdf, verts_wt, msdf_aug, vert_ab, used_wt, poly, cut_code = ctx.saved_tensors
         N, V, M1, M2 = ctx.dims
         dev = pos.device
         flat = torch.zeros((5 * N,), dtype=torch.float32, device=dev)          # one fill, three views
         g_pos, g_sdf, g_msdf = flat[:3 * N].view(N, 3), flat[3 * N:4 * N], flat[4 * N:]
-        if V > 0 and not (g_verts_aug is None and g_msdf_aug is None and g_verts_wt is None):
+        if ctx.tng is None:
+            g_tng_aug = None
+        if V > 0 and not (g_verts_aug is None and g_msdf_aug is None and g_verts_wt is None and g_tng_aug is None):
             def prep(g):
                 return None if g is None else g.contiguous().float()
             ga, gm, gw = prep(g_verts_aug), prep(g_msdf_aug), prep(g_verts_wt)
+            g_mv = None
+            if g_tng_aug is not None:
+                faces_wt, acc, v_tng_aug, uv_lin, Nuv = ctx.tng
+                gt = prep(g_tng_aug)
+                g_vw_t = torch.empty((V, 3), dtype=torch.float32, device=dev)
+                g_mv = torch.empty((V,), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    work = torch.empty((V, 9), dtype=torch.float32, device=dev)
+                    check(_lib.lib().gs_mtets_tangents_bwd(c_int64(V), c_int64(M1), c_int64(M2), ptr(verts_wt), ptr(faces_wt), ptr(msdf_aug), ptr(poly),
+                                                           ptr(uv_lin), c_int64(Nuv), ptr(acc), ptr(v_tng_aug), ptr(gt, torch.float32, "g_tng_aug"), ptr(work),
+                                                           ptr(g_vw_t), ptr(g_mv), stream()), "gs_mtets_tangents_bwd")
+                gw = g_vw_t if gw is None else gw + g_vw_t
             with torch.cuda.device(dev):
                 scratch = torch.empty((V, 5), dtype=torch.float32, device=dev)
                 check(_lib.lib().gs_mtets_bwd(c_int64(N), c_int64(V), c_int64(M1), c_int64(M2), ptr(pos), ptr(sdf), ptr(msdf),
                                               ptr(verts_wt), ptr(msdf_aug), ptr(vert_ab), ptr(used_wt), ptr(poly), ptr(cut_code),
-                                              ptr(ga), ptr(gm), ptr(gw), ptr(scratch), ptr(g_pos), ptr(g_sdf), ptr(g_msdf),
+                                              ptr(ga), ptr(gm), ptr(gw), ptr(g_mv), ptr(scratch), ptr(g_pos), ptr(g_sdf), ptr(g_msdf),
                                               stream()), "gs_mtets_bwd")
         ps, ss, ms = ctx.in_shapes
         return g_pos.reshape(ps), g_sdf.reshape(ss), g_msdf.reshape(ms), None, None, None
-
-
-class _TangentGradGuard(torch.autograd.Function):
-    """Identity on the tangents, with an autograd edge to the vertices they were computed from: a loss that consumes
-    v_tng_aug reaches this node in its backward pass and gets an error, not a silently missing term."""
-
-    @staticmethod
-    def forward(ctx, v_tng, verts_aug):
-        return v_tng.view_as(v_tng)
-
-    @staticmethod
-    def backward(ctx, g):
-        raise _lib.GShellHipError("the gradient of v_tng_aug / v_tng_watertight (compute_tangents, reference geometry/gshell_tets.py:40-78) is not "
-                                  "implemented in the HIP path; the reference's training path never consumes it")
 
 
 class GShell_Tets:
@@ -188,8 +192,6 @@ class GShell_Tets:
         verts_aug, msdf_aug, verts_wt, faces_aug, faces_wt, faces_i32, v_tng_aug, tet_id = _MarchingTetsFn.apply(
             pos_nx3, sdf_n, msdf_n, topo, self.compute_tangents, presigned)
         V = verts_wt.shape[0]
-        if verts_aug.requires_grad:
-            v_tng_aug = _TangentGradGuard.apply(v_tng_aug, verts_aug)
         extra = {
             'n_verts_watertight': V,
             'vertices_watertight': verts_wt,

@@ -100,16 +100,25 @@ int gs_mtets_bwd(int64_t N, int64_t V, int64_t M1, int64_t M2, const float* pos_
                  const float* sdf_n, const float* msdf_n, const float* verts_wt,
                  const float* msdf_aug, const int32_t* vert_ab, const uint8_t* used_wt,
                  const int32_t* poly, const uint8_t* cut_code, const float* g_verts_aug,
-                 const float* g_msdf_aug, const float* g_verts_wt, float* scratch,
-                 float* g_pos, float* g_sdf, float* g_msdf, gs_stream_t stream);
+                 const float* g_msdf_aug, const float* g_verts_wt,
+                 const float* g_mv_full /* [V] or NULL: d loss / d watertight mSDF values WITH the weights' gradient (gs_mtets_tangents_bwd) */,
+                 float* scratch, float* g_pos, float* g_sdf, float* g_msdf, gs_stream_t stream);
 
 /* Tangent frame of the watertight mesh interpolated to the boundary vertices
- * (gshell_tets.py:9-78, :318-319, :375-380; forward only -- dead on the training path).
+ * (gshell_tets.py:9-78, :318-319, :375-380; dead on the training path: gshell_tets_geometry.py:206-208, render.py:264-267).
  *   scratch [V,7] f32; lin [Nuv] f32 = torch.linspace(0, 1-1/Nuv, Nuv), Nuv=ceil(sqrt(F)) */
 int gs_mtets_tangents(int64_t V, int64_t M1, int64_t M2, int64_t F, const float* verts_wt,
                       const int64_t* faces_wt, const float* msdf_aug, const int32_t* poly,
                       const float* lin, int64_t Nuv, float* scratch, float* v_tng_aug,
                       gs_stream_t stream);
+/* Adjoint of gs_mtets_tangents = autograd through compute_tangents + auto_normals + the boundary interpolation
+ * (gshell_tets.py:9-78, :318-319, :375-380).  acc = the forward call's `scratch` (kept by the caller), v_tng_aug its output,
+ * g_tng_aug [V + 3 M1 + 4 M2, 3] the upstream gradient.  WRITTEN: g_verts_wt [V,3] (add it to gs_mtets_bwd's g_verts_wt) and
+ * g_mv [V] (gs_mtets_bwd's g_mv_full).  work [V,9] f32. */
+int gs_mtets_tangents_bwd(int64_t V, int64_t M1, int64_t M2, const float* verts_wt, const int64_t* faces_wt,
+                          const float* msdf_aug, const int32_t* poly, const float* lin, int64_t Nuv,
+                          const float* acc, const float* v_tng_aug, const float* g_tng_aug, float* work,
+                          float* g_verts_wt, float* g_mv, gs_stream_t stream);
 
 /* Generative-decode variant of the extraction (replaces GShell_Tets.marching_from_auggrid,
  * geometry/gshell_tets.py:446-629; caller getMesh_from_augmented_grid_withocc,

@@ -179,17 +179,51 @@ def test_presigned_extraction_equals_plain_extraction():
     assert torch.equal(f3, f1) and torch.equal(v3, v1)
 
 
-def test_tangent_gradient_raises_instead_of_vanishing():
-    """E5: compute_tangents' gradient (gshell_tets.py:40-78) is not implemented; a loss through v_tng_aug must fail loudly."""
-    from gshell_amd import _lib, grid
+@pytest.mark.parametrize("gspec,sk,mk,seed", [(("bcc", 12), "sphere", "wavy", 0), (("bcc", 20), "sphere_noise", "rand", 11), (("kuhn", 16), "skirt", "halfspace", 13),
+                                              (("bcc", 26), "skirt", "wavy", 15)])
+def test_tangent_gradient_matches_autograd_of_the_oracle(gspec, sk, mk, seed):
+    """E5: d loss / d (pos, sdf, msdf) through v_tng_aug -- compute_tangents + auto_normals + the boundary interpolation with the mSDF
+    weights (gshell_tets.py:9-78, :318-319, :375-380) -- gs_mtets_tangents_bwd vs autograd through oracle/mtets_oracle._tangents (pinned to
+    goldens minted from the real reference).  The unit tangent of a vertex whose face terms nearly cancel has an unbounded derivative, so
+    the float32 answer itself is only defined up to the float32-vs-float64 difference of the ORACLE: the bar is 1e-4 or 4 x that floor."""
+    from gshell_amd import grid
     from gshell_amd.geometry.gshell_tets import GShell_Tets
-    verts, tets = grid.bcc_grid(6)
+    verts, tets = (grid.bcc_grid(gspec[1]) if gspec[0] == "bcc" else grid.kuhn_grid(gspec[1]))
     vn = verts.numpy()
+    vn = (vn + fields.make_deform(vn, 1.0 / gspec[1], seed)).astype(np.float32)
+    sdf, msdf = fields.make_sdf(vn, sk, seed).astype(np.float32), fields.make_msdf(vn, mk, seed).astype(np.float32)
+
+    def oracle(dt):
+        pos = torch.tensor(vn, dtype=dt, requires_grad=True)
+        s = torch.tensor(sdf, dtype=dt, requires_grad=True)
+        m = torch.tensor(msdf, dtype=dt, requires_grad=True)
+        o = mtets_oracle.extract(pos, s, m, tets)
+        w = torch.tensor(np.random.default_rng(seed).normal(size=tuple(o["v_tng_aug"].shape)), dtype=dt)
+        (o["v_tng_aug"] * w).sum().backward()
+        return o, w, (pos.grad, s.grad, m.grad)
+    o32, w, g32 = oracle(torch.float32)
     pos = torch.tensor(vn, device=DEV, requires_grad=True)
-    s = torch.tensor(fields.make_sdf(vn, "sphere", 0), device=DEV, requires_grad=True)
-    m = torch.tensor(fields.make_msdf(vn, "wavy", 0), device=DEV, requires_grad=True)
+    s = torch.tensor(sdf, device=DEV, requires_grad=True)
+    m = torch.tensor(msdf, device=DEV, requires_grad=True)
     v, f, _, _, tng, extra = GShell_Tets()(pos, s, m, tets.to(DEV))
-    assert tng.requires_grad and extra["v_tng_watertight"].requires_grad
-    v.sum().backward(retain_graph=True)                       # the training path: tangents unused -> fine
-    with pytest.raises(_lib.GShellHipError, match="v_tng_aug"):
-        (v.sum() + tng.sum()).backward()
+    assert tng.requires_grad and extra["v_tng_watertight"].requires_grad and tng.shape == o32["v_tng_aug"].shape
+    (tng * w.to(DEV)).sum().backward()
+    if o32["v_tng_aug"].shape[0] == 0:
+        return
+    # float64 run of the same oracle on the same float32 inputs: what float32 round-off alone does to this gradient
+    try:
+        _, _, g64 = oracle(torch.float64)
+    except Exception:
+        g64 = None
+    for name, a, b32, k in (("pos", pos.grad, g32[0], 0), ("sdf", s.grad, g32[1], 1), ("msdf", m.grad, g32[2], 2)):
+        a = a.cpu()
+        assert torch.isfinite(a).all() and float(b32.abs().max()) > 0, name
+        rel = float((a - b32).norm() / b32.norm())
+        floor = float((b32.double() - g64[k]).norm() / g64[k].norm()) if g64 is not None else 0.0
+        print(f"  tangent gradient {name}: HIP vs oracle(f32) rel L2 {rel:.2e}; oracle f32 vs f64 {floor:.2e}")
+        assert rel <= max(1e-4, 4.0 * floor), (name, rel, floor)
+    # and the training path is untouched: tangents unused -> the extraction's own gradients only
+    pos.grad = None
+    v2, _, _, _, tng2, _ = GShell_Tets()(pos, s, m, tets.to(DEV))
+    v2.sum().backward()
+    assert torch.isfinite(pos.grad).all()
