@@ -250,3 +250,60 @@ def test_hash_grid_and_texture_field_on_the_covered_pixels_at_512(scene):
     badx = ((gx - gr).abs() > 1e-4 * gr.abs() + 1e-5 * float(gr.abs().max())).any(-1)
     print(f"  position-gradient rows outside: {int(badx.sum())} of {x.shape[0]} (points on a cell face of some level)")
     assert int(badx.sum()) <= max(4, x.shape[0] // 20000)
+
+
+def test_fused_texture_field_training_path_against_the_oracle_at_512(scene):
+    """the FUSED texture field of the training path -- MLPTexture3D.sample_many: AABB normalisation + clamp + level-major
+    encoding of both coordinate sets in one pass, the texture MLP on the matrix cores, and in the backward the BINNED table gradient
+    (per-bin records summed in 64-bit fixed point) -- directly against oracle/hashgrid_oracle + a plain torch MLP (pipeline_oracle.TextureOracle),
+    not against the product's own operator-by-operator path.  Real g-buffer of the 512^2 frames, masked to the covered pixels, with the
+    reference's two gradient hooks (mlptexture.py:72-77: x128 on the table, /128 x128 = 1 on the position)."""
+    from gshell_amd.render.mlptexture import MLPTexture3D
+    from oracle import pipeline_oracle as pl
+    s = scene
+    rast_ref, _ = ro.rast_from_ids(s['clip_c'], s['tri_c'], s['ids_ref'])
+    gb_pos = ro.interpolate(s['mesh'].v_pos.detach().cpu()[None], rast_ref, s['tri_c'])
+    mask = (s['ids_ref'] >= 0).float()
+    gen = torch.Generator().manual_seed(6)
+    noise = torch.randn(2, H, W, 3, generator=gen) * 0.01
+    lo, hi = gb_pos[mask > 0].min(0).values - 0.02, gb_pos[mask > 0].max(0).values + 0.02
+    aabb = (lo.to(DEV), hi.to(DEV))
+    mn = torch.tensor([0, 0, 0, 0, 0.08, 0], dtype=torch.float32, device=DEV)
+    mx = torch.tensor([1, 1, 1, 0.3, 1, 1], dtype=torch.float32, device=DEV)
+    torch.manual_seed(7)
+    tex = MLPTexture3D(aabb, channels=6, min_max=[mn, mx])
+    with torch.no_grad():
+        tex.encoder.params.mul_(3000.0)
+    go = torch.randn(2, 2, H, W, 6, generator=gen) * mask[None, ..., None]
+    p_d = gb_pos.to(DEV).requires_grad_(True)
+    a, b = tex.sample_many([p_d + noise.to(DEV), p_d], mask.to(DEV))
+    ((a * go[0].to(DEV)).sum() + (b * go[1].to(DEV)).sum()).backward()
+    # oracle
+    lin = [m for m in tex.net.net if isinstance(m, torch.nn.Linear)]
+    weights = [m.weight.detach().cpu().clone().requires_grad_(True) for m in lin]
+    params = tex.encoder.params.detach().cpu().clone().requires_grad_(True)
+    tex_o = pl.TextureOracle((lo, hi), tex.encoder.cfg, params, weights, mn.cpu(), mx.cpu())
+    p_c = gb_pos.clone().requires_grad_(True)
+    cov = mask > 0
+    # the oracle evaluates the covered rows only (the others are masked out of the loss on both sides)
+    a_o = tex_o.sample((p_c + noise)[cov])
+    b_o = tex_o.sample(p_c[cov])
+    ((a_o * go[0][cov]).sum() + (b_o * go[1][cov]).sum()).backward()
+    for name, x, y in (("jittered", a.detach().cpu()[cov], a_o.detach()), ("plain", b.detach().cpu()[cov], b_o.detach())):
+        err = (x - y).abs().max(-1).values
+        print(f"\n  tet-res{s['res']} fused field, {name}: {int(cov.sum())} rows, max abs err {float(err.max()):.2e}, rows outside 1e-4: {int((err > 1e-4).sum())}")
+        assert int((err > 1e-4).sum()) == 0
+    pairs = [("hash-grid table (x128 hook)", tex.encoder.params.grad.cpu(), params.grad * 128.0)]
+    pairs += [(f"texture MLP weight {i}", m.weight.grad.cpu(), w.grad) for i, (m, w) in enumerate(zip(lin, weights))]
+    for name, x, y in pairs:
+        e = float((x - y).abs().max() / y.abs().max())
+        print(f"  gradient {name}: max err / max {e:.2e}, rel L2 {float((x - y).norm() / y.norm()):.2e}")
+        assert e <= 1e-4, (name, e)
+    # d / d position: piecewise-trilinear features -> the slope JUMPS at the cell faces of every level (cells of 1/4096 of the box at the finest):
+    # a surface point within float32 round-off of a face takes either slope.  Rows are compared where both sides sit in the same cells.
+    gx, gr = p_d.grad.cpu()[cov], p_c.grad[cov]
+    bad = ((gx - gr).abs() > 1e-4 * gr.abs() + 1e-5 * float(gr.abs().max())).any(-1)
+    print(f"  position gradient: rows outside {int(bad.sum())} of {int(cov.sum())}; rel L2 over the rest {float((gx[~bad] - gr[~bad]).norm() / gr[~bad].norm()):.2e}")
+    assert int(bad.sum()) <= max(8, int(cov.sum()) // 5000)
+    assert float((gx[~bad] - gr[~bad]).norm() / gr[~bad].norm()) <= 1e-5
+    assert float(p_d.grad.cpu()[~cov].abs().max()) == 0.0
