@@ -555,6 +555,9 @@ __global__ void __launch_bounds__(256) k_encode_bin_reduce(GridMeta M, EncArgs A
     const int b = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = min(A.bin_count[b], A.bin_cap);
     if (n == 0u) return;                                    // (a counter that overflowed is > 0, so it is reset below)
+    // records that did not fit took the atomic path: counted in the word after the last bin's counter (never reset here), so that a caller
+    // can see that its capacity is too small for its frames
+    if (tid == 0 && A.bin_count[b] > A.bin_cap) atomicAdd(&A.bin_count[gridDim.x], A.bin_count[b] - A.bin_cap);
     int l = 0;
     for (int k = 0; k < M.n_levels; ++k)
         if (A.bin_base[k] >= 0 && A.bin_base[k] <= b) l = k;

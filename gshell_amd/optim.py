@@ -43,10 +43,17 @@ class HipAdam(torch.optim.Adam):
                     st["_host_step"] = None
                 if st.get("_host_step") is None:          # fresh state or one loaded from a checkpoint: read the counter once
                     st["_host_step"] = float(st["step"])
+                    # a checkpoint written by torch's default (non-fused) Adam keeps `step` on the CPU: the kernel writes the counter through
+                    # this pointer, so it has to be a float32 scalar on the parameter's device
+                    if st["step"].device != p.device or st["step"].dtype != torch.float32:
+                        st["step"] = st["step"].detach().to(device=p.device, dtype=torch.float32)
+                    for name in ("exp_avg", "exp_avg_sq"):
+                        if st[name].device != p.device or st[name].dtype != torch.float32:
+                            st[name] = st[name].detach().to(device=p.device, dtype=torch.float32).contiguous()
                 st["_host_step"] += 1.0
                 if not (p.is_contiguous() and st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()):
                     raise _lib.GShellHipError("HipAdam: parameters and their moments must be contiguous")
-                key = (p.device, group["betas"], group["eps"], st["_host_step"])
+                key = (p.device, tuple(group["betas"]), group["eps"], st["_host_step"])          # a loaded state may carry betas as a list
                 by_key.setdefault(key, []).append((p, p.grad if p.grad.is_contiguous() else p.grad.contiguous(), st, float(group["lr"])))
         L = _lib.lib()
         for (dev, betas, eps, step_value), items in by_key.items():

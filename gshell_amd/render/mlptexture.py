@@ -83,22 +83,41 @@ class _TexMlpFn(torch.autograd.Function):
 
 
 BINNED_TABLE_GRAD = True   # _FieldFn backward: hashed levels' table gradient through per-bin record arrays (gs_hashgrid_encode_bwd_binned), no atomics
-BIN_COVERAGE = 0.2         # bin capacity is sized for this fraction of the rows having mask > 0 (x1.25 slack); fuller frames spill to the atomic path
+BIN_COVERAGE = 0.2         # without a hint: bin capacity for this fraction of the rows having mask > 0; fuller frames spill to the atomic path
+ACTIVE_ROWS_HINT = [None]  # rows with mask > 0 of the coming call, when the caller knows them on the host (render.shade: the covered pixels x 2
+                           # coordinate sets -- the shader's pixel list is synchronised anyway): the capacity then follows the frame
 _bin_scratch = {}
 
 
 def _bins(cfg, N, device):
-    """(counters, records, capacity) of the binned table gradient, cached per device and size (the reducer leaves the counters zero)."""
+    """(counters [+ spill word], records, capacity) of the binned table gradient, cached per device.  The capacity only grows (in steps of
+    1.5x, so that alternating frame sizes do not reallocate): 1.25 x the uniform share of the hinted active rows."""
     nb = int(_lib.lib().gs_hashgrid_bin_count(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4])))
     if nb <= 0:
         return None
     per_level = max(1, (1 << cfg[2]) // int(_lib.lib().gs_hashgrid_bin_entries()))      # bins of a full-size (hashed) level
-    cap = int(1.25 * BIN_COVERAGE * N * 8 / per_level) + 1024
-    key = (str(device), nb, cap)
-    if key not in _bin_scratch:
-        _bin_scratch.clear()
-        _bin_scratch[key] = (torch.zeros(nb, dtype=torch.int32, device=device), torch.empty(nb * cap * 3, dtype=torch.int32, device=device), cap)
+    active = ACTIVE_ROWS_HINT[0] if ACTIVE_ROWS_HINT[0] is not None else BIN_COVERAGE * N
+    want = int(1.25 * min(active, N) * 8 / per_level) + 1024
+    key = (str(device), nb)
+    cur = _bin_scratch.get(key)
+    if cur is None or cur[2] < want:
+        cap = want if cur is None else max(want, int(1.5 * cur[2]))
+        spilled = 0 if cur is None else int(cur[0][nb])
+        _bin_scratch.pop(key, None)
+        counters = torch.zeros(nb + 1, dtype=torch.int32, device=device)
+        counters[nb] = spilled
+        _bin_scratch[key] = (counters, torch.empty(nb * cap * 3, dtype=torch.int32, device=device), cap)
     return _bin_scratch[key]
+
+
+def bin_spill_count():
+    """records of the binned table gradient that did not fit their bin and took the atomic path, summed over the process (one host sync)"""
+    return sum(int(v[0][-1]) for v in _bin_scratch.values())
+
+
+def free_bin_scratch():
+    """release the cached record arrays (trainer teardown; ~0.5 GB at 4 x 512^2)"""
+    _bin_scratch.clear()
 
 
 COMPACT_ROWS = True      # _FieldFn: texture MLP over a device-compacted list of the masked rows (False: masked waves over all rows)

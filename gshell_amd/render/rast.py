@@ -320,14 +320,18 @@ class _AntialiasFn(torch.autograd.Function):
 
 class _AntialiasInplaceFn(torch.autograd.Function):
     """antialias of a frame the caller OWNS, in place (gs_aa_apply_*_inplace): only the silhouette pixels are read and written instead of two
-    passes over the whole [B,H,W,C] frame each way.  Bit-identical to _AntialiasFn.  The incoming gradient is updated in place as well: it has
-    exactly this node as its consumer (the engine hands a node either its single producer's tensor or its own accumulation buffer)."""
+    passes over the whole [B,H,W,C] frame each way.  Bit-identical to _AntialiasFn.  The incoming gradient is updated in place as well WHEN it
+    the caller vouches that it is this node's alone (`grad_exclusive`).  An incoming gradient can be shared: AddBackward hands ONE tensor to
+    both operands, a tensor hook may keep what it is shown.  render_mesh can vouch: the frame's direct consumers are `frame_sums` (its
+    backward allocates what it returns) and VIEWS of the frame (split / slice backward allocate a fresh full frame), and several consumers
+    are summed into the engine's own buffer.  Every other caller gets a copy of the gradient first."""
 
     @staticmethod
-    def forward(ctx, color, pos, rast, tri, topo):
+    def forward(ctx, color, pos, rast, tri, topo, grad_exclusive=False):
         L = _lib.lib()
         if not (color.is_cuda and color.dtype == torch.float32 and color.is_contiguous()):
             raise _lib.GShellHipError("in-place antialias needs a contiguous fp32 frame in HBM")
+        ctx.grad_exclusive = bool(grad_exclusive)
         B, H, W, C = color.shape
         alpha = aa_analyze(rast, pos, tri, topo)
         saved = torch.empty_like(color)          # only the entries of modified pixels are ever touched
@@ -345,6 +349,9 @@ class _AntialiasInplaceFn(torch.autograd.Function):
         B, H, W, C = out.shape
         need_pos = ctx.needs_input_grad[1]
         g = g_out if (g_out.is_contiguous() and g_out.dtype == torch.float32) else g_out.contiguous().float()
+        if g is g_out and not ctx.grad_exclusive:
+            g = g_out.clone()
+            INPLACE_GRAD_COPIES[0] += 1
         g_scratch = torch.empty_like(g)
         g_alpha = torch.empty_like(alpha) if need_pos else None
         g_pos = None
@@ -356,7 +363,10 @@ class _AntialiasInplaceFn(torch.autograd.Function):
                 check(L.gs_aa_analyze_bwd(ptr(pos_c), c_int64(pos_c.shape[0]), c_int64(pos_c.shape[1]), ptr(tri), c_int64(tri.shape[0]), ptr(opp),
                                           ptr(rast_c), c_int64(H), c_int64(W), ptr(alpha), ptr(g_alpha), ptr(g_pos), stream()),
                       "gs_aa_analyze_bwd")
-        return g, g_pos, None, None, None
+        return g, g_pos, None, None, None, None
+
+
+INPLACE_GRAD_COPIES = [0]      # how often the in-place antialias backward had to copy its incoming gradient (0 on the training path)
 
 
 _aa_cache = {"key": None, "refs": None, "topo": None, "alpha": None}
@@ -384,9 +394,10 @@ def antialias_cache_clear():
     _aa_cache.update(key=None, refs=None, topo=None, alpha=None)
 
 
-def antialias_stacked(colors, rast, pos, tri, topo=None, inplace=False):
+def antialias_stacked(colors, rast, pos, tri, topo=None, inplace=False, grad_exclusive=False):
     """Antialias several [B,H,W,Ci] buffers with ONE analysis and ONE apply launch (channels stacked).  `inplace` (a single buffer that the
-    caller owns and hands over): the frame is updated in place, only its silhouette pixels are touched."""
+    caller owns and hands over): the frame is updated in place, only its silhouette pixels are touched.  `grad_exclusive`: the caller
+    guarantees that the gradient arriving for the result is referenced by nobody else, so the backward may update it in place too."""
     if tri.shape[0] == 0:
         return list(colors)
     if topo is None:
@@ -394,7 +405,7 @@ def antialias_stacked(colors, rast, pos, tri, topo=None, inplace=False):
     if len(colors) == 1:          # (torch.cat / torch.split of ONE tensor still copy it, forward and backward: 2 x 190 MB at 4 x 512^2 x 45)
         c = colors[0]
         if inplace and c.is_cuda and c.dtype == torch.float32 and c.is_contiguous() and not c.is_leaf:
-            return [_AntialiasInplaceFn.apply(c, pos, rast, tri, topo)]
+            return [_AntialiasInplaceFn.apply(c, pos, rast, tri, topo, grad_exclusive)]
         return [_AntialiasFn.apply(c, pos, rast, tri, topo, None)]
     sizes = [c.shape[-1] for c in colors]
     out = _AntialiasFn.apply(torch.cat(colors, dim=-1), pos, rast, tri, topo, None)

@@ -231,6 +231,11 @@ def shade(FLAGS, rast, gb_depth, gb_pos, gb_geometric_normal, gb_normal, gb_tang
                                                            rnd_seed=None if FLAGS.decorrelated else rnd_seed, shadow_scale=shadow_scale,
                                                            **extra, **_view_map(FLAGS))
         rnd_seed += 1
+        if ou.last_covered_pixels is not None:
+            # the texture field's backward sizes the bins of its table gradient by the rows that carry gradient: the covered pixels of this
+            # frame (known on the host since the shader's pixel list) x the two coordinate sets sampled above
+            from . import mlptexture as _mt
+            _mt.ACTIVE_ROWS_HINT[0] = 2 * int(ou.last_covered_pixels)
         if fused:
             # everything below (demodulated filtering weights, kd * (1 - metalness), the buffer dictionary with its alpha
             # channels) happens inside gs_shade_assemble, called by render_mesh once the background is known
@@ -439,7 +444,10 @@ def render_mesh(FLAGS, ctx, mesh, mtx_in, view_pos, lgt, resolution, spp=1, num_
         sizes = [4] * 11 + ([1] if pf.msdf_image is not None else [])
         comp = _ShadeAssembleFn.apply(rast, pf.tex, pf.texj, pf.n_in, pf.n_jit, pf.mask_tap, pf.n_shade, pf.n_geo, pf.depth, pf.dif, pf.spc,
                                       pf.msdf_image, background[..., 0:3])
-        aa = dr.antialias_stacked([comp], rast, v_pos_clip, tri, inplace=True)[0]        # comp is this function's own: updated in place
+        # comp is this function's own: updated in place.  Its gradient is exclusive too: `aa` leaves this function only as `out_buffers.stacked`
+        # (consumed by regularizer.frame_sums, whose backward allocates what it returns) and as the split views below, whose backward
+        # (cat of the parts' gradients) allocates a fresh frame; several consumers are summed into the engine's own buffer
+        aa = dr.antialias_stacked([comp], rast, v_pos_clip, tri, inplace=True, grad_exclusive=True)[0]
         out_list = list(torch.split(aa, sizes, dim=-1))
         buffers = None
     else:

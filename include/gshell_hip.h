@@ -438,8 +438,9 @@ int gs_hashgrid_encode_bwd(int n_levels, int F, int log2_T, int base_res, float 
  * table is cut into bins of 4096 entries, k_encode_bwd writes (entry, d pair) records into per-bin arrays of `bin_capacity`
  * 12-byte records (one returning atomic per workgroup, level and bin reserves the run), a second launch sums every bin in LDS
  * and adds it to g_params.  A reservation past `bin_capacity` takes the atomic path, so the result is correct for ANY capacity;
- * uniform hashing puts ~ 8 * (rows with mask > 0) / 128 records in a bin.  `bin_count` [gs_hashgrid_bin_count()] uint32, zero
- * before the first call (the reducer leaves it zero); `bin_records` [bins * bin_capacity * 12 bytes] scratch. */
+ * uniform hashing puts ~ 8 * (rows with mask > 0) / 128 records in a bin.  `bin_count` [gs_hashgrid_bin_count() + 1] uint32, zero
+ * before the first call (the reducer leaves the per-bin words zero; the LAST word accumulates the number of records that spilled to
+ * the atomic path and is never reset by the library); `bin_records` [bins * bin_capacity * 12 bytes] scratch. */
 int64_t gs_hashgrid_bin_count(int n_levels, int F, int log2_T, int base_res, float per_level_scale);
 int64_t gs_hashgrid_bin_entries(void);     /* table entries per bin */
 int gs_hashgrid_encode_bwd_binned(int n_levels, int F, int log2_T, int base_res, float per_level_scale,

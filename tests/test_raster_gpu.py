@@ -293,3 +293,42 @@ def test_inplace_antialias_equals_the_streaming_one_bit_for_bit(kind, C):
     assert torch.equal(res[0][1], res[1][1])
     scale = float(res[0][2].abs().max())
     assert scale > 0 and float((res[0][2] - res[1][2]).abs().max()) <= 1e-5 * scale
+
+
+def test_inplace_antialias_backward_does_not_corrupt_a_gradient_someone_else_holds():
+    """the in-place backward used to overwrite its incoming gradient tensor unconditionally.  A consumer may hand on a tensor that
+    somebody else also holds (AddBackward gives ONE tensor to both operands; a tensor hook can keep what it is shown): unless the caller
+    vouches for exclusivity (`grad_exclusive`, render_mesh does) the gradient is copied first.  Either way the results equal the
+    out-of-place kernels'."""
+    from gshell_amd.render import rast as dr
+    verts, tri = _scene("sheet", 4)
+    pos, _, _ = _clip(verts, 2, first=1)
+    H, W, C = 80, 80, 7
+    tri_d = torch.tensor(tri, device=DEV)
+    rast_d, _ = dr.rasterize(None, pos.to(DEV), tri_d, (H, W))
+    g = torch.Generator().manual_seed(21)
+    color = torch.rand(2, H, W, C, generator=g)
+    wgt = torch.rand(2, H, W, C, generator=g).to(DEV)
+    res = {}
+    for mode in ("streaming", "inplace", "inplace+exclusive", "inplace+shared"):
+        c = color.to(DEV).requires_grad_(True)
+        p = pos.to(DEV).requires_grad_(True)
+        other = torch.zeros(2, H, W, C, device=DEV, requires_grad=True)
+        frame = c * 1.0
+        before = dr.INPLACE_GRAD_COPIES[0]
+        out = dr.antialias_stacked([frame], rast_d.detach(), p, tri_d, inplace=mode != "streaming", grad_exclusive=mode == "inplace+exclusive")[0]
+        kept = []
+        if mode == "inplace+shared":          # AddBackward hands the SAME gradient tensor to `out` and to `other`; a hook keeps it as well
+            out.register_hook(lambda t: kept.append(t))
+            y = out + other
+            y.backward(wgt)
+        else:
+            (out * wgt).sum().backward()
+        res[mode] = (c.grad.clone(), p.grad.clone(), dr.INPLACE_GRAD_COPIES[0] - before, other.grad, kept)
+    for mode in ("inplace", "inplace+exclusive", "inplace+shared"):
+        assert torch.equal(res[mode][0], res["streaming"][0]), mode
+        scale = float(res["streaming"][1].abs().max())
+        assert float((res[mode][1] - res["streaming"][1]).abs().max()) <= 1e-5 * scale, mode
+    assert res["inplace"][2] == 1 and res["inplace+shared"][2] == 1 and res["inplace+exclusive"][2] == 0
+    assert torch.equal(res["inplace+shared"][3], wgt), "the gradient shared with the other operand of the addition was overwritten"
+    assert torch.equal(res["inplace+shared"][4][0], wgt), "the gradient a tensor hook kept was overwritten"
