@@ -120,6 +120,33 @@ __device__ __forceinline__ float bvh_half8(const uint4& g, int i) {
     return (float)c.h[i & 1];
 }
 
+// 8-bit mask of the children of internal node c whose (half-float, outward-rounded) boxes the ray pierces at some t >= 0
+__device__ __forceinline__ uint32_t bvh_children_hit(const BvhView& bv, const BvhRay& r, int32_t c) {
+    // groups of the record: 0..2 = lo.x lo.y lo.z, 3..5 = hi.x hi.y hi.z; near plane of axis a = group a + 3 [d_a < 0]
+    const uint4* rec = bv.nodes + (int64_t)c * 6;
+    const int sx = (int)(r.sel & 1u) * 3, sy = (int)((r.sel >> 1) & 1u) * 3, sz = (int)((r.sel >> 2) & 1u) * 3;
+    const uint4 nx = rec[sx], ny = rec[1 + sy], nz = rec[2 + sz];
+    const uint4 fx = rec[3 - sx], fy = rec[4 - sy], fz = rec[5 - sz];
+    uint32_t m2 = 0u;
+#pragma unroll
+    for (int j = 0; j < BVH_W; ++j) {
+        const float tnx = __builtin_fmaf(bvh_half8(nx, j), r.ix, r.nox), tfx = __builtin_fmaf(bvh_half8(fx, j), r.ix, r.nox);
+        const float tny = __builtin_fmaf(bvh_half8(ny, j), r.iy, r.noy), tfy = __builtin_fmaf(bvh_half8(fy, j), r.iy, r.noy);
+        const float tnz = __builtin_fmaf(bvh_half8(nz, j), r.iz, r.noz), tfz = __builtin_fmaf(bvh_half8(fz, j), r.iz, r.noz);
+        // an empty slot has lo > hi on every axis: its near plane lies behind its far plane for either sign of d -> tf < tn
+        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+        const float tf = fminf(fminf(tfx, tfy), tfz);
+        m2 |= (tf >= tn) ? (1u << j) : 0u;
+    }
+    return m2;
+}
+
+// does the box of child k (0..7) of internal node c contain the point?  (an empty slot, lo > hi, contains nothing)
+__device__ __forceinline__ bool bvh_child_contains(const BvhView& bv, int32_t c, int k, float x, float y, float z) {
+    const _Float16* h = reinterpret_cast<const _Float16*>(bv.nodes + (int64_t)c * 6);
+    return (float)h[k] <= x && x <= (float)h[24 + k] && (float)h[8 + k] <= y && y <= (float)h[32 + k] && (float)h[16 + k] <= z && z <= (float)h[40 + k];
+}
+
 // visits the lowest pending child of r.node.  Returns BVH_CONTINUE / BVH_MISS (nothing pending) / BVH_HIT.
 template <bool STATS = false>
 __device__ __forceinline__ int bvh_step(const BvhView& bv, BvhRay& r, int32_t* st, int nthreads, int* n_nodes = nullptr, int* n_tris = nullptr) {
@@ -138,22 +165,7 @@ __device__ __forceinline__ int bvh_step(const BvhView& bv, BvhRay& r, int32_t* s
         if (tri_hit(bvh_as_float4(q0), bvh_as_float4(q1), bvh_as_float4(q2), r.ox, r.oy, r.oz, r.dx, r.dy, r.dz)) return BVH_HIT;
     } else {
         if (STATS) ++*n_nodes;
-        // groups of the record: 0..2 = lo.x lo.y lo.z, 3..5 = hi.x hi.y hi.z; near plane of axis a = group a + 3 [d_a < 0]
-        const uint4* rec = bv.nodes + (int64_t)c * 6;
-        const int sx = (int)(r.sel & 1u) * 3, sy = (int)((r.sel >> 1) & 1u) * 3, sz = (int)((r.sel >> 2) & 1u) * 3;
-        const uint4 nx = rec[sx], ny = rec[1 + sy], nz = rec[2 + sz];
-        const uint4 fx = rec[3 - sx], fy = rec[4 - sy], fz = rec[5 - sz];
-        uint32_t m2 = 0u;
-#pragma unroll
-        for (int j = 0; j < BVH_W; ++j) {
-            const float tnx = __builtin_fmaf(bvh_half8(nx, j), r.ix, r.nox), tfx = __builtin_fmaf(bvh_half8(fx, j), r.ix, r.nox);
-            const float tny = __builtin_fmaf(bvh_half8(ny, j), r.iy, r.noy), tfy = __builtin_fmaf(bvh_half8(fy, j), r.iy, r.noy);
-            const float tnz = __builtin_fmaf(bvh_half8(nz, j), r.iz, r.noz), tfz = __builtin_fmaf(bvh_half8(fz, j), r.iz, r.noz);
-            // an empty slot has lo > hi on every axis: its near plane lies behind its far plane for either sign of d -> tf < tn
-            const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-            const float tf = fminf(fminf(tfx, tfy), tfz);
-            m2 |= (tf >= tn) ? (1u << j) : 0u;
-        }
+        const uint32_t m2 = bvh_children_hit(bv, r, c);
         if (m2 != 0u) {
             if (mask != 0u) {
                 st[min(r.sp, BVH_STACK - 1) * nthreads] = (int32_t)(((uint32_t)r.node << 8) | mask);

@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "../../include/gshell_hip.h"
 #include "bvh.hpp"
@@ -896,6 +897,13 @@ __global__ void __launch_bounds__(256) k_shade_trace(ShadeArgs A, int64_t n_rays
         A.vis_bits[(chunk0 >> 6) + lane] = (uint64_t)s_vis[wave][2 * lane] | ((uint64_t)s_vis[wave][2 * lane + 1] << 32);
 }
 
+// Tried and removed (round 4, profiles/r04_trace_variants.txt): a SHARED-ORIGIN variant for 2 n^2 % 64 == 0 -- the 64 rays a wave stages belong
+// to one pixel, so the nodes whose box contains that origin (about 7 of the ~15 a miss visits) were found once per batch (lane k tests
+// child k) and then slab-tested by all lanes in lock step, the divergent traversal starting below them from per-ray child masks (12 bytes per
+// ray staged in LDS).  Visibility bits identical, but 5.40 ms against 3.58 for the forward family (110 VGPRs = 4 waves / SIMD; capped to 5 / 6
+// waves: 6.7 / 7.6 ms with spills): the per-batch chain (K list: ~8 dependent record fetches; then ~8 uniform-address records per lane)
+// is pure latency that four waves do not cover, and even free of latency the lock-step part still costs ~900 instructions per ray against
+// the ~1900 it replaces -- a ceiling of ~18 % for the kernel.
 // Pass 3 (fwd): per-pixel sum of V * contribution
 __global__ void __launch_bounds__(256) k_shade_accumulate(ShadeArgs A) {
     const int G = A.G;
