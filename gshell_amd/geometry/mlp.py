@@ -579,14 +579,22 @@ def row_sparse_backward(net, x, g_y, need_x):
         _watch_rows_overflow(net, count)
         saved = _SavedChain(net, 1, x.detach().contiguous(), rows, cap, n_dev=count)
         return g_x, saved.backward(g_rows, g_x)
-    rows = torch.nonzero(g != 0).reshape(-1).int()                  # one host sync (the count sizes the saved planes)
-    n = int(rows.numel())
+    # rows with gradient: compacted by the library's own three launches (ascending indices + their values), ONE host sync for the count that
+    # sizes the saved planes (torch.nonzero + gather + scatter were ~11 launches)
+    L = _lib.lib()
+    N = g.numel()
+    rows_all = torch.empty(N, dtype=torch.int32, device=x.device)
+    g_all = torch.zeros(N + 256, dtype=torch.float32, device=x.device)          # zero tail: the chain kernels read whole 128-row tiles
+    count = torch.empty(2, dtype=torch.int64, device=x.device)
+    scratch = torch.empty(int(L.gs_compact_rows_scratch_bytes(c_int64(N))) // 4 + 4, dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(L.gs_compact_rows(ptr(g), c_int64(N), c_int64(N), ptr(scratch), ptr(rows_all), ptr(g_all), ptr(count), stream()), "gs_compact_rows")
+    n = int(count[0])                                               # the host sync
     if n == 0:
         return g_x, torch.zeros(sum(p.numel() for p in net.parameters()), dtype=torch.float32, device=x.device)
-    saved = _SavedChain(net, 1, x.detach().contiguous(), rows, n)
-    g_rows = torch.zeros((saved.Rpad,), dtype=torch.float32, device=x.device)
-    g_rows[:n] = g[rows.long()]
-    return g_x, saved.backward(g_rows, g_x)
+    saved = _SavedChain(net, 1, x.detach().contiguous(), rows_all[:n], n)
+    assert saved.Rpad <= g_all.numel()
+    return g_x, saved.backward(g_all[:saved.Rpad], g_x)
 
 
 def _watch_rows_overflow(net, count):
