@@ -92,7 +92,7 @@ struct BvhRay {
     int32_t node;    // -1 = virtual parent of the root
     uint32_t mask;   // children of `node` not visited yet (never 0 between steps)
     int sp;
-    uint32_t sel;    // bit k: direction component k is negative -> the near plane of axis k is the child's hi plane
+    uint32_t sel;    // six 3-bit group indices of a node record: near x, y, z, far x, y, z (near plane of an axis = the child's hi plane when d < 0)
 };
 
 // false = the direction is degenerate (zero / NaN): the ray hits nothing
@@ -104,7 +104,9 @@ __device__ __forceinline__ bool bvh_ray_init(BvhRay& r, float ox, float oy, floa
     r.iy = fabsf(dy) > 1e-18f ? __fdiv_rn(1.0f, dy) : copysignf(1e18f, dy);
     r.iz = fabsf(dz) > 1e-18f ? __fdiv_rn(1.0f, dz) : copysignf(1e18f, dz);
     r.nox = -ox * r.ix; r.noy = -oy * r.iy; r.noz = -oz * r.iz;
-    r.sel = (r.ix < 0.f ? 1u : 0u) | (r.iy < 0.f ? 2u : 0u) | (r.iz < 0.f ? 4u : 0u);
+    // the six 16-byte groups of a node record this ray reads as near x, y, z and far x, y, z planes (3 bits each): group a + 3 [d_a < 0] / a + 3 [d_a >= 0]
+    const uint32_t nx = r.ix < 0.f ? 3u : 0u, ny = r.iy < 0.f ? 4u : 1u, nz = r.iz < 0.f ? 5u : 2u;
+    r.sel = nx | (ny << 3) | (nz << 6) | ((3u - nx) << 9) | ((5u - ny) << 12) | ((7u - nz) << 15);
     r.node = -1;
     r.mask = 1u;
     r.sp = 0;
@@ -122,11 +124,14 @@ __device__ __forceinline__ float bvh_half8(const uint4& g, int i) {
 
 // 8-bit mask of the children of internal node c whose (half-float, outward-rounded) boxes the ray pierces at some t >= 0
 __device__ __forceinline__ uint32_t bvh_children_hit(const BvhView& bv, const BvhRay& r, int32_t c) {
-    // groups of the record: 0..2 = lo.x lo.y lo.z, 3..5 = hi.x hi.y hi.z; near plane of axis a = group a + 3 [d_a < 0]
-    const uint4* rec = bv.nodes + (int64_t)c * 6;
-    const int sx = (int)(r.sel & 1u) * 3, sy = (int)((r.sel >> 1) & 1u) * 3, sz = (int)((r.sel >> 2) & 1u) * 3;
-    const uint4 nx = rec[sx], ny = rec[1 + sy], nz = rec[2 + sz];
-    const uint4 fx = rec[3 - sx], fy = rec[4 - sy], fz = rec[5 - sz];
+    // groups of the record: 0..2 = lo.x lo.y lo.z, 3..5 = hi.x hi.y hi.z; near plane of axis a = group a + 3 [d_a < 0].
+    // Addresses as UNIFORM base + 32-bit lane offset (record c at byte 96 c; the near / far group of an axis 48 bytes apart, chosen by
+    // the direction's signs once per ray, bvh_ray_init): a multiply + six (bit-field extract, shift-add) pairs -- 64-bit pointer arithmetic per group was ~36 of the ~140
+    // instructions of a node visit (the kernel is bound by instruction issue).
+    const char* base = reinterpret_cast<const char*>(bv.nodes);
+    const uint32_t o = (uint32_t)c * 96u;
+    auto group = [&](int k) { return *reinterpret_cast<const uint4*>(base + (size_t)(o + (((r.sel >> (3 * k)) & 7u) << 4))); };
+    const uint4 nx = group(0), ny = group(1), nz = group(2), fx = group(3), fy = group(4), fz = group(5);
     uint32_t m2 = 0u;
 #pragma unroll
     for (int j = 0; j < BVH_W; ++j) {

@@ -812,7 +812,7 @@ constexpr int TRACE_CHUNK = 1024;  // rays per wave
 #define TRACE_REFILL 16               // refill when at least this many lanes are idle
 #endif
 
-__global__ void __launch_bounds__(256) k_shade_trace(ShadeArgs A, int64_t n_rays, int rays_per_pixel) {
+__global__ void __launch_bounds__(256, 6) k_shade_trace(ShadeArgs A, int64_t n_rays, int rays_per_pixel) {
     __shared__ int32_t stack[BVH_STACK * 256];
     __shared__ float s_ray[4][6][64];
     __shared__ int32_t s_id[4][64];
