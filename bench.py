@@ -176,7 +176,7 @@ def main():
             dt3, _ = timed(a.schedule_it, 4, a.extra_steps, tgts=one, gb=8)
             side["configs3_global_batch_8"] = {"ms_per_step": round(dt3 / a.extra_steps * 1e3, 3), "value": round(8 * H * W * a.extra_steps / dt3 / 1e6, 4),
                                                "iters_per_sec": round(a.extra_steps / dt3, 4), "scaling": "strong", "global_batch": 8, "views_per_gpu": 1, "steps": a.extra_steps,
-                                               "what": "BASELINE.json configs[3]: tet-res256, global batch 8 over 8 GPUs, 1 view of 512^2 per GPU"}
+                                               "what": f"BASELINE.json configs[3] partitioning: tet-res{a.res}, global batch 8 over 8 GPUs, 1 view of {H}^2 per GPU"}
     if _mlp.FALLBACKS:
         raise SystemExit(f"bench.py: the SDF network left the HIP kernels during the run ({_mlp.FALLBACKS}); no number is reported for a torch path")
     if rank == 0:
