@@ -37,11 +37,30 @@ class _ConstantMaterial(torch.nn.Module):
 
 @pytest.mark.parametrize("iteration,seed", [(500, 23), (1500, 5)])
 def test_config0_tick_and_every_parameter_gradient_match_the_oracle_chain(iteration, seed):
+    _tick_chain("tets", 64, iteration, seed)
+
+
+@pytest.mark.parametrize("open_reg", [False, True])
+def test_flexicubes_tick_and_every_parameter_gradient_match_the_oracle_chain(open_reg):
+    """The same chain for the G-FlexiCubes geometry (BASELINE configs[4]'s extractor, res 32: 35 937 grid vertices, 32 768 cubes): SDF network
+    -> oracle/flexi_oracle.extract (pinned to goldens minted from the real gshell_flexicubes.py) -> render -> `tick` + the L_dev regulariser
+    x 0.25 (gshell_flexicubes_geometry.py:358), with the per-cube weights among the parameters.
+
+    open_reg: the mSDF "open" Huber term (tick :330-336) sums over EVERY entry of the augmented mSDF vector, i.e. also over the boundary
+    vertices of edges whose two dual vertices lie on the same side of the cut: their value u_a j_a + u_b j_b, j = (u_b, -u_a) / (u_b - u_a), is
+    analytically 0 but its gradient +-c u / (u_b - u_a) is not, and on a smooth mSDF field u_b - u_a is a difference of nearly equal float32
+    sums.  That part of d loss / d msdf and d loss / d weights is round-off noise in the reference's own formula -- the float32 and float64
+    runs of the ORACLE differ by O(1) there (printed) -- so with the term on, those two tensors are held to 4 x that floor, and with it off
+    (False) to 1e-4 like everything else."""
+    _tick_chain("flexicubes", 32, 500, 31, None if open_reg else dict(msdf_reg_open_scale=0.0))
+
+
+def _tick_chain(kind, res, iteration, seed, flag_overrides=None):
     from gshell_amd import workload
     from gshell_amd.geometry.mlp import MLP
     from gshell_amd.render import optixutils as ou, render
     torch.manual_seed(0)
-    tr = workload.build(res=64, n_samples=1, batch=1, train_res=(H, W), fit_steps=200)
+    tr = workload.build(res=res, n_samples=1, batch=1, train_res=(H, W), fit_steps=200, geometry=kind, **(flag_overrides or {}))
     tr.mat['kd_ks'] = _ConstantMaterial()
     tr.mat_params = list(tr.mat['kd_ks'].parameters())
     with torch.no_grad():      # a probe with structure, so that the light gradient and the importance sampling matter
@@ -91,19 +110,39 @@ def test_config0_tick_and_every_parameter_gradient_match_the_oracle_chain(iterat
     msdf = g.msdf.detach().cpu().clone().requires_grad_(True)
     kdks = tr.mat['kd_ks'].value.detach().cpu().clone().requires_grad_(True)
     light = tr.lgt.base.detach().cpu().clone().requires_grad_(True)
-    v_def = g.verts.cpu() + g.max_displacement * deform
+    max_disp = g.max_displacement.cpu() if torch.is_tensor(g.max_displacement) else g.max_displacement
+    v_def = g.verts.cpu() + max_disp * deform
     sdf = net(v_def)
     sdf.retain_grad()
     off = g.offset.cpu() if torch.is_tensor(g.offset) else g.offset
-    ex = mtets_oracle.extract(v_def + off, sdf, msdf, g.indices.cpu().long(), with_tangents=False)
+    cube_w = None
+    if kind == "flexicubes":
+        from oracle import flexi_oracle as fo
+        cube_w = g.per_cube_weights.detach().cpu().clone().requires_grad_(True)
+        v_ref, c_ref = fo.construct_voxel_grid(res)
+        assert torch.equal(g.indices.cpu(), c_ref)
+        fv, ff, L_dev, fex = fo.extract(v_def + off, sdf, msdf, c_ref, res, cube_w[:, :12], cube_w[:, 12:20], cube_w[:, 20])
+        ex = {'verts_aug': fv, 'faces_aug': ff, 'msdf': fex['msdf'], 'msdf_boundary': fex['msdf_boundary'], 'n_verts_watertight': fex['n_verts_watertight']}
+    else:
+        ex = mtets_oracle.extract(v_def + off, sdf, msdf, g.indices.cpu().long(), with_tangents=False)
     v, f = ex['verts_aug'], ex['faces_aug']
     m = d['imesh']
     assert torch.equal(m.t_pos_idx.cpu(), f), "the extracted topology differs from the oracle chain's"
     dv = float((m.v_pos.detach().cpu() - v.detach()).abs().max())
     print(f"\n  mesh: V_aug={v.shape[0]} T={f.shape[0]}; max |v_pos - oracle| = {dv:.2e}")
-    assert dv <= 2e-6
-    dm = float((d['msdf'].detach().cpu().reshape(-1) - ex['msdf'].detach().reshape(-1)).abs().max())
-    assert dm <= 2e-6, dm
+    used = torch.zeros(v.shape[0], dtype=torch.bool)
+    used[f.reshape(-1)] = True
+    if kind == "flexicubes":
+        # dual vertices are ratios of float-atomic sums, boundary vertices on edges whose end points lie on one side of the cut extrapolate
+        # without bound and are referenced by no face (tests/test_flexi_gpu.py): what a face references must agree
+        dv = float((m.v_pos.detach().cpu() - v.detach())[used].abs().max())
+        assert dv <= 2e-5, dv
+        dm = float((d['msdf'].detach().cpu().reshape(-1) - ex['msdf'].detach().reshape(-1))[used].abs().max())
+        assert dm <= 5e-5, dm
+    else:
+        assert dv <= 2e-6
+        dm = float((d['msdf'].detach().cpu().reshape(-1) - ex['msdf'].detach().reshape(-1)).abs().max())
+        assert dm <= 2e-6, dm
     # The SDF values of the two chains differ by float32 round-off (fp16-pair kernel vs torch: 2e-7), hence the crossing points by 1e-6.
     # The render stages are compared on the SAME mesh values: the oracle's vertices carry the HIP path's values and the oracle chain's
     # graph (straight-through substitution), so every later difference is the render stages' own and every gradient still flows through
@@ -118,6 +157,9 @@ def test_config0_tick_and_every_parameter_gradient_match_the_oracle_chain(iterat
            'sdf': sdf, 'sampled_pts': d['sampled_pts'].detach().cpu()}
     tgt_o = {'img': target['img'].cpu()}
     img_o, _, reg_o, terms = tick_oracle.tick(tr.FLAGS, g.grid_res, net, g.all_edges.cpu().long(), d_o, tgt_o, iteration)
+    if kind == "flexicubes":
+        terms['L_dev'] = L_dev.mean() * 0.25                        # gshell_flexicubes_geometry.py:358
+        reg_o = reg_o + terms['L_dev']
     (img_o + reg_o).backward()
 
     # ---- buffers, pixel by pixel
@@ -161,6 +203,24 @@ def test_config0_tick_and_every_parameter_gradient_match_the_oracle_chain(iterat
     pairs = [(f"sdf_net.{n}", p.grad, dict(net.named_parameters())[n].grad) for n, p in g.sdf_net.named_parameters()]
     pairs += [("deform", g.deform.grad, deform.grad), ("msdf", g.msdf.grad, msdf.grad), ("material", tr.mat['kd_ks'].value.grad, kdks.grad),
               ("light", tr.lgt.base.grad, light.grad)]
+    floor = {}
+    if cube_w is not None:
+        pairs.append(("per_cube_weights", g.per_cube_weights.grad, cube_w.grad))
+        if tr.FLAGS.msdf_reg_open_scale > 0:
+            # float32 vs float64 of the oracle's OWN open-regulariser gradient (see the docstring of the FlexiCubes test)
+            import torch.nn.functional as Fn
+            from oracle import flexi_oracle as fo2
+
+            def open_grads(dt):
+                lv = [t.detach().to(dt).requires_grad_(True) for t in (msdf, cube_w)]
+                _, _, _, e2 = fo2.extract((v_def + off).detach().to(dt), sdf.detach().to(dt), lv[0], c_ref, res, lv[1][:, :12], lv[1][:, 12:20], lv[1][:, 20])
+                eps = torch.tensor([1e-3], dtype=dt)
+                mm = e2['msdf']
+                (tr.FLAGS.msdf_reg_open_scale * (64 / g.grid_res) ** 3 * Fn.huber_loss(mm.clamp(min=-eps).squeeze(), -eps.expand(mm.size(0)), reduction='sum')).backward()
+                return [t.grad.double() for t in lv]
+            g32, g64 = open_grads(torch.float32), open_grads(torch.float64)
+            floor = {"msdf": float((g32[0] - g64[0]).norm() / msdf.grad.double().norm()), "per_cube_weights": float((g32[1] - g64[1]).norm() / cube_w.grad.double().norm())}
+            print(f"  oracle float32 vs float64, open-regulariser gradient relative to the whole gradient: {floor}")
     for name, a, b in (("d/d v_pos (render stages)", m.v_pos.grad, v.grad), ("d/d msdf_aug", d['msdf'].grad, msdf_aug.grad), ("d/d sdf (extraction + sdf regulariser)", d['sdf'].grad, sdf.grad)):
         if a is not None and b is not None:
             a = a.detach().cpu().reshape(b.shape)
@@ -190,6 +250,7 @@ def test_config0_tick_and_every_parameter_gradient_match_the_oracle_chain(iterat
         # of d loss / d v_pos, whose own error (7e-5, 99 % of it in ten vertices, float-atomic order varies it from run to run) they inherit with
         # some cancellation: 1.5e-4; the output bias is one signed sum: + 1e-5 x its condition number
         tol = (1.5e-4 if (name.startswith("sdf_net") or name == "deform") else 1e-4) + (1e-5 * cond_bias if b.numel() == 1 else 0.0)
+        tol = max(tol, 4.0 * floor.get(name, 0.0))
         print(f"  gradient {name}: relative L2 {rel:.2e}, max error / max {mx:.2e}" + (f"  (sum of {sdf.shape[0]} signed terms, cond {cond_bias:.0f}: tol {tol:.1e})" if b.numel() == 1 else ""))
         if rel > tol:
             failures.append((name, rel))
