@@ -159,6 +159,9 @@ def _c_lib():
         import ctypes
         import os
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_c", "raster_c.so")
+        if not os.path.isfile(path):          # a checkout without build(): the checker builds itself (gcc is part of the image on both boxes)
+            import subprocess
+            subprocess.run(["make", "-C", os.path.dirname(os.path.abspath(__file__)), "_c/raster_c.so"], check=False, capture_output=True)
         if not os.path.isfile(path):
             raise RuntimeError(f"{path} is missing: run `make -C oracle` (or __graft_entry__.build())")
         L = ctypes.CDLL(path)
