@@ -1262,6 +1262,13 @@ __device__ __forceinline__ void wgrad16_layer(const WgradArgs& W, int l, __bf16*
     if (tid < D) atomicAdd(W.db[l] + tid, red[tid]);
 }
 
+// Tried and removed (round 4): the same reduction with its phases OVERLAPPED -- the D fragments loaded straight from the planes into registers
+// (8 consecutive rows of one feature are 32 contiguous bytes), an X-only image (51 KB) double-buffered so that slab s + 1 is converted and
+// written BETWEEN the MFMA groups of slab s, every register piece re-requested for slab s + 2 as soon as consumed, one barrier per slab, the
+// loop body branch-free (a conditional around a load makes hipcc wait for ALL outstanding loads in front of every piece: 1.59 ms).  Gradients
+// identical; 1.32 ms per iteration for both passes against 1.25 (the 160 accumulators of the skip layer leave no room for the staging
+// registers: 22 spills), and 1.248 against 1.259 with the skip layer left on this kernel -- no gain: the kernel streams 4.5 GB of fp32
+// planes per iteration at 3.6 TB/s, and it is that stream, not the store / MFMA phase order, that its time follows.
 __global__ void __launch_bounds__(NT, 2) k_h2_wgrad16(WgradArgs W) {
     extern __shared__ __attribute__((aligned(16))) __bf16 smem_b[];
     const int l = blockIdx.y, tid = threadIdx.x;
