@@ -239,7 +239,7 @@ def main():
 
 ROOFLINE_CANDIDATES = {"gs_env_shade_fwd", "gs_sdf_mlp_fwd_h1", "gs_sdf_mlp_fwd_h2", "gs_sdf_mlp_fwd", "gs_sdf_mlp_h2_refine_rows", "gs_mtets_flag_refine_rows",
                        "gs_env_shade_bwd_saved", "gs_hashgrid_encode_bwd", "gs_hashgrid_encode_bwd_binned", "gs_sdf_mlp_h2_wgrad", "gs_sdf_mlp_h2_bwd",
-                       "gs_sdf_mlp_h2_save_fwd", "gs_flexi_vd_bwd", "gs_flexi_vd_fwd"}
+                       "gs_sdf_mlp_h2_save_fwd", "gs_sdf_eikonal_rr_fwd", "gs_sdf_eikonal_rr_bwd", "gs_flexi_vd_bwd", "gs_flexi_vd_fwd"}
 
 
 def pmc_traffic(kernel):
@@ -376,13 +376,25 @@ def roofline_of(name, rec, op_times, N, Ftets, V_aug, T, B, H, W, n, trainer):
         # the weight gradient D^T X; the saved forward = one forward.  Per LAUNCH: the mean over the grid pass (rows with gradient) and the
         # eikonal pass (4 virtual rows per surface sample), which are the two launches of each kernel in an iteration.
         rows = _mlp.LAST_CHAIN_ROWS
-        per_launch = 0.5 * (rows.get(1, 0) + 4 * rows.get(2, 0))
+        launches = max((1 if rows.get(1, 0) else 0) + (1 if rows.get(2, 0) else 0), 1)      # the eikonal term has its own entry points in its default (reverse) formulation
+        per_launch = (rows.get(1, 0) + 4 * rows.get(2, 0)) / launches
         flops = 826880.0 * per_launch
         kern = {"gs_sdf_mlp_h2_bwd": "k_h2_bwd<ROWS|EIK> reverse chain", "gs_sdf_mlp_h2_wgrad": "k_h2_wgrad16 (+ k_h2_wgrad for the output layer)",
                 "gs_sdf_mlp_h2_save_fwd": "k_h2_fwd<ROWS|EIK> recompute + saved planes"}[name]
         return mfma(kern, flops, 2500.0, rows_with_gradient=int(rows.get(1, 0)), eikonal_samples=int(rows.get(2, 0)), mean_virtual_rows_per_launch=int(per_launch),
                     hbm_plane_bytes_per_launch=int(per_launch * 7 * 256 * 4),
                     note="fp16-pair (reverse chain, saved forward) / bf16-pair (weight gradient) operands: three products per algorithmic product")
+    if name in ("gs_sdf_eikonal_rr_fwd", "gs_sdf_eikonal_rr_bwd"):
+        # the eikonal term by reverse over reverse (the reference's autograd formulation, gshell_tets_geometry.py:302-324), per sample:
+        #   _fwd = value pass + reverse chain to grad_x f                                   = 2 x 826 880 flop
+        #   _bwd = tangent pass + reverse chain with source + two outer products per layer    = 4 x 826 880 flop
+        ns = _mlp.LAST_CHAIN_ROWS.get(4, 0)
+        fwd = name.endswith("_fwd")
+        flops = (2 if fwd else 4) * 826880.0 * ns
+        return mfma("gs_sdf_eikonal_rr_fwd (k_h2_fwd<ROWS> + k_h2_bwd<ROWS>)" if fwd else "gs_sdf_eikonal_rr_bwd (k_h2_fwd<RR> + k_h2_bwd<RR> + k_h2_wgrad16)",
+                    flops, 2500.0, eikonal_samples=int(ns), hbm_plane_bytes_per_launch=int(ns * 7 * 256 * 4 * (3 if fwd else 11)),
+                    note="fp16-pair / bf16-pair operands: three products per algorithmic product; bound by the fp32 planes it writes and reads "
+                         "(3 plane passes in _fwd, 11 in _bwd)")
     if name == "gs_env_shade_fwd":
         # 68 B/px in + 24 B/px out; 2 n^2 shadow rays per covered pixel are the work that binds it
         n_cov = _ou.last_covered_pixels

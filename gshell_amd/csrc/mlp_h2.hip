@@ -69,7 +69,16 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 //         (no bias; activation a' = sigma'(z) z'), so that |grad f| of the eikonal term costs one pass over 4 n rows.
 //   FIX : row rows[r] of x, r < R, nothing saved: the second pass of the two-pass forward (k_h1_fwd first): out[rows[r]] is
 //         overwritten with the three-product value, the sign bit of the row is corrected, max |new - old| is recorded
-enum { MODE_GRID = 0, MODE_ROWS = 1, MODE_EIK = 2, MODE_FIX = 3 };
+//   RR  : the eikonal term by REVERSE over reverse (round 4; what the reference's autograd does, gshell_tets_geometry.py:302-324), half the
+//         row passes of EIK.  With a_l = sigma(z_l), s_l = sigma'(z_l), in_l = the layer's input ([a_{l-1} | e] at the skip layer):
+//           1. ROWS forward over the samples (saves a_l, e)             2. ROWS reverse chain with g_out = 1: delta_l = s_l (W_{l+1}^T delta_{l+1}),
+//              grad f = J_enc^T (adjoint of e)  ->  loss = sum (|grad f| - 1)^2, gbar = d loss / d grad f
+//           3. k_h2_fwd<RR>: the adjoint of pass 2 is a TANGENT pass in direction gbar:  dt_l = W_l uin_l  (uin_0 = J_enc gbar, no bias),
+//              u_l = s_l dt_l (saved: the X operand of delta_l in dW_l), and the second-order source  S_l = 100 (1 - s_l) delta_l dt_l
+//           4. k_h2_bwd<RR>: the adjoint of pass 1 with that source:  zbar_l = s_l (W_{l+1}^T zbar_{l+1}) + S_l   (top: 0)
+//           5. dW_l = sum_rows zbar_l (x) in_l + delta_l (x) uin_l,  db_l = sum zbar_l,  dw_out = sum u_{L-1}: ONE weight-gradient launch over
+//              2 Rpad rows -- the planes are laid out [a ; u], [zbar ; delta], [e ; J gbar] with the second operand pair Rpad rows below the first.
+enum { MODE_GRID = 0, MODE_ROWS = 1, MODE_EIK = 2, MODE_FIX = 3, MODE_RR = 4 };
 // status words of the forward kernels (device, zeroed by the caller): [0] != 0: a non-finite value left the network (an activation
 // or weight beyond the fp16 range -- the caller re-runs the exact-fp32 kernel); [1]: bits of max |three-product - one-product| over
 // the rows the second pass recomputed (the a-posteriori check of the one-product pass's error bound)
@@ -93,6 +102,14 @@ struct H2Args {
     const float* bias[MAX_LAYERS];  // [256] fp32
     const float* w_out;             // [256] fp32 followed by the output bias
     float tau;                      // MODE_FIX: > 0 = also record status[ST_MAXREL] = max |new - old| / max(tau, |new|)  (status then has 3 words)
+    int64_t Pstride;                // rows per layer of the saved planes; 0 = Rpad (RR: 2 Rpad, the two operand pairs share one allocation)
+    // MODE_RR (tangent pass): A = u planes WRITTEN, EMB = J_enc gbar WRITTEN; read: the value pass's planes, the unit direction and its scalar
+    const float* A_in;              // a_l planes of the value pass
+    const float* EMB_in;            // its saved encoding [Rpad][EK]
+    const float* D_in;              // delta_l planes (reverse chain with g_out = 1)
+    float* S_out;                   // source planes S_l WRITTEN
+    const float* gbar;              // [N][3] d loss / d grad f for a unit upstream gradient
+    const float* gmul;              // device scalar: the upstream gradient of the loss
 };
 
 __device__ __forceinline__ void split_h2(float v, _Float16& hi, _Float16& lo) {
@@ -143,8 +160,11 @@ __device__ __forceinline__ f2 logistic100_pair(f2 z) {
 }
 // the same derivative from the SAVED softplus value a = softplus(z) >= 0:  sigma' = 1 - exp(-100 a)   (exact identity)
 __device__ __forceinline__ float slope_from_value(float a) {
+    // both forms evaluated, one selected: as a branch this split every epilogue that uses it into ~30 basic blocks (one per element), each
+    // waiting for its own plane load
     const float x = 100.0f * a;
-    return x < 0.01f ? x * (1.0f - 0.5f * x + 0.16666667f * x * x) : 1.0f - __builtin_amdgcn_exp2f(-SP_C1 * a);
+    const float small = x * (1.0f - 0.5f * x + 0.16666667f * x * x), big = 1.0f - __builtin_amdgcn_exp2f(-SP_C1 * a);
+    return x < 0.01f ? small : big;
 }
 
 #ifndef GS_H2_BPF
@@ -252,6 +272,11 @@ __device__ __forceinline__ void zero_acc(v16f (&hi)[2], v16f (&lo)[2]) {
         for (int r = 0; r < 16; ++r) hi[s][r] = lo[s][r] = 0.f;
 }
 
+__device__ __forceinline__ float pow2_scale_for(float gmax) {      // 2^-floor(log2 gmax), 1 for zero / tiny rows
+    const int e = (__float_as_int(gmax) >> 23) & 0xff;
+    return (e < 32 || e > 222) ? 1.0f : __int_as_float((254 - e) << 23);
+}
+
 // Point of tile row `row` (and, for EIK, which virtual row it is: c = 0 value, 1..3 tangent d = c - 1).
 template <int MODE>
 __device__ __forceinline__ bool tile_point(const H2Args& A, int64_t n_act, int64_t tile, int row, float (&p)[3], int& c) {
@@ -264,7 +289,7 @@ __device__ __forceinline__ bool tile_point(const H2Args& A, int64_t n_act, int64
     } else {
         src = tile * TM + row;
         if (src >= n_act) return false;
-        if (MODE == MODE_ROWS || MODE == MODE_FIX) src = A.rows[src];
+        if ((MODE == MODE_ROWS || MODE == MODE_FIX) && A.rows) src = A.rows[src];       // rows == nullptr: the rows are x[0 .. N)
     }
     p[0] = A.x[3 * src]; p[1] = A.x[3 * src + 1]; p[2] = A.x[3 * src + 2];
     return true;
@@ -289,6 +314,7 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
     const int64_t tile = DUAL ? 2 * (int64_t)blockIdx.x + half : (int64_t)blockIdx.x, r0 = tile * TM;
     const int64_t n_act = ((MODE == MODE_ROWS || MODE == MODE_FIX) && A.n_dev) ? min(*A.n_dev, A.N) : A.N;
     if ((MODE == MODE_ROWS || MODE == MODE_FIX) && (DUAL ? 2 * (int64_t)blockIdx.x : tile) * TM >= n_act) return;      // whole workgroup past the device-side count
+    const int64_t PS = A.Pstride ? A.Pstride : A.Rpad;
 
     // encoding of the tile, zero padded to EK columns, zero rows past the end.  24 work items per row: 18 (frequency, axis)
     // pairs -- ONE sincosf serves the sin and the cos column (and, on tangent rows, both derivatives) --, the 3 coordinates,
@@ -300,7 +326,43 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
         E2[row * LDEH + f] = lo;
         if (MODE == MODE_ROWS || MODE == MODE_EIK) A.EMB[(r0 + row) * EK + f] = v;
     };
-    for (int idx = tid; idx < TM * 24; idx += NT) {
+    if (MODE == MODE_RR) {
+        // tangent pass: the input is J_enc(x) gbar, from the SAVED sin / cos of the value pass (no sincosf), every row scaled by a power of
+        // two so that the chain runs at O(1) whatever the upstream scalar is (it is linear in gbar); the planes are written unscaled
+        const float gm = *A.gmul;
+        for (int idx = tid; idx < TM * 24; idx += NT) {
+            const int row = idx / 24, slot = idx - row * 24;
+            const int64_t src = r0 + row;
+            const bool valid = src < n_act;
+            float gb[3] = {0.f, 0.f, 0.f};
+            if (valid) { gb[0] = A.gbar[3 * src] * gm; gb[1] = A.gbar[3 * src + 1] * gm; gb[2] = A.gbar[3 * src + 2] * gm; }
+            const float rsc = pow2_scale_for(fmaxf(fmaxf(fabsf(gb[0]), fabsf(gb[1])), fabsf(gb[2])));
+            const float* em = A.EMB_in + src * EK;
+            auto put_t = [&](int f, float v) {
+                _Float16 hi, lo;
+                split_h2(v * rsc, hi, lo);
+                E1[row * LDEH + f] = hi;
+                E2[row * LDEH + f] = lo;
+                A.EMB[src * EK + f] = v;
+            };
+            if (slot < 18) {
+                const int k = slot / 3, ax = slot - 3 * k;
+                float vs = 0.f, vc = 0.f;
+                if (valid && k < A.n_freq) {
+                    const float fr = (float)(1 << k);
+                    vs = fr * em[3 + 6 * k + 3 + ax] * gb[ax];          // d sin(2^k x) = 2^k cos(2^k x) dx
+                    vc = -fr * em[3 + 6 * k + ax] * gb[ax];
+                }
+                put_t(3 + 6 * k + ax, vs);
+                put_t(3 + 6 * k + 3 + ax, vc);
+            } else if (slot < 21) {
+                put_t(slot - 18, gb[slot - 18]);
+            } else {
+                for (int j = 0; j < 3; ++j) put_t(39 + 3 * (slot - 21) + j, 0.0f);
+            }
+        }
+    }
+    for (int idx = tid; MODE != MODE_RR && idx < TM * 24; idx += NT) {
         const int row = idx / 24, slot = idx - row * 24;
         float p[3] = {0.f, 0.f, 0.f};
         int c = 0;
@@ -330,6 +392,15 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
     const int n_base = wave * 32 + 4 * (lane >> 5);      // + 8 g + j  (g = reg >> 2, j = reg & 3)
     const int m_lane = lane & 31;                        // + 32 s
     const bool low16 = (lane & 16) == 0;                 // EIK: this lane holds (value, d/dy) rows; the other half (d/dx, d/dz)
+    float isc[2] = {1.0f, 1.0f};                         // RR: 1 / row scale of rows m_lane, 32 + m_lane (exact: powers of two)
+    if (MODE == MODE_RR) {
+        const float gm = *A.gmul;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int64_t r = r0 + 32 * s + m_lane;
+            if (r < n_act) isc[s] = 1.0f / pow2_scale_for(fmaxf(fmaxf(fabsf(A.gbar[3 * r] * gm), fabsf(A.gbar[3 * r + 1] * gm)), fabsf(A.gbar[3 * r + 2] * gm)));
+        }
+    }
     for (int l = 0; l < A.n_layers; ++l) {
         v16f hi[2], lo[2];
         zero_acc(hi, lo);
@@ -346,9 +417,21 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
         float4 b4v[4], w4v[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            b4v[g] = *reinterpret_cast<const float4*>(bl + 8 * g);
-            w4v[g] = last ? *reinterpret_cast<const float4*>(A.w_out + n_base + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b4v[g] = MODE == MODE_RR ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(bl + 8 * g);
+            w4v[g] = (last && MODE != MODE_RR) ? *reinterpret_cast<const float4*>(A.w_out + n_base + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        // RR: the saved a_l and delta_l of this lane's elements, one group of four features AHEAD of its use (the first group before the
+        // barrier): issued in front of the previous group's plane stores, which the compiler may not move them across (same allocations)
+        float avn[2][4], dvn[2][4];
+        auto load_group = [&](int g) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int64_t pi = plane_idx(PS, l, r0 + 32 * s + m_lane, n_base + 8 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { avn[s][j] = A.A_in[pi + 32 * j]; dvn[s][j] = A.D_in[pi + 32 * j]; }
+            }
+        };
+        if (MODE == MODE_RR) load_group(0);
 #ifndef GS_H2_NOBAR      // timing experiment: no barriers inside the layer loop (wrong results)
         __syncthreads();     // every wave is done reading the planes: they are overwritten in place
 #endif
@@ -359,11 +442,31 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
             const f2 bj[2] = {f2{b4.x, b4.y}, f2{b4.z, b4.w}};
             const f2 wj[2] = {f2{w4v[g].x, w4v[g].y}, f2{w4v[g].z, w4v[g].w}};
             f2 v[2][2];          // [row half s][pair]
+            f2 src_t[2][2];      // RR: the second-order source S_l of the same elements
+            float av[2][4], dv[2][4];
+            if (MODE == MODE_RR) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { av[s][j] = avn[s][j]; dv[s][j] = dvn[s][j]; }
+                if (g + 1 < 4) load_group(g + 1);
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int r = 4 * g + 2 * q;
                 const f2 z0 = f2{hi[0][r], hi[0][r + 1]} + f2{lo[0][r], lo[0][r + 1]} * LO_INV;
                 const f2 z1 = f2{hi[1][r], hi[1][r + 1]} + f2{lo[1][r], lo[1][r + 1]} * LO_INV;
+                if (MODE == MODE_RR) {
+                    // u = s dt (the next layer's input, still scaled);  S = 100 (1 - s) delta dt, unscaled
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const f2 z = s == 0 ? z0 : z1;
+                        const f2 sl = f2{slope_from_value(av[s][2 * q]), slope_from_value(av[s][2 * q + 1])};
+                        v[s][q] = sl * z;
+                        src_t[s][q] = (1.0f - sl) * f2{dv[s][2 * q], dv[s][2 * q + 1]} * z * (100.0f * isc[s]);
+                    }
+                    continue;
+                }
 #ifdef GS_H2_NOEPI       // timing experiment only: no softplus (wrong results)
                 if (true) {
                     v[0][q] = z0 + bj[q];
@@ -387,11 +490,18 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 if (MODE == MODE_ROWS || MODE == MODE_EIK) {
-                    float* ap = A.A + plane_idx(A.Rpad, l, r0 + 32 * s + m_lane, n_base + 8 * g);
+                    float* ap = A.A + plane_idx(PS, l, r0 + 32 * s + m_lane, n_base + 8 * g);
                     ap[0] = v[s][0].x; ap[32] = v[s][0].y; ap[64] = v[s][1].x; ap[96] = v[s][1].y;
                 }
+                if (MODE == MODE_RR) {
+                    const int64_t pi = plane_idx(PS, l, r0 + 32 * s + m_lane, n_base + 8 * g);
+                    float* ap = A.A + pi;
+                    float* sp = A.S_out + pi;
+                    ap[0] = v[s][0].x * isc[s]; ap[32] = v[s][0].y * isc[s]; ap[64] = v[s][1].x * isc[s]; ap[96] = v[s][1].y * isc[s];
+                    sp[0] = src_t[s][0].x; sp[32] = src_t[s][0].y; sp[64] = src_t[s][1].x; sp[96] = src_t[s][1].y;
+                }
                 if (last) {
-                    part[s] = part[s] + v[s][0] * wj[0] + v[s][1] * wj[1];
+                    if (MODE != MODE_RR) part[s] = part[s] + v[s][0] * wj[0] + v[s][1] * wj[1];
                 } else {
                     h2 a0, b0, a1, b1;
                     split_h2_pair(v[s][0], a0, b0);
@@ -402,7 +512,7 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
                 }
             }
         }
-        if (last && MODE != MODE_ROWS) {
+        if (last && MODE != MODE_ROWS && MODE != MODE_RR) {
             // output layer: this lane holds the sum over its 16 features; add the other 16 of the wave's 32 (lane ^ 32), then
             // the 8 waves through LDS in a fixed order (deterministic)
             float* red = reinterpret_cast<float*>(E1);       // [8 waves][64 rows] fp32 = 2 KB (the encoding planes are dead now)
@@ -420,7 +530,7 @@ __global__ void __launch_bounds__(DUAL ? 2 * NT : NT, 4) k_h2_fwd(H2Args A) {
 #endif
     }
     if (DUAL && half == 0) __syncthreads();              // same number of barriers in both halves
-    if (MODE != MODE_ROWS && tid < TM) {
+    if (MODE != MODE_ROWS && MODE != MODE_RR && tid < TM) {
         const float* red = reinterpret_cast<const float*>(E1);
         float s = 0.f;
 #pragma unroll
@@ -761,12 +871,11 @@ struct BwdArgs {
     const h8* wfragT[MAX_LAYERS];   // [n-step 16][block nbT(l)][piece 2][lane 64]
     int nblkT[MAX_LAYERS];
     const float* w_out;
+    int64_t Pstride;      // rows per layer of the planes; 0 = Rpad
+    // MODE_RR (adjoint of the value pass with the second-order source): Dsave holds S_l on entry and zbar_l on exit; g_out is not read
+    const float* gbar;    // [R][3], gmul: device scalar -- the rows' power-of-two scales, as in the tangent pass
+    const float* gmul;
 };
-
-__device__ __forceinline__ float pow2_scale_for(float gmax) {      // 2^-floor(log2 gmax), 1 for zero / tiny rows
-    const int e = (__float_as_int(gmax) >> 23) & 0xff;
-    return (e < 32 || e > 222) ? 1.0f : __int_as_float((254 - e) << 23);
-}
 
 constexpr int LDG = EK + 1;      // fp32 encoding-adjoint tile row stride
 
@@ -786,9 +895,18 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
     const bool low16 = (lane & 16) == 0;
     const bool need_x = MODE == MODE_ROWS && B.g_x != nullptr;
 
-    float go[2] = {B.g_out[r0 + m_lane], B.g_out[r0 + 32 + m_lane]};
+    const int64_t PS = B.Pstride ? B.Pstride : B.Rpad;
+    float go[2] = {0.f, 0.f};
+    if (MODE != MODE_RR) { go[0] = B.g_out[r0 + m_lane]; go[1] = B.g_out[r0 + 32 + m_lane]; }
     float sc[2];
-    if (MODE == MODE_EIK) {
+    if (MODE == MODE_RR) {
+        const float gm = *B.gmul;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int64_t r = r0 + 32 * s + m_lane;
+            sc[s] = r < n_act ? pow2_scale_for(fmaxf(fmaxf(fabsf(B.gbar[3 * r] * gm), fabsf(B.gbar[3 * r + 1] * gm)), fabsf(B.gbar[3 * r + 2] * gm))) : 1.0f;
+        }
+    } else if (MODE == MODE_EIK) {
         float gm = fmaxf(fabsf(go[0]), fabsf(go[1]));
         gm = fmaxf(gm, __shfl_xor(gm, 16, 64));              // the four virtual rows of a sample share one scale
         sc[0] = sc[1] = pow2_scale_for(gm);
@@ -823,6 +941,7 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
 #define GS_H2_ABL 0      // experiments (tools/build_variant.sh): 1 = no D-plane stores, 2 = no A-plane loads, 4 = no dgrad GEMM
 #endif
     float4 an[2][4];
+    float4 sn[2][4];        // RR: the source S_l of the same elements (read where zbar_l is written)
     auto fetch_plane = [&](int l) {
         if (GS_H2_ABL & 2) {
 #pragma unroll
@@ -831,10 +950,15 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float* p0 = B.A + plane_idx(B.Rpad, l, r0 + m_lane, n_base + 8 * g);
-            const float* p1 = B.A + plane_idx(B.Rpad, l, r0 + 32 + m_lane, n_base + 8 * g);
+            const int64_t i0 = plane_idx(PS, l, r0 + m_lane, n_base + 8 * g), i1 = plane_idx(PS, l, r0 + 32 + m_lane, n_base + 8 * g);
+            const float *p0 = B.A + i0, *p1 = B.A + i1;
             an[0][g] = make_float4(p0[0], p0[32], p0[64], p0[96]);
             an[1][g] = make_float4(p1[0], p1[32], p1[64], p1[96]);
+            if (MODE == MODE_RR) {
+                const float *q0 = B.Dsave + i0, *q1 = B.Dsave + i1;
+                sn[0][g] = make_float4(q0[0], q0[32], q0[64], q0[96]);
+                sn[1][g] = make_float4(q1[0], q1[32], q1[64], q1[96]);
+            }
         }
     };
     fetch_plane(B.n_layers - 1);
@@ -849,7 +973,11 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = 4 * g + j;
-                if (MODE != MODE_EIK) {
+                if (MODE == MODE_RR) {
+                    const float sv0[4] = {sn[0][g].x, sn[0][g].y, sn[0][g].z, sn[0][g].w}, sv1[4] = {sn[1][g].x, sn[1][g].y, sn[1][g].z, sn[1][g].w};
+                    d0[j] = __builtin_fmaf(G[0][r], slope_from_value(av0[j]), sv0[j] * sc[0]);
+                    d1[j] = __builtin_fmaf(G[1][r], slope_from_value(av1[j]), sv1[j] * sc[1]);
+                } else if (MODE != MODE_EIK) {
                     d0[j] = G[0][r] * slope_from_value(av0[j]);
                     d1[j] = G[1][r] * slope_from_value(av1[j]);
                 } else {
@@ -868,8 +996,8 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
                 }
             }
             if (!(GS_H2_ABL & 1)) {
-                float* dp0 = B.Dsave + plane_idx(B.Rpad, l, r0 + m_lane, n_base + 8 * g);
-                float* dp1 = B.Dsave + plane_idx(B.Rpad, l, r0 + 32 + m_lane, n_base + 8 * g);
+                float* dp0 = B.Dsave + plane_idx(PS, l, r0 + m_lane, n_base + 8 * g);
+                float* dp1 = B.Dsave + plane_idx(PS, l, r0 + 32 + m_lane, n_base + 8 * g);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     dp0[32 * j] = d0[j] * isc[0];
@@ -899,15 +1027,9 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
         __syncthreads();
         // ---- G = W_l^T D_l
         v16f hi[2], lo[2];
-        if (l > 0) {
-            zero_acc(hi, lo);
-            if (!(GS_H2_ABL & 4)) gemm_seg<LDH, D / 16>(hi, lo, H1, H2, B.wfragT[l], wave, B.nblkT[l], lane);
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) G[s][r] = __builtin_fmaf(lo[s][r], LO_INV, hi[s][r]);
-        }
-        if (need_x && (l == 0 || l == B.skip_layer) && wave < 2) {     // adjoint of the encoding: two 32-feature blocks (48 used)
+        // the adjoint of the encoding FIRST (two 32-feature blocks, 48 used): the previous G is dead here, so the two GEMMs never hold G and a
+        // second accumulator set at once (after the main GEMM they did: 62 spilled registers in <ROWS>)
+        if (need_x && (l == 0 || l == B.skip_layer) && wave < 2) {
             zero_acc(hi, lo);
             gemm_seg<LDH, D / 16>(hi, lo, H1, H2, B.wfragT[l], (l == 0 ? 0 : 8) + wave, B.nblkT[l], lane);
 #pragma unroll
@@ -917,6 +1039,21 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
                     const int f = 32 * wave + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
                     if (f < EK) GE[(32 * s + m_lane) * LDG + f] += __builtin_fmaf(lo[s][r], LO_INV, hi[s][r]);
                 }
+        }
+        if (l > 0) {
+            zero_acc(hi, lo);
+            if (!(GS_H2_ABL & 4)) gemm_seg<LDH, D / 16>(hi, lo, H1, H2, B.wfragT[l], wave, B.nblkT[l], lane);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) G[s][r] = __builtin_fmaf(lo[s][r], LO_INV, hi[s][r]);
+        } else {
+            // G is not read again (l == 0 is the last pass), but the compiler does not see that: without this redefinition it keeps the OLD G
+            // alive across the encoding GEMM above -- 30 registers spilled and reloaded around it in every layer
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) G[s][r] = 0.f;
         }
         if (!EARLY && l > 0) fetch_plane(l - 1);
         __syncthreads();
@@ -935,7 +1072,7 @@ __global__ void __launch_bounds__(NT, 4) k_h2_bwd(BwdArgs B) {
                     const float fr = (float)(1 << k);
                     acc += fr * (em[3 + 6 * k + 3 + c] * ge[3 + 6 * k + c] - em[3 + 6 * k + c] * ge[3 + 6 * k + 3 + c]);
                 }
-                B.g_x[3 * (int64_t)B.rows[r] + c] = acc * SC[row];
+                B.g_x[3 * (B.rows ? (int64_t)B.rows[r] : r) + c] = acc * SC[row];        // rows == nullptr: the rows are x[0 .. R)
             }
         }
     }
@@ -1010,7 +1147,7 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs& W, int l, float* sm
             *reinterpret_cast<float4*>(buf + row * D + 4 * (tid & 63)) = dreg[i];
             if (HAS_H) *reinterpret_cast<float4*>(buf + WG_D + row * D + 4 * (tid & 63)) = xreg[i];
             // bias gradient: value rows only (EIK: tile rows 0..15 of every 64)
-            const bool value_row = W.mode != MODE_EIK || (((slab * WS + row) & 63) < 16);
+            const bool value_row = W.mode == MODE_RR ? 2 * slab * WS < W.Rpad : (W.mode != MODE_EIK || (((slab * WS + row) & 63) < 16));      // RR: the zbar half
             if (value_row) { bsum.x += dreg[i].x; bsum.y += dreg[i].y; bsum.z += dreg[i].z; bsum.w += dreg[i].w; }
         }
         if (HAS_E && tid < WS * (EK / 4)) *reinterpret_cast<float4*>(buf + 2 * WG_D + (tid / (EK / 4)) * 64 + 4 * (tid % (EK / 4))) = ereg;
@@ -1152,7 +1289,8 @@ __device__ __forceinline__ void wgrad16_layer(const WgradArgs& W, int l, __bf16*
         const float* xs = HAS_H ? Xh + next * (int64_t)(WS * D) + frow : nullptr;
         // bias gradient: value rows only (EIK: tile rows 0..15 of every 64 = the even slab's rows 0..15 = this thread's four rows or
         // none of them); a multiplier, not a branch: sixteen divergent branches per slab kept the scheduler from overlapping anything
-        const float vsel = (W.mode != MODE_EIK || ((slab & 1) == 0 && frow < 16)) ? 1.0f : 0.0f;
+        // RR: rows [0, Rpad / 2) are the zbar rows, the delta rows below them carry no bias term
+        const float vsel = (W.mode == MODE_RR ? 2 * slab * WS < W.Rpad : (W.mode != MODE_EIK || ((slab & 1) == 0 && frow < 16))) ? 1.0f : 0.0f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int f = fsub + 8 * c;
@@ -1535,6 +1673,34 @@ __global__ void __launch_bounds__(256) k_eikonal_loss(const float* __restrict__ 
     }
 }
 
+// RR set-up: g_all [2 Rpad] = the per-row upstream gradients of the two launches that read one -- rows [Rpad, Rpad + n) = 1 (the reverse chain
+// with g_out = 1 reads g_all + Rpad; the output layer's weight gradient sum_rows g_all[row] x[row] then picks the u rows), 0 elsewhere
+__global__ void __launch_bounds__(256) k_rr_init(float* __restrict__ g_all, int64_t n, int64_t Rpad, float* __restrict__ loss) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < 2 * Rpad) g_all[i] = (i >= Rpad && i - Rpad < n) ? 1.0f : 0.0f;
+    if (i == 0) loss[0] = 0.f;
+}
+// loss += sum_i (|g_i| - 1)^2,  gbar_i = d loss / d g_i  (the clamp of k_eikonal_loss: a zero gradient has a zero subgradient)
+__global__ void __launch_bounds__(256) k_rr_loss(const float* __restrict__ gx, int64_t n, float* __restrict__ loss, float* __restrict__ gbar) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float acc = 0.f;
+    if (i < n) {
+        const float jx = gx[3 * i], jy = gx[3 * i + 1], jz = gx[3 * i + 2];
+        const float nrm = sqrtf(jx * jx + jy * jy + jz * jz);
+        acc = (nrm - 1.0f) * (nrm - 1.0f);
+        const float k = 2.0f * (nrm - 1.0f) / fmaxf(nrm, 1e-20f);
+        gbar[3 * i] = k * jx; gbar[3 * i + 1] = k * jy; gbar[3 * i + 2] = k * jz;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    __shared__ float sw[4];
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+        if (t != 0.f) atomicAdd(loss, t);
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t gs_sdf_mlp_h2_packed_bytes(int n_freq, int n_hidden, int skip_layer) {
@@ -1677,20 +1843,16 @@ extern "C" int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* ro
 // Weight / bias gradients from the saved planes, ACCUMULATED (float atomics) into torch-layout tensors:
 // dW, db = HOST arrays of n_hidden + 2 DEVICE pointers (Linear.weight.grad [out,in], Linear.bias.grad), output layer last;
 // db[n_hidden + 1] (the output bias, = sum of g_out over the value rows) is not touched.
-extern "C" int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, const int64_t* n_dev, int n_freq, int n_hidden, int skip_layer,
-                                   const float* A_save, const float* EMB_save, const float* D_save, float* const* dW, float* const* db,
-                                   int exact_fp32, gs_stream_t stream) {
-    if (n == 0) return 0;
-    GS_REQUIRE(mode == MODE_ROWS || mode == MODE_EIK, "gs_sdf_mlp_h2_wgrad: mode must be 1 (rows) or 2 (eikonal)");
-    GS_REQUIRE(g_out && A_save && EMB_save && D_save && dW && db, "gs_sdf_mlp_h2_wgrad: null pointer");
-    if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
+static int wgrad_launch(int mode, const float* g_out, int64_t Rpad, int64_t n_rows, const int64_t* n_dev, int n_freq, int n_hidden, int skip_layer,
+                        const float* A_save, const float* EMB_save, const float* D_save, float* const* dW, float* const* db, int exact_fp32,
+                        hipStream_t stream) {
     WgradArgs W{};
-    W.A = A_save; W.EMB = EMB_save; W.D = D_save; W.g_out = g_out; W.Rpad = gs_sdf_mlp_h2_rows_padded(mode, n);
-    W.n_dev = mode == MODE_ROWS ? n_dev : nullptr;
-    W.n = mode == MODE_ROWS ? n : W.Rpad;
+    W.A = A_save; W.EMB = EMB_save; W.D = D_save; W.g_out = g_out; W.Rpad = Rpad;
+    W.n_dev = n_dev;
+    W.n = n_rows;
     W.E = 3 * (2 * n_freq + 1); W.n_layers = n_hidden + 1; W.skip_layer = skip_layer; W.mode = mode;
     for (int l = 0; l <= W.n_layers; ++l) {
-        GS_REQUIRE(dW[l] && (l == W.n_layers || db[l]), "gs_sdf_mlp_h2_wgrad: null gradient pointer");
+        GS_REQUIRE(dW[l] && (l == W.n_layers || db[l]), "sdf_mlp_h2 weight gradients: null gradient pointer");
         W.dW[l] = dW[l];
         W.db[l] = db[l];
     }
@@ -1704,15 +1866,27 @@ extern "C" int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, cons
     strips = (int)gs::cdiv(nslabs, W.slabs_per_strip);
     GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_WGRAD_BYTES));
     if (exact_fp32) {
-        hipLaunchKernelGGL(k_h2_wgrad, dim3((unsigned)strips, (unsigned)(W.n_layers + 1)), dim3(NT), SMEM_WGRAD_BYTES, (hipStream_t)stream, W);
+        hipLaunchKernelGGL(k_h2_wgrad, dim3((unsigned)strips, (unsigned)(W.n_layers + 1)), dim3(NT), SMEM_WGRAD_BYTES, stream, W);
     } else {
         GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_wgrad16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_WGRAD16_BYTES));
-        hipLaunchKernelGGL(k_h2_wgrad16, dim3((unsigned)strips, (unsigned)W.n_layers), dim3(NT), SMEM_WGRAD16_BYTES, (hipStream_t)stream, W);
+        hipLaunchKernelGGL(k_h2_wgrad16, dim3((unsigned)strips, (unsigned)W.n_layers), dim3(NT), SMEM_WGRAD16_BYTES, stream, W);
         W.only_output = 1;
-        hipLaunchKernelGGL(k_h2_wgrad, dim3((unsigned)strips, 1), dim3(NT), SMEM_WGRAD_BYTES, (hipStream_t)stream, W);
+        hipLaunchKernelGGL(k_h2_wgrad, dim3((unsigned)strips, 1), dim3(NT), SMEM_WGRAD_BYTES, stream, W);
     }
     GS_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, const int64_t* n_dev, int n_freq, int n_hidden, int skip_layer,
+                                   const float* A_save, const float* EMB_save, const float* D_save, float* const* dW, float* const* db,
+                                   int exact_fp32, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_REQUIRE(mode == MODE_ROWS || mode == MODE_EIK, "gs_sdf_mlp_h2_wgrad: mode must be 1 (rows) or 2 (eikonal)");
+    GS_REQUIRE(g_out && A_save && EMB_save && D_save && dW && db, "gs_sdf_mlp_h2_wgrad: null pointer");
+    if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
+    const int64_t Rpad = gs_sdf_mlp_h2_rows_padded(mode, n);
+    return wgrad_launch(mode, g_out, Rpad, mode == MODE_ROWS ? n : Rpad, mode == MODE_ROWS ? n_dev : nullptr, n_freq, n_hidden, skip_layer, A_save, EMB_save, D_save,
+                        dW, db, exact_fp32, (hipStream_t)stream);
 }
 
 extern "C" int gs_sdf_eikonal_loss(const float* out_rows, int64_t n, int64_t rows_padded, float* loss, float* g_unit, gs_stream_t stream) {
@@ -1724,4 +1898,71 @@ extern "C" int gs_sdf_eikonal_loss(const float* out_rows, int64_t n, int64_t row
     hipLaunchKernelGGL(k_eikonal_loss, dim3((unsigned)gs::cdiv(tiles * 16, 256)), dim3(256), 0, (hipStream_t)stream, out_rows, n, tiles, loss, g_unit);
     GS_LAUNCH_CHECK();
     return 0;
+}
+
+// ---- eikonal term, reverse over reverse (MODE_RR above) ----------------------------------------------------------------------------
+// Buffers (caller-owned, alive from _fwd to _bwd): with Rpad = gs_sdf_eikonal_rr_rows_padded(n) and L = n_hidden + 1 layers
+//   A_all [L][2 Rpad][256], D_all [L][2 Rpad][256] (plane layout), EMB_all [2 Rpad][48], g_all [2 Rpad], gbar [n][3], grad_f [n][3].
+extern "C" int64_t gs_sdf_eikonal_rr_rows_padded(int64_t n) { return gs::cdiv(n, TM) * TM; }      // every 64-row tile holds a sample: no tile is skipped
+
+// loss[0] = sum_i (|grad_x f(x_i)| - 1)^2 (WRITTEN), grad_f [n][3] = grad_x f (WRITTEN), gbar = d loss / d grad_f (WRITTEN); first halves of A_all / EMB_all
+// (a_l, e) and second half of D_all (delta_l) WRITTEN.
+extern "C" int gs_sdf_eikonal_rr_fwd(const float* x, int64_t n, const void* packed, int n_freq, int n_hidden, int skip_layer, float* A_all, float* EMB_all,
+                                     float* D_all, float* g_all, float* grad_f, float* gbar, float* loss, gs_stream_t stream) {
+    GS_REQUIRE(loss, "gs_sdf_eikonal_rr_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) { GS_HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(float), st)); return 0; }
+    GS_REQUIRE(x && packed && A_all && EMB_all && D_all && g_all && grad_f && gbar, "gs_sdf_eikonal_rr_fwd: null pointer");
+    if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
+    const PackLayout L = make_layout(n_freq, n_hidden, skip_layer);
+    const int64_t Rpad = gs_sdf_eikonal_rr_rows_padded(n);
+    hipLaunchKernelGGL(k_rr_init, dim3((unsigned)gs::cdiv(2 * Rpad, 256)), dim3(256), 0, st, g_all, n, Rpad, loss);
+    H2Args A{};
+    A.x = x; A.N = n; A.n_freq = n_freq; A.A = A_all; A.EMB = EMB_all; A.Rpad = Rpad; A.Pstride = 2 * Rpad;
+    fill_fwd_args(A, packed, L);
+    if (int rc = launch_fwd<MODE_ROWS>(A, Rpad / TM, st)) return rc;
+    BwdArgs B{};
+    B.g_out = g_all + Rpad; B.A = A_all; B.EMB = EMB_all; B.Dsave = D_all + Rpad * D; B.g_x = grad_f;
+    B.R = n; B.Rpad = Rpad; B.Pstride = 2 * Rpad; B.E = L.E; B.n_layers = L.n_layers; B.skip_layer = L.skip_layer;
+    for (int l = 0; l < L.n_layers; ++l) {
+        B.wfragT[l] = (const h8*)packed + L.fragT_off[l];
+        B.nblkT[l] = L.nblkT[l];
+    }
+    B.w_out = (const float*)((const char*)packed + L.tail_off_bytes) + (int64_t)L.n_layers * D;
+    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_bwd<MODE_ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BWD_BYTES));
+    hipLaunchKernelGGL(k_h2_bwd<MODE_ROWS>, dim3((unsigned)(Rpad / TM)), dim3(NT), SMEM_BWD_BYTES, st, B);
+    hipLaunchKernelGGL(k_rr_loss, dim3((unsigned)gs::cdiv(n, 256)), dim3(256), 0, st, (const float*)grad_f, n, loss, gbar);
+    GS_LAUNCH_CHECK();
+    return 0;
+}
+
+// Parameter gradients of g_up * loss, ACCUMULATED into dW / db (as gs_sdf_mlp_h2_wgrad; the output bias gets none): g_up = device scalar.
+// Second halves of A_all / EMB_all (u_l, J gbar) and the first half of D_all (S_l, then zbar_l) WRITTEN.
+extern "C" int gs_sdf_eikonal_rr_bwd(int64_t n, const void* packed, int n_freq, int n_hidden, int skip_layer, float* A_all, float* EMB_all, float* D_all,
+                                     const float* g_all, const float* gbar, const float* g_up, float* const* dW, float* const* db, int exact_fp32,
+                                     gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_REQUIRE(packed && A_all && EMB_all && D_all && g_all && gbar && g_up && dW && db, "gs_sdf_eikonal_rr_bwd: null pointer");
+    if (int rc = check_shape(n_freq, n_hidden, skip_layer)) return rc;
+    const PackLayout L = make_layout(n_freq, n_hidden, skip_layer);
+    const int64_t Rpad = gs_sdf_eikonal_rr_rows_padded(n);
+    hipStream_t st = (hipStream_t)stream;
+    H2Args A{};
+    A.N = n; A.n_freq = n_freq; A.Rpad = Rpad; A.Pstride = 2 * Rpad;
+    A.A = A_all + Rpad * D; A.EMB = EMB_all + Rpad * EK; A.A_in = A_all; A.EMB_in = EMB_all; A.D_in = D_all + Rpad * D; A.S_out = D_all;
+    A.gbar = gbar; A.gmul = g_up;
+    fill_fwd_args(A, packed, L);
+    if (int rc = launch_fwd<MODE_RR>(A, Rpad / TM, st)) return rc;
+    BwdArgs B{};
+    B.A = A_all; B.EMB = EMB_all; B.Dsave = D_all; B.R = n; B.Rpad = Rpad; B.Pstride = 2 * Rpad; B.E = L.E; B.n_layers = L.n_layers; B.skip_layer = L.skip_layer;
+    B.gbar = gbar; B.gmul = g_up;
+    for (int l = 0; l < L.n_layers; ++l) {
+        B.wfragT[l] = (const h8*)packed + L.fragT_off[l];
+        B.nblkT[l] = L.nblkT[l];
+    }
+    B.w_out = (const float*)((const char*)packed + L.tail_off_bytes) + (int64_t)L.n_layers * D;
+    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_bwd<MODE_RR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BWD_BYTES));
+    hipLaunchKernelGGL(k_h2_bwd<MODE_RR>, dim3((unsigned)(Rpad / TM)), dim3(NT), SMEM_BWD_BYTES, st, B);
+    GS_LAUNCH_CHECK();
+    return wgrad_launch(MODE_RR, g_all, 2 * Rpad, 2 * Rpad, nullptr, n_freq, n_hidden, skip_layer, A_all, EMB_all, D_all, dW, db, exact_fp32, st);
 }

@@ -645,11 +645,67 @@ class _EikonalFn(torch.autograd.Function):
         return None, None, g_flat
 
 
+# "reverse": reverse over reverse, the reference's own formulation (value pass, reverse chain, tangent pass, reverse chain with the second-order
+# source: 6 row passes per sample); "tangent": forward-mode tangent rows (4 virtual rows per sample through 3 passes: 12).  Same gradient.
+EIKONAL_FORMULATION = "reverse"
+
+
+class _EikonalRRFn(torch.autograd.Function):
+    """sum_i (|grad_x f(x_i)| - 1)^2 by reverse over reverse (csrc/mlp_h2.hip MODE_RR): forward = gs_sdf_eikonal_rr_fwd (value pass + reverse
+    chain + loss), backward = gs_sdf_eikonal_rr_bwd (tangent pass + reverse chain with source + ONE weight-gradient launch over 2 n rows)."""
+
+    @staticmethod
+    def forward(ctx, pts, net, gate):
+        L = _lib.lib()
+        n = pts.shape[0]
+        x = pts.detach().contiguous().float()
+        dev = x.device
+        _, n_hidden, skip = _layer_structure(net)
+        packed, _, _ = pack_weights_h2(net)
+        Rpad = int(L.gs_sdf_eikonal_rr_rows_padded(c_int64(n)))
+        LAST_CHAIN_ROWS[4] = n
+        nl = n_hidden + 1
+        A = torch.empty((nl, 2 * Rpad, 256), dtype=torch.float32, device=dev)
+        Dp = torch.empty_like(A)
+        EMB = torch.empty((2 * Rpad, 48), dtype=torch.float32, device=dev)
+        g_all = torch.empty(2 * Rpad, dtype=torch.float32, device=dev)
+        grad_f = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        gbar = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.gs_sdf_eikonal_rr_fwd(ptr(x, torch.float32, "pts"), c_int64(n), ptr(packed), c_int(net.emb.N_freqs), c_int(n_hidden), c_int(skip), ptr(A), ptr(EMB),
+                                          ptr(Dp), ptr(g_all), ptr(grad_f), ptr(gbar), ptr(loss), stream()), "gs_sdf_eikonal_rr_fwd")
+        ctx.state = (net, n, packed, n_hidden, skip, A, EMB, Dp, g_all, gbar)
+        ctx.grad_f = grad_f          # grad_x f of the samples (tests)
+        return loss[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        net, n, packed, n_hidden, skip, A, EMB, Dp, g_all, gbar = ctx.state
+        ctx.state = None
+        L = _lib.lib()
+        dev = A.device
+        lin, _, _ = _layer_structure(net)
+        params = list(net.parameters())
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+        grads = dict(zip((id(p) for p in params), split_param_grads(net, flat)))
+        dW = [grads[id(m.weight)] for m in lin]
+        db = [grads[id(m.bias)] for m in lin]
+        g_up = g.detach().reshape(1).float().contiguous()
+        with torch.cuda.device(dev):
+            check(L.gs_sdf_eikonal_rr_bwd(c_int64(n), ptr(packed), c_int(net.emb.N_freqs), c_int(n_hidden), c_int(skip), ptr(A), ptr(EMB), ptr(Dp), ptr(g_all),
+                                          ptr(gbar), ptr(g_up), _ptr_array(dW), _ptr_array(db), c_int(1 if SDF_MLP_WGRAD_FP32 else 0), stream()),
+                  "gs_sdf_eikonal_rr_bwd")
+        return None, None, flat
+
+
 def eikonal_sq_sum(net, pts):
     """sum_i (|d net / d x (pts_i)| - 1)^2, differentiable w.r.t. the parameters of `net` (the points are constants, as in the
     reference, which detaches them)."""
     if _fusable(net, pts, "eikonal term"):
-        return _EikonalFn.apply(pts, net, param_gate(net, reuse=True))
+        fn = _EikonalRRFn if EIKONAL_FORMULATION == "reverse" else _EikonalFn
+        return fn.apply(pts, net, param_gate(net, reuse=True))
     v = pts.detach().requires_grad_(True)
     grad = torch.autograd.grad(net(v).sum(), v, create_graph=True)[0]
     return (grad.pow(2).sum(dim=-1).sqrt() - 1).pow(2).sum()

@@ -732,6 +732,22 @@ int gs_sdf_mlp_h2_wgrad(int mode, const float* g_out, int64_t n, const int64_t* 
  *   gs_sdf_mlp_h2_bwd / _wgrad as g_out. */
 int gs_sdf_eikonal_loss(const float* out_rows, int64_t n, int64_t rows_padded, float* loss,
                         float* g_unit, gs_stream_t stream);
+/* The same term by REVERSE over reverse -- the formulation of the reference's autograd (autograd.grad(..., create_graph=True) followed by
+ * a second backward, geometry/gshell_tets_geometry.py:302-324) -- at half the row passes of the tangent-row form above (default since round 4):
+ *   _fwd: value pass over the n samples x [n,3], reverse chain with g_out = 1  ->  grad_f [n,3] WRITTEN = grad_x f,
+ *         loss [1] WRITTEN = sum_i (|grad_f_i| - 1)^2, gbar [n,3] WRITTEN = d loss / d grad_f;
+ *   _bwd: tangent pass in direction g_up * gbar (the adjoint of the reverse chain), reverse chain with the second-order source, one weight-gradient
+ *         launch: dW / db (host arrays of n_hidden + 2 device pointers as for gs_sdf_mlp_h2_wgrad) ACCUMULATED with the gradient of g_up * loss;
+ *         g_up = DEVICE scalar (the upstream gradient of the loss: no host read, no scaling launch).
+ * Scratch owned by the caller, alive from _fwd to _bwd, with Rpad = gs_sdf_eikonal_rr_rows_padded(n), L = n_hidden + 1:
+ *   A_all, D_all [L * 2 Rpad * 256] floats, EMB_all [2 Rpad * 48], g_all [2 Rpad]. */
+int64_t gs_sdf_eikonal_rr_rows_padded(int64_t n);
+int gs_sdf_eikonal_rr_fwd(const float* x, int64_t n, const void* packed, int n_freq, int n_hidden, int skip_layer,
+                          float* A_all, float* EMB_all, float* D_all, float* g_all, float* grad_f, float* gbar, float* loss,
+                          gs_stream_t stream);
+int gs_sdf_eikonal_rr_bwd(int64_t n, const void* packed, int n_freq, int n_hidden, int skip_layer, float* A_all, float* EMB_all,
+                          float* D_all, const float* g_all, const float* gbar, const float* g_up, float* const* dW,
+                          float* const* db, int exact_fp32, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * G-FlexiCubes topology   (replaces the index machinery of GShellFlexiCubes.__call__,

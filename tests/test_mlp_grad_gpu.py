@@ -64,10 +64,14 @@ def test_row_sparse_backward_matches_float64_autograd(n_hidden, skip_in, need_x,
     assert worst_hip < max(20 * worst_torch, 2e-6 if wgrad_fp32 else 3e-5), (worst_hip, worst_torch)
 
 
-@pytest.mark.parametrize("n", [1000 + 7, 16])
-def test_eikonal_term_matches_float64_double_backward(n):
+@pytest.mark.parametrize("formulation,n,n_hidden,skip_in", [("reverse", 1000 + 7, 6, (3,)), ("reverse", 16, 6, (3,)), ("reverse", 129, 2, ()),
+                                                             ("tangent", 1000 + 7, 6, (3,)), ("tangent", 16, 6, (3,))])
+def test_eikonal_term_matches_float64_double_backward(formulation, n, n_hidden, skip_in, monkeypatch):
+    """both formulations of the term (reverse over reverse = the reference's; forward-mode tangent rows) against float64 autograd"""
+    from gshell_amd.geometry import mlp as M
     from gshell_amd.geometry.mlp import eikonal_sq_sum
-    net = _net()
+    monkeypatch.setattr(M, "EIKONAL_FORMULATION", formulation)
+    net = _net(n_hidden, skip_in)
     g = torch.Generator(device=DEV).manual_seed(2)
     pts = (torch.rand(n, 3, device=DEV, generator=g) * 1.2 - 0.6).contiguous()
     loss = eikonal_sq_sum(net, pts) * 0.37
@@ -84,6 +88,30 @@ def test_eikonal_term_matches_float64_double_backward(n):
             assert float(a.abs().max()) == 0.0, name
             continue
         assert _rel(a, b) < 1e-4, (name, _rel(a, b))
+
+
+def test_eikonal_reverse_formulation_gradient_of_network_output_and_empty_input():
+    """grad_x f of the reverse-over-reverse pass (its first two launches) vs autograd of the fp64 network; zero samples are legal"""
+    from gshell_amd.geometry import mlp as M
+    net = _net()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    n = 333
+    pts = (torch.rand(n, 3, device=DEV, generator=g) - 0.5).contiguous()
+    net64 = copy.deepcopy(net).double()
+
+    class Ctx:
+        pass
+    ctx = Ctx()
+    with torch.no_grad():
+        loss = M._EikonalRRFn.forward(ctx, pts, net, None)
+    v = pts.double().requires_grad_(True)
+    gr = torch.autograd.grad(net64(v).sum(), v)[0]
+    assert float((ctx.grad_f.double() - gr).abs().max()) < 1e-5 * float(gr.abs().max())
+    assert abs(float(loss) - float((gr.norm(dim=-1) - 1).pow(2).sum())) < 1e-5 * float(loss)
+    empty = M.eikonal_sq_sum(net, pts[:0])
+    assert float(empty) == 0.0
+    grads = torch.autograd.grad(empty, list(net.parameters()))
+    assert all(float(t.abs().max()) == 0.0 for t in grads)
 
 
 def test_eikonal_gradient_of_network_output_equals_autograd():

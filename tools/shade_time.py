@@ -14,7 +14,7 @@ tr.it = 1000
 for _ in range(3):
     tr.step(tg)
 names = {"gs_env_shade_fwd", "gs_env_shade_bwd_saved", "gs_bvh_build", "gs_hashgrid_encode_bwd", "gs_hashgrid_encode_bwd_binned", "gs_sdf_mlp_fwd_h1", "gs_sdf_mlp_h2_wgrad", "gs_sdf_mlp_h2_bwd",
-         "gs_sdf_mlp_h2_save_fwd"}
+         "gs_sdf_mlp_h2_save_fwd", "gs_sdf_eikonal_rr_fwd", "gs_sdf_eikonal_rr_bwd"}
 _lib.enable_op_timing(True, only=names)
 _lib.reset_op_timing()
 import time
