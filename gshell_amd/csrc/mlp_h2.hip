@@ -1097,6 +1097,7 @@ struct WgradArgs {
     int E, n_layers, skip_layer, mode;
     int slabs_per_strip;  // 32-row slabs per workgroup
     int only_output;      // 1: k_h2_wgrad handles the output layer only (the hidden layers run in k_h2_wgrad16)
+    int wg_first[MAX_LAYERS + 1];   // k_h2_wgrad16 (1-D grid): workgroups [wg_first[l], wg_first[l + 1]) reduce layer l -- in proportion to the layer's work
     float* dW[MAX_LAYERS + 1];     // torch layout [256][K_l]; [n_layers] = output layer [1][256]
     float* db[MAX_LAYERS + 1];     // [256]; the output layer's bias gradient is the caller's
 };
@@ -1240,10 +1241,15 @@ __device__ __forceinline__ void split_bf16_4(const float (&v)[4], bf4& hi, bf4& 
 #define GS_WG_PIPE 0     // 1: reload each register piece right after it has been staged (measured: 1.55 vs 1.46 ms without, both passes)
 #endif
 template <int NB, bool HAS_H, bool HAS_E>
-__device__ __forceinline__ void wgrad16_layer(const WgradArgs& W, int l, __bf16* img, int tid) {
+__device__ __forceinline__ void wgrad16_layer(const WgradArgs& W, int l, __bf16* img, int tid, int strip, int nstrips) {
     const int lane = tid & 63, wave = tid >> 6;
-    const int64_t nslabs_total = wgrad_rows(W) / WS, stride = gridDim.x, slab0 = blockIdx.x;      // round-robin slabs, as wgrad_layer
-    const int64_t nslab = slab0 < nslabs_total ? (nslabs_total - slab0 + stride - 1) / stride : 0;
+#ifndef GS_WG_CONTIG
+#define GS_WG_CONTIG 1   // 1: a workgroup reduces a CONTIGUOUS range of slabs (of the device-side row count, so any count stays balanced); 0: round-robin
+#endif
+    const int64_t nslabs_total = wgrad_rows(W) / WS;
+    const int64_t per = (nslabs_total + nstrips - 1) / nstrips;
+    const int64_t stride = GS_WG_CONTIG ? 1 : (int64_t)nstrips, slab0 = GS_WG_CONTIG ? strip * per : (int64_t)strip;
+    const int64_t nslab = slab0 < nslabs_total ? (GS_WG_CONTIG ? min(per, nslabs_total - slab0) : (nslabs_total - slab0 + stride - 1) / stride) : 0;
     if (nslab <= 0) return;
     const float* Dl = W.D + (int64_t)l * W.Rpad * D;
     const float* Xh = HAS_H ? W.A + (int64_t)(l - 1) * W.Rpad * D : nullptr;
@@ -1342,18 +1348,57 @@ __device__ __forceinline__ void wgrad16_layer(const WgradArgs& W, int l, __bf16*
         const int roff = 8 * (lane >> 5);
         const __bf16* ah = hi_img + (wave * 32 + (lane & 31)) * WB_RS + roff;
         const __bf16* al = lo_img + (wave * 32 + (lane & 31)) * WB_RS + roff;
+#ifndef GS_WG_PAIR
+#define GS_WG_PAIR 1     // 1: accumulator blocks in PAIRS, their three products interleaved (an MFMA never follows the one just issued on its own
+#endif                   //    accumulator), the next pair's four fragments requested before the current pair's six MFMAs (scheduling groups pin the order)
+        auto feat_of = [&](int b) { return (HAS_H ? (b < 8 ? D + 32 * b : 2 * D + 32 * (b - 8)) : 2 * D + 32 * b) + (lane & 31); };
+        if constexpr (GS_WG_PAIR && NB <= 8) {
+            static_assert(NB % 2 == 0, "accumulator blocks are processed in pairs");
+            constexpr int PP = NB / 2, NP = (WS / 16) * PP;        // pairs per k-step, pair steps per slab
+            bf8 dh[WS / 16], dl[WS / 16];
 #pragma unroll
-        for (int ks = 0; ks < WS / 16; ++ks) {
-            const bf8 dh = *reinterpret_cast<const bf8*>(ah + 16 * ks), dl = *reinterpret_cast<const bf8*>(al + 16 * ks);
+            for (int ks = 0; ks < WS / 16; ++ks) {
+                dh[ks] = *reinterpret_cast<const bf8*>(ah + 16 * ks);
+                dl[ks] = *reinterpret_cast<const bf8*>(al + 16 * ks);
+            }
+            bf8 xh[2][2], xl[2][2];
+            auto request = [&](int q, int buf) {
+                const int ks = q / PP, b = 2 * (q % PP);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int feat = (HAS_H ? (b < 8 ? D + 32 * b : 2 * D + 32 * (b - 8)) : 2 * D + 32 * b) + (lane & 31);
-                const bf8 xh = *reinterpret_cast<const bf8*>(hi_img + feat * WB_RS + roff + 16 * ks);
-                const bf8 xl = *reinterpret_cast<const bf8*>(lo_img + feat * WB_RS + roff + 16 * ks);
-                if (GS_WG_ABL & 1) continue;
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, xh, acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, xl, acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl, xh, acc[b], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) {
+                    xh[buf][i] = *reinterpret_cast<const bf8*>(hi_img + feat_of(b + i) * WB_RS + roff + 16 * ks);
+                    xl[buf][i] = *reinterpret_cast<const bf8*>(lo_img + feat_of(b + i) * WB_RS + roff + 16 * ks);
+                }
+            };
+            request(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (WS / 16) + 4, 0);         // the D fragments and the first pair
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int ks = q / PP, b = 2 * (q % PP), buf = q & 1;
+                if (q + 1 < NP) request(q + 1, buf ^ 1);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh[ks], xh[buf][0], acc[b], 0, 0, 0);
+                acc[b + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh[ks], xh[buf][1], acc[b + 1], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh[ks], xl[buf][0], acc[b], 0, 0, 0);
+                acc[b + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh[ks], xl[buf][1], acc[b + 1], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl[ks], xh[buf][0], acc[b], 0, 0, 0);
+                acc[b + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl[ks], xh[buf][1], acc[b + 1], 0, 0, 0);
+                if (q + 1 < NP) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // 4 LDS reads (the next pair)
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                       // 6 MFMAs (this pair)
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < WS / 16; ++ks) {
+                const bf8 dh = *reinterpret_cast<const bf8*>(ah + 16 * ks), dl = *reinterpret_cast<const bf8*>(al + 16 * ks);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const int feat = feat_of(b);
+                    const bf8 xh = *reinterpret_cast<const bf8*>(hi_img + feat * WB_RS + roff + 16 * ks);
+                    const bf8 xl = *reinterpret_cast<const bf8*>(lo_img + feat * WB_RS + roff + 16 * ks);
+                    if (GS_WG_ABL & 1) continue;
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, xh, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, xl, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl, xh, acc[b], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -1409,10 +1454,14 @@ __device__ __forceinline__ void wgrad16_layer(const WgradArgs& W, int l, __bf16*
 // planes per iteration at 3.6 TB/s, and it is that stream, not the store / MFMA phase order, that its time follows.
 __global__ void __launch_bounds__(NT, 2) k_h2_wgrad16(WgradArgs W) {
     extern __shared__ __attribute__((aligned(16))) __bf16 smem_b[];
-    const int l = blockIdx.y, tid = threadIdx.x;
-    if (l == 0) wgrad16_layer<2, false, true>(W, l, smem_b, tid);
-    else if (l == W.skip_layer) wgrad16_layer<10, true, true>(W, l, smem_b, tid);
-    else wgrad16_layer<8, true, false>(W, l, smem_b, tid);
+    const int tid = threadIdx.x;
+    int l = 0;
+    for (int k = 1; k < W.n_layers; ++k)
+        if ((int)blockIdx.x >= W.wg_first[k]) l = k;            // uniform: the table sits in scalar registers
+    const int strip = (int)blockIdx.x - W.wg_first[l], nstrips = W.wg_first[l + 1] - W.wg_first[l];
+    if (l == 0) wgrad16_layer<2, false, true>(W, l, smem_b, tid, strip, nstrips);
+    else if (l == W.skip_layer) wgrad16_layer<10, true, true>(W, l, smem_b, tid, strip, nstrips);
+    else wgrad16_layer<8, true, false>(W, l, smem_b, tid, strip, nstrips);
 }
 
 __global__ void __launch_bounds__(NT, 2) k_h2_wgrad(WgradArgs W) {
@@ -1868,8 +1917,34 @@ static int wgrad_launch(int mode, const float* g_out, int64_t Rpad, int64_t n_ro
     if (exact_fp32) {
         hipLaunchKernelGGL(k_h2_wgrad, dim3((unsigned)strips, (unsigned)(W.n_layers + 1)), dim3(NT), SMEM_WGRAD_BYTES, stream, W);
     } else {
+        // ONE round of workgroups (the 92 KB image holds a CU), dealt to the layers in proportion to their work: every workgroup ends with 256 x K float atomics on its layer's gradient, and with 80
+        // strips for every layer those 45 M atomics were HALF of the kernel's time (timing-only variants, round 4: 0.28 of 0.44 ms were left
+        // with the loads, the staging and the MFMAs all removed)
+        int n_wg = 256;
+        {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n_wg = cus;
+        }
+#ifdef GS_WG_ROUNDS
+        n_wg *= GS_WG_ROUNDS;
+#endif
+        n_wg = (int)std::max<int64_t>(W.n_layers, std::min<int64_t>(n_wg, nslabs * W.n_layers));
+#ifndef GS_WG_W0
+#define GS_WG_W0 0.6
+#endif
+        // a layer's cost per slab follows the BYTES it stages (D + X: 38 / 64 / 70 KB for the first / a hidden / the skip layer), not its MFMAs
+        auto weight = [&](int l) { return l == 0 ? (double)GS_WG_W0 : (l == W.skip_layer ? 1.1 : 1.0); };
+        double wsum = 0.0;
+        for (int l = 0; l < W.n_layers; ++l) wsum += weight(l);
+        W.wg_first[0] = 0;
+        double run = 0.0;
+        for (int l = 0; l < W.n_layers; ++l) {
+            run += weight(l);
+            const int end = l + 1 == W.n_layers ? n_wg : (int)std::lround(run / wsum * n_wg);
+            W.wg_first[l + 1] = std::max(end, W.wg_first[l] + 1);            // at least one workgroup per layer
+        }
         GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_wgrad16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_WGRAD16_BYTES));
-        hipLaunchKernelGGL(k_h2_wgrad16, dim3((unsigned)strips, (unsigned)W.n_layers), dim3(NT), SMEM_WGRAD16_BYTES, stream, W);
+        hipLaunchKernelGGL(k_h2_wgrad16, dim3((unsigned)W.wg_first[W.n_layers]), dim3(NT), SMEM_WGRAD16_BYTES, stream, W);
         W.only_output = 1;
         hipLaunchKernelGGL(k_h2_wgrad, dim3((unsigned)strips, 1), dim3(NT), SMEM_WGRAD_BYTES, stream, W);
     }

@@ -35,11 +35,19 @@ def rgb_to_srgb(img):
     return srgb if img.shape[-1] == 3 else torch.cat((srgb, img[..., 3:4]), dim=-1)
 
 
+_PIXEL_GRIDS = {}
+
+
 def pixel_grid(width, height, center_x=0.5, center_y=0.5, device="cuda"):
-    """[height, width, 2] of (x, y) pixel-centre coordinates in [0,1]."""
-    xs = (torch.arange(width, dtype=torch.float32, device=device) + center_x) / width
-    ys = (torch.arange(height, dtype=torch.float32, device=device) + center_y) / height
-    return torch.stack((xs[None, :].expand(height, width), ys[:, None].expand(height, width)), dim=-1)
+    """[height, width, 2] of (x, y) pixel-centre coordinates in [0,1].  A constant of the frame size: built once per (size, device) and
+    returned READ-ONLY (seven launches per render otherwise); callers that change it clone it."""
+    key = (int(width), int(height), float(center_x), float(center_y), str(device))
+    g = _PIXEL_GRIDS.get(key)
+    if g is None:
+        xs = (torch.arange(width, dtype=torch.float32, device=device) + center_x) / width
+        ys = (torch.arange(height, dtype=torch.float32, device=device) + center_y) / height
+        g = _PIXEL_GRIDS[key] = torch.stack((xs[None, :].expand(height, width), ys[:, None].expand(height, width)), dim=-1)
+    return g
 
 
 def scale_img_nhwc(x, size, mag='bilinear', min='area'):
