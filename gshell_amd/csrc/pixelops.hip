@@ -313,28 +313,46 @@ __global__ void __launch_bounds__(256) k_frame_sums(const float* __restrict__ st
                                                     float* __restrict__ partial, const float* __restrict__ g9, float* __restrict__ g_st, int n_sums,
                                                     int img_loss, int img_tm) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    // backward: a pixel's C gradient channels are assembled in LDS and leave as whole lines (a thread writing its own 180-byte record
-    // made every store instruction touch 64 different lines: 0.245 ms for 188 MB)
-    // ... and the forward pass reads the frame the same way: the tile is loaded as whole lines, then every thread walks its record in LDS
-    extern __shared__ float fs_tile[];          // [256][C]: BWD the gradient records, FWD the frame records
+    // Both directions read the frame tile as whole lines into LDS ([256 pixels][C], 16-byte pieces where the tile allows) and every thread walks
+    // ITS record there (stride C floats: conflict-free for odd C).  Backward: the thread first gathers the channels it needs, then zeroes its own
+    // record and assembles the gradient channels IN PLACE; the tile leaves as whole lines.  (A thread reading its 180-byte record from HBM made
+    // every load instruction touch 64 lines: 0.12 ms for 188 MB; writing it that way: 0.245 ms.)
+    extern __shared__ __attribute__((aligned(16))) float fs_tile[];          // [256][C]
     float acc[FS_COUNT];
 #pragma unroll
     for (int k = 0; k < FS_COUNT; ++k) acc[k] = 0.0f;
-    {
-        const int64_t p0 = (int64_t)blockIdx.x * 256, cnt = min((int64_t)256, n - p0) * C;
-        if (BWD) {
-            for (int q = threadIdx.x; q < 256 * C; q += 256) fs_tile[q] = 0.0f;
-        } else {
-            for (int64_t q = threadIdx.x; q < cnt; q += 256) fs_tile[q] = st[p0 * C + q];
-        }
-        __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * 256, cnt = min((int64_t)256, n - p0) * C;
+    const bool vec4 = (cnt & 3) == 0 && ((reinterpret_cast<uintptr_t>(st + p0 * C) | (BWD ? reinterpret_cast<uintptr_t>(g_st + p0 * C) : 0)) & 15) == 0;
+    if (vec4) {
+        const float4* src = reinterpret_cast<const float4*>(st + p0 * C);
+        float4* dst = reinterpret_cast<float4*>(fs_tile);
+        for (int64_t q = threadIdx.x; q < cnt / 4; q += 256) dst[q] = src[q];
+    } else {
+        for (int64_t q = threadIdx.x; q < cnt; q += 256) fs_tile[q] = st[p0 * C + q];
     }
+    __syncthreads();
     if (i < n) {
-        const float* p = BWD ? st + i * C : fs_tile + threadIdx.x * C;
-        float* g = BWD ? fs_tile + threadIdx.x * C : nullptr;
+        float* rec = fs_tile + threadIdx.x * C;
+        // the channels this thread reads (absent buffers: zeros, never used)
+        float sh[4] = {0.f, 0.f, 0.f, 0.f}, msd = 0.f, dfl[3] = {0.f, 0.f, 0.f}, spl[3] = {0.f, 0.f, 0.f}, kdv[4] = {0.f, 0.f, 0.f, 0.f},
+              ksv[4] = {0.f, 0.f, 0.f, 0.f}, nrv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (o.shaded >= 0)
+            for (int c = 0; c < 4; ++c) sh[c] = rec[o.shaded + c];
+        if (o.msdf >= 0) msd = rec[o.msdf];
+        if (o.diff >= 0 && o.spec >= 0)
+            for (int c = 0; c < 3; ++c) { dfl[c] = rec[o.diff + c]; spl[c] = rec[o.spec + c]; }
+        if (o.kdg >= 0)
+            for (int c = 0; c < 4; ++c) kdv[c] = rec[o.kdg + c];
+        if (o.ksg >= 0)
+            for (int c = 0; c < 4; ++c) ksv[c] = rec[o.ksg + c];
+        if (o.nrmg >= 0)
+            for (int c = 0; c < 4; ++c) nrv[c] = rec[o.nrmg + c];
+        float* g = BWD ? rec : nullptr;
+        if (BWD)
+            for (int c = 0; c < C; ++c) rec[c] = 0.0f;          // this thread's record only: no barrier needed
         const float m = ref[4 * i + 3];
         if (o.shaded >= 0) {
-            const float a = p[o.shaded + 3];
+            const float a = sh[3];
             acc[FS_ALPHA] = (a - m) * (a - m);
             if (BWD) g[o.shaded + 3] = g9[FS_ALPHA] * 2.0f * (a - m);
             if (img_loss >= 0) {
@@ -342,7 +360,7 @@ __global__ void __launch_bounds__(256) k_frame_sums(const float* __restrict__ st
                 // element sum of renderutils' image_loss, loss.cu) -- so that the frame has ONE consumer and ONE gradient tensor
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float x = p[o.shaded + c] * m, y = ref[4 * i + c] * m;
+                    const float x = sh[c] * m, y = ref[4 * i + c] * m;
                     const float tx = tonemap(x, img_tm), ty = tonemap(y, img_tm);
                     acc[FS_IMG] += loss_fwd(tx, ty, img_loss);
                     if (BWD) {
@@ -354,15 +372,15 @@ __global__ void __launch_bounds__(256) k_frame_sums(const float* __restrict__ st
             }
         }
         if (o.msdf >= 0) {
-            const float x = p[o.msdf];
+            const float x = msd;
             const float k0 = m == 0.0f ? 1.0f : 0.0f, k1 = m == 1.0f ? 1.0f : 0.0f;
             acc[FS_MSDF0] = fabsf(fmaxf(x, 0.0f) * k0);                      // | clamp(x, min=0) * [m == 0] - 0 |
             acc[FS_MSDF1] = fabsf(fminf(x, 0.0f) * k1 - 1.0f);               // | clamp(x, max=0) * [m == 1] - 1 |
             if (BWD) g[o.msdf] = g9[FS_MSDF0] * (x > 0.0f ? k0 : 0.0f) - g9[FS_MSDF1] * (x <= 0.0f ? k1 : 0.0f);
         }
         if (o.diff >= 0 && o.spec >= 0) {
-            const float dl = (p[o.diff] + p[o.diff + 1] + p[o.diff + 2]) / 3.0f;
-            const float sl = (p[o.spec] + p[o.spec + 1] + p[o.spec + 2]) / 3.0f;
+            const float dl = (dfl[0] + dfl[1] + dfl[2]) / 3.0f;
+            const float sl = (spl[0] + spl[1] + spl[2]) / 3.0f;
             const float v = fmaxf(fmaxf(ref[4 * i], ref[4 * i + 1]), ref[4 * i + 2]);
             float gx;
             const float t1 = fl_logsrgb((dl + sl) * m, &gx), t2 = fl_logsrgb(v * m, nullptr);
@@ -377,7 +395,7 @@ __global__ void __launch_bounds__(256) k_frame_sums(const float* __restrict__ st
             }
         }
         if (o.kdg >= 0) {
-            const float s3 = (p[o.kdg] + p[o.kdg + 1] + p[o.kdg + 2]) / 3.0f, w = p[o.kdg + 3];
+            const float s3 = (kdv[0] + kdv[1] + kdv[2]) / 3.0f, w = kdv[3];
             acc[FS_KD] = s3 * w;
             if (BWD) {
                 const float gk = g9[FS_KD] * w / 3.0f;
@@ -386,7 +404,7 @@ __global__ void __launch_bounds__(256) k_frame_sums(const float* __restrict__ st
             }
         }
         if (o.ksg >= 0) {
-            const float s3 = p[o.ksg] + p[o.ksg + 1] + p[o.ksg + 2], w = p[o.ksg + 3];
+            const float s3 = ksv[0] + ksv[1] + ksv[2], w = ksv[3];
             acc[FS_KS] = s3 * w;
             if (BWD) {
                 const float gk = g9[FS_KS] * w;
@@ -395,7 +413,7 @@ __global__ void __launch_bounds__(256) k_frame_sums(const float* __restrict__ st
             }
         }
         if (o.nrmg >= 0) {
-            const float s3 = p[o.nrmg] + p[o.nrmg + 1] + p[o.nrmg + 2], w = p[o.nrmg + 3];
+            const float s3 = nrv[0] + nrv[1] + nrv[2], w = nrv[3];
             acc[FS_NRM] = s3 * w;
             if (BWD) {
                 const float gk = g9[FS_NRM] * w;
@@ -406,8 +424,13 @@ __global__ void __launch_bounds__(256) k_frame_sums(const float* __restrict__ st
     }
     if (BWD) {
         __syncthreads();
-        const int64_t p0 = (int64_t)blockIdx.x * 256, cnt = min((int64_t)256, n - p0) * C;
-        for (int64_t q = threadIdx.x; q < cnt; q += 256) g_st[p0 * C + q] = fs_tile[q];
+        if (vec4) {
+            const float4* src = reinterpret_cast<const float4*>(fs_tile);
+            float4* dst = reinterpret_cast<float4*>(g_st + p0 * C);
+            for (int64_t q = threadIdx.x; q < cnt / 4; q += 256) dst[q] = src[q];
+        } else {
+            for (int64_t q = threadIdx.x; q < cnt; q += 256) g_st[p0 * C + q] = fs_tile[q];
+        }
         return;
     }
     __shared__ float ws[4][FS_COUNT];

@@ -65,11 +65,14 @@ def test_row_sparse_backward_matches_float64_autograd(n_hidden, skip_in, need_x,
 
 
 @pytest.mark.parametrize("formulation,n,n_hidden,skip_in", [("reverse", 1000 + 7, 6, (3,)), ("reverse", 16, 6, (3,)), ("reverse", 129, 2, ()),
-                                                             ("tangent", 1000 + 7, 6, (3,)), ("tangent", 16, 6, (3,))])
+                                                             ("reverse-fp32-wgrad", 300, 6, (3,)), ("tangent", 1000 + 7, 6, (3,)), ("tangent", 16, 6, (3,))])
 def test_eikonal_term_matches_float64_double_backward(formulation, n, n_hidden, skip_in, monkeypatch):
     """both formulations of the term (reverse over reverse = the reference's; forward-mode tangent rows) against float64 autograd"""
     from gshell_amd.geometry import mlp as M
     from gshell_amd.geometry.mlp import eikonal_sq_sum
+    if formulation.endswith("-fp32-wgrad"):          # the exact-fp32 weight-gradient kernel over the [zbar; delta] x [a; u] planes
+        monkeypatch.setattr(M, "SDF_MLP_WGRAD_FP32", True)
+        formulation = formulation.split("-")[0]
     monkeypatch.setattr(M, "EIKONAL_FORMULATION", formulation)
     net = _net(n_hidden, skip_in)
     g = torch.Generator(device=DEV).manual_seed(2)
