@@ -257,6 +257,14 @@ def pack_weights_h2(net, status=None):
     status: optional int32 [2] device tensor (word 0 is raised for a weight beyond the fp16 range)."""
     import ctypes
     lin, n_hidden, skip = _layer_structure(net)
+    # the packed image of the SAME parameter values is reused (an iteration packs for the grid pass, the eikonal term and the row-sparse
+    # backward: two of three launches and their host time -- right after the extraction's sync, where the GPU waits for the host).  Key: storage
+    # and version counter of every parameter (torch's in-place updates and HipAdam.step both bump the version).  A call that asks for the
+    # fp16-range check (`status`) always packs.
+    key = tuple((p.data_ptr(), p._version) for m in lin for p in (m.weight, m.bias))
+    cached = net.__dict__.get("_gs_packed_cache")
+    if status is None and cached is not None and cached[0] == key:
+        return cached[1], n_hidden, skip
     L = _lib.lib()
     nf = net.emb.N_freqs
     dev = lin[0].weight.device
@@ -271,6 +279,7 @@ def pack_weights_h2(net, status=None):
     with torch.cuda.device(dev):
         check(L.gs_sdf_mlp_h2_pack(PtrArr(*[t.data_ptr() for t in ws]), PtrArr(*[t.data_ptr() for t in bs]), c_int(nf), c_int(n_hidden), c_int(skip),
                                    ptr(packed), ptr(status), stream()), "gs_sdf_mlp_h2_pack")
+    net.__dict__["_gs_packed_cache"] = (key, packed)
     return packed, n_hidden, skip
 
 
@@ -665,13 +674,16 @@ class _EikonalRRFn(torch.autograd.Function):
         Rpad = int(L.gs_sdf_eikonal_rr_rows_padded(c_int64(n)))
         LAST_CHAIN_ROWS[4] = n
         nl = n_hidden + 1
-        A = torch.empty((nl, 2 * Rpad, 256), dtype=torch.float32, device=dev)
-        Dp = torch.empty_like(A)
-        EMB = torch.empty((2 * Rpad, 48), dtype=torch.float32, device=dev)
-        g_all = torch.empty(2 * Rpad, dtype=torch.float32, device=dev)
-        grad_f = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        gbar = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        # two allocations (the planes; everything else): the call sits right behind the extraction's sync, where host time is GPU idle time
+        planes = torch.empty((2, nl, 2 * Rpad, 256), dtype=torch.float32, device=dev)
+        A, Dp = planes[0], planes[1]
+        rest = torch.empty(2 * Rpad * 48 + 2 * Rpad + 6 * n + 4, dtype=torch.float32, device=dev)
+        o = 0
+        EMB = rest[o:o + 2 * Rpad * 48].view(2 * Rpad, 48); o += 2 * Rpad * 48
+        g_all = rest[o:o + 2 * Rpad]; o += 2 * Rpad
+        grad_f = rest[o:o + 3 * n].view(n, 3); o += 3 * n
+        gbar = rest[o:o + 3 * n].view(n, 3); o += 3 * n
+        loss = rest[o:o + 1]
         with torch.cuda.device(dev):
             check(L.gs_sdf_eikonal_rr_fwd(ptr(x, torch.float32, "pts"), c_int64(n), ptr(packed), c_int(net.emb.N_freqs), c_int(n_hidden), c_int(skip), ptr(A), ptr(EMB),
                                           ptr(Dp), ptr(g_all), ptr(grad_f), ptr(gbar), ptr(loss), stream()), "gs_sdf_eikonal_rr_fwd")

@@ -66,6 +66,9 @@ class HipAdam(torch.optim.Adam):
                                      vp(*[st["step"].data_ptr() for _, _, st, _ in items]), (ctypes.c_int64 * n)(*[p.numel() for p, _, _, _ in items]),
                                      (ctypes.c_double * n)(*[lr for _, _, _, lr in items]), ctypes.c_double(betas[0]), ctypes.c_double(betas[1]),
                                      ctypes.c_double(eps), ctypes.c_double(step_value), c_int(CONTRACT), stream()), "gs_adam_step")
+            # the kernel writes the parameters through raw pointers: tell autograd (saved-tensor checks, and every cache keyed on a parameter's
+            # version such as the packed SDF-network weights, see them as modified in place)
+            torch.autograd.graph.increment_version([p for p, _, _, _ in items])
         return loss
 
     def state_dict(self):

@@ -109,6 +109,7 @@ class ViewShard:
         if self.world > 1:
             for t in tensors:
                 dist.broadcast(t.data if hasattr(t, "data") else t, src=src, group=self.group)
+                torch.autograd.graph.increment_version(t)          # written through .data: caches keyed on the version (packed SDF weights) must see it
 
 
 def flat_all_reduce_grads(params, shard, buf=None):
