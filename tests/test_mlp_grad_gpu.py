@@ -64,7 +64,7 @@ def test_row_sparse_backward_matches_float64_autograd(n_hidden, skip_in, need_x,
     assert worst_hip < max(20 * worst_torch, 2e-6 if wgrad_fp32 else 3e-5), (worst_hip, worst_torch)
 
 
-@pytest.mark.parametrize("formulation,n,n_hidden,skip_in", [("reverse", 1000 + 7, 6, (3,)), ("reverse", 16, 6, (3,)), ("reverse", 129, 2, ()),
+@pytest.mark.parametrize("formulation,n,n_hidden,skip_in", [("reverse", 1000 + 7, 6, (3,)), ("reverse", 16, 6, (3,)), ("reverse", 1, 6, (3,)), ("reverse", 129, 2, ()),
                                                              ("reverse-fp32-wgrad", 300, 6, (3,)), ("tangent", 1000 + 7, 6, (3,)), ("tangent", 16, 6, (3,))])
 def test_eikonal_term_matches_float64_double_backward(formulation, n, n_hidden, skip_in, monkeypatch):
     """both formulations of the term (reverse over reverse = the reference's; forward-mode tangent rows) against float64 autograd"""
@@ -165,3 +165,29 @@ def test_row_sparse_backward_without_host_sync_equals_the_synchronising_path():
     with pytest.raises(GShellHipError):
         row_sparse_backward(net, x, gy, False)                    # ... at the next call
     del net._gs_rows_bound
+
+
+def test_packed_weights_are_reused_until_a_parameter_changes():
+    """pack_weights_h2 hands back the SAME image while every parameter's (storage, version) is unchanged and packs again after an in-place
+    update by torch OR by HipAdam (whose kernel writes through raw pointers and bumps the version counters itself)"""
+    from gshell_amd.geometry.mlp import pack_weights_h2
+    from gshell_amd.optim import HipAdam
+    net = _net()
+    a, _, _ = pack_weights_h2(net)
+    b, _, _ = pack_weights_h2(net)
+    assert a is b
+    st = torch.zeros(2, dtype=torch.int32, device=DEV)
+    c, _, _ = pack_weights_h2(net, st)                 # a call that asks for the fp16-range check always packs
+    assert c is not a and torch.equal(a, c)
+    with torch.no_grad():
+        next(iter(net.parameters())).mul_(1.5)
+    d, _, _ = pack_weights_h2(net)
+    assert d is not c and not torch.equal(c, d)
+    opt = HipAdam(net.parameters(), lr=1e-2)
+    for p in net.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    e, _, _ = pack_weights_h2(net)
+    assert e is not d and not torch.equal(d, e)
+    f, _, _ = pack_weights_h2(net)
+    assert f is e
