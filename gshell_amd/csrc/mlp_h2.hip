@@ -1376,6 +1376,7 @@ __device__ __forceinline__ void wgrad16_layer(const WgradArgs& W, int l, __bf16*
             for (int q = 0; q < NP; ++q) {
                 const int ks = q / PP, b = 2 * (q % PP), buf = q & 1;
                 if (q + 1 < NP) request(q + 1, buf ^ 1);
+                if (GS_WG_ABL & 1) continue;
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh[ks], xh[buf][0], acc[b], 0, 0, 0);
                 acc[b + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh[ks], xh[buf][1], acc[b + 1], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh[ks], xl[buf][0], acc[b], 0, 0, 0);
