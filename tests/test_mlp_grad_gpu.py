@@ -178,16 +178,16 @@ def test_packed_weights_are_reused_until_a_parameter_changes():
     assert a is b
     st = torch.zeros(2, dtype=torch.int32, device=DEV)
     c, _, _ = pack_weights_h2(net, st)                 # a call that asks for the fp16-range check always packs
-    assert c is not a and torch.equal(a, c)
+    assert c is not a and torch.equal(a[:-2], c[:-2])           # (the buffer's last bytes are alignment padding)
     with torch.no_grad():
         next(iter(net.parameters())).mul_(1.5)
     d, _, _ = pack_weights_h2(net)
-    assert d is not c and not torch.equal(c, d)
+    assert d is not c and not torch.equal(c[:-2], d[:-2])
     opt = HipAdam(net.parameters(), lr=1e-2)
     for p in net.parameters():
         p.grad = torch.ones_like(p)
     opt.step()
     e, _, _ = pack_weights_h2(net)
-    assert e is not d and not torch.equal(d, e)
+    assert e is not d and not torch.equal(d[:-2], e[:-2])
     f, _, _ = pack_weights_h2(net)
     assert f is e
