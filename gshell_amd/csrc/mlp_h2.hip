@@ -1451,8 +1451,10 @@ __device__ __forceinline__ void wgrad16_layer(const WgradArgs& W, int l, __bf16*
 // written BETWEEN the MFMA groups of slab s, every register piece re-requested for slab s + 2 as soon as consumed, one barrier per slab, the
 // loop body branch-free (a conditional around a load makes hipcc wait for ALL outstanding loads in front of every piece: 1.59 ms).  Gradients
 // identical; 1.32 ms per iteration for both passes against 1.25 (the 160 accumulators of the skip layer leave no room for the staging
-// registers: 22 spills), and 1.248 against 1.259 with the skip layer left on this kernel -- no gain: the kernel streams 4.5 GB of fp32
-// planes per iteration at 3.6 TB/s, and it is that stream, not the store / MFMA phase order, that its time follows.
+// registers: 22 spills), and 1.248 against 1.259 with the skip layer left on this kernel -- no gain.  Later timing-only variants:
+// the MFMAs are hidden, the fragment-read + MFMA loop alone runs at 80 % of the matrix rate, and what is left is the lock-step latency chain
+// store -> barrier -> reads + MFMAs -> barrier of ONE workgroup per CU; also measured without gain and removed: a 64-feature x half-K wave tile
+// (a third less LDS read traffic).
 __global__ void __launch_bounds__(NT, 2) k_h2_wgrad16(WgradArgs W) {
     extern __shared__ __attribute__((aligned(16))) __bf16 smem_b[];
     const int tid = threadIdx.x;
