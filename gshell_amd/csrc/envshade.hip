@@ -811,6 +811,12 @@ constexpr int TRACE_CHUNK = 1024;  // rays per wave
 #ifndef TRACE_REFILL
 #define TRACE_REFILL 16               // refill when at least this many lanes are idle
 #endif
+#ifndef TRACE_INNER
+#define TRACE_INNER 4                 // traversal steps between two passes of the staging / refill logic
+#endif
+#ifndef TRACE_INNER_BREAK
+#define TRACE_INNER_BREAK 1           // leave the inner loop when no lane has a ray
+#endif
 
 __global__ void __launch_bounds__(256, 6) k_shade_trace(ShadeArgs A, int64_t n_rays, int rays_per_pixel) {
     __shared__ int32_t stack[BVH_STACK * 256];
@@ -883,12 +889,20 @@ __global__ void __launch_bounds__(256, 6) k_shade_trace(ShadeArgs A, int64_t n_r
             if (fetched >= chunk_n) break;   // nothing in flight, nothing staged, nothing left
             continue;
         }
-        if (active) {
-            const int state = bvh_step(A.bvh, ray, st, 256);
-            if (state != BVH_CONTINUE) {
-                if (state == BVH_HIT) atomicAnd(&s_vis[wave][my >> 5], ~(1u << (my & 31)));
-                active = false;
+        // TRACE_INNER traversal steps per pass of the hand-out logic above: staging / refill / exit tests are ~90 instructions per pass against
+        // the ~150 of a node visit, and a lane whose ray ends here waits for the refill threshold anyway
+#pragma unroll 1
+        for (int it = 0; it < TRACE_INNER; ++it) {
+            if (active) {
+                const int state = bvh_step(A.bvh, ray, st, 256);
+                if (state != BVH_CONTINUE) {
+                    if (state == BVH_HIT) atomicAnd(&s_vis[wave][my >> 5], ~(1u << (my & 31)));
+                    active = false;
+                }
             }
+#if TRACE_INNER_BREAK
+            if (__ballot(active) == 0ull) break;
+#endif
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
