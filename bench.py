@@ -166,7 +166,7 @@ def main():
                                 "what": "same iteration with SDF_TWO_PASS = False: every grid row through the three-product fp16-pair kernel (k_h2_fwd<GRID>)"}
         # (2) coverage sensitivity: S2 / R5 / S3 scale with the covered pixels; the headline camera leaves 86 % of the frame empty
         near = [workload.make_targets(trainer, [(it * B_global + v) % 72 for v in shard.local_views(B_global)], (H, W), radius=1.4) for it in range(2)]
-        dt2, _ = timed(a.schedule_it, 4, a.extra_steps, tgts=near)          # new tensor sizes: the caching allocator and the bin scratch settle in the warm-up
+        dt2, _ = timed(a.schedule_it, 8, a.extra_steps, tgts=near)          # new tensor sizes: the caching allocator and the bin scratch settle in the warm-up (4 steps were not enough on every box)
         cov2 = _ou.last_covered_pixels
         side["coverage_sensitivity"] = {"camera_radius": 1.4, "ms_per_step": round(dt2 / a.extra_steps * 1e3, 3), "value": round(B_global * H * W * a.extra_steps / dt2 / 1e6, 4),
                                         "covered_pixels_per_rank": cov2, "coverage": None if cov2 is None else round(cov2 / (B_local * H * W), 4), "steps": a.extra_steps}
