@@ -818,13 +818,18 @@ constexpr int TRACE_CHUNK = 1024;  // rays per wave
 #define TRACE_INNER_BREAK 1           // leave the inner loop when no lane has a ray
 #endif
 
-__global__ void __launch_bounds__(256, 6) k_shade_trace(ShadeArgs A, int64_t n_rays, int rays_per_pixel) {
-    __shared__ int32_t stack[BVH_STACK * 256];
-    __shared__ float s_ray[4][6][64];
-    __shared__ int32_t s_id[4][64];
-    __shared__ uint32_t s_vis[4][TRACE_CHUNK / 32];
+#ifndef TRACE_WAVES
+#define TRACE_WAVES 1                 // waves per workgroup: each wave owns its own chunk and shares nothing, but a workgroup's slot is held until its
+                                      // slowest wave is done -- forward family with 4 / 2 / 1 waves: 3.61 / 3.53 / 3.48 ms (one box, one call)
+#endif
+constexpr int TRACE_NT = 64 * TRACE_WAVES;
+__global__ void __launch_bounds__(TRACE_NT, 6) k_shade_trace(ShadeArgs A, int64_t n_rays, int rays_per_pixel) {
+    __shared__ int32_t stack[BVH_STACK * TRACE_NT];
+    __shared__ float s_ray[TRACE_WAVES][6][64];
+    __shared__ int32_t s_id[TRACE_WAVES][64];
+    __shared__ uint32_t s_vis[TRACE_WAVES][TRACE_CHUNK / 32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t chunk0 = ((int64_t)blockIdx.x * 4 + wave) * TRACE_CHUNK;
+    const int64_t chunk0 = ((int64_t)blockIdx.x * TRACE_WAVES + wave) * TRACE_CHUNK;
     if (chunk0 >= n_rays) return;
     const int chunk_n = (int)min((int64_t)TRACE_CHUNK, n_rays - chunk0);
     if (lane < TRACE_CHUNK / 32) s_vis[wave][lane] = 0xffffffffu;
@@ -894,7 +899,7 @@ __global__ void __launch_bounds__(256, 6) k_shade_trace(ShadeArgs A, int64_t n_r
 #pragma unroll 1
         for (int it = 0; it < TRACE_INNER; ++it) {
             if (active) {
-                const int state = bvh_step(A.bvh, ray, st, 256);
+                const int state = bvh_step(A.bvh, ray, st, TRACE_NT);
                 if (state != BVH_CONTINUE) {
                     if (state == BVH_HIT) atomicAnd(&s_vis[wave][my >> 5], ~(1u << (my & 31)));
                     active = false;
@@ -1247,7 +1252,7 @@ extern "C" int gs_env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n
     A.spec = spec;
     int64_t lanes = n_cov * A.G;
     hipLaunchKernelGGL(k_shade_samples<false>, dim3((unsigned)gs::cdiv(lanes, 256)), dim3(256), 0, stream, A);
-    hipLaunchKernelGGL(k_shade_trace, dim3((unsigned)gs::cdiv(n_rays, 4 * TRACE_CHUNK)), dim3(256), 0, stream, A, n_rays, (int)S2);
+    hipLaunchKernelGGL(k_shade_trace, dim3((unsigned)gs::cdiv(n_rays, TRACE_WAVES * TRACE_CHUNK)), dim3(TRACE_NT), 0, stream, A, n_rays, (int)S2);
     if (diff && spec) hipLaunchKernelGGL(k_shade_accumulate, dim3((unsigned)gs::cdiv(lanes, 256)), dim3(256), 0, stream, A);
     GS_LAUNCH_CHECK();
     return 0;
