@@ -41,6 +41,8 @@ void set_scene(const float* verts, const int* tris, long long T) {
     }
     optixhost::g_scene.v0e1e2 = g_tri.data();
     optixhost::g_scene.T = T;
+    ah_grid_free(&optixhost::g_scene.grid);
+    if (optixhost::g_scene.use_grid) ah_grid_build(&optixhost::g_scene.grid, g_tri.data(), T);   // not built (degenerate scene): brute force
 }
 
 struct Args {
@@ -90,6 +92,9 @@ extern "C" {
 
 // host threads of the pixel loop (1 = launch order z, y, x: deterministic atomicAdd order into light_grad)
 void ref_set_threads(int n) { omp_set_num_threads(n > 0 ? n : omp_get_num_procs()); }
+
+// any-hit evaluation of the launches that follow: 0 = every triangle (the definition), 1 = grid-filtered candidates (default)
+void ref_set_anyhit_mode(int use_grid) { optixhost::g_scene.use_grid = use_grid ? 1 : 0; }
 
 // env_shade_fwd (torch_bindings.cpp:123-189).  diff / spec [B,H,W,3] are zero-filled here like torch::zeros there.
 int ref_env_shade_fwd(const float* mask, const float* ro, const float* gb_pos, const float* gb_normal, const float* view_pos,
@@ -179,6 +184,18 @@ int ref_env_shade_trace_pixel(int x, int y, int z, float* out) {
         pdf_light = lightPDF(d);
         o = out + (2 * i + 1) * 6;
         o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = pdf_light; o[4] = pdf_bsdf; o[5] = shadow_test(idx, ray_origin, d, 0.f);
+    }
+    return 0;
+}
+
+// the same record for a list of pixels (linear index (z * H + y) * W + x) of the LAST launch: out [n_pix, 2*n*n, 6]
+int ref_env_shade_trace_pixels(const long long* pix, long long n_pix, float* out) {
+    const uint3 dim = optixhost::g_dim;
+    const long long S2 = 2LL * params.n_samples_x * params.n_samples_x;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long long i = 0; i < n_pix; ++i) {
+        const long long p = pix[i];
+        ref_env_shade_trace_pixel((int)(p % dim.x), (int)((p / dim.x) % dim.y), (int)(p / ((long long)dim.x * dim.y)), out + i * S2 * 6);
     }
     return 0;
 }

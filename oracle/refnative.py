@@ -106,6 +106,20 @@ def env_shade_bwd(mask, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pd
     return tuple(a for a, _ in outs)
 
 
+def set_anyhit_mode(grid):
+    """any-hit evaluation of the following env-shade launches: False = every triangle (the definition), True = the grid-filtered
+    candidates of the same predicate (oracle/anyhit_grid.h; the default)."""
+    _lib("ref_envshade").ref_set_anyhit_mode(ctypes.c_int(1 if grid else 0))
+
+
+def env_shade_trace_pixels(pix, n):
+    """Per-sample records [len(pix), 2 n^2, 6] of the pixels `pix` (linear indices (z H + y) W + x) of the LAST launch."""
+    pix = np.ascontiguousarray(pix, dtype=np.int64)
+    out, p = _out((pix.shape[0], 2 * n * n, 6))
+    _lib("ref_envshade").ref_env_shade_trace_pixels(pix.ctypes.data_as(ctypes.c_void_p), ctypes.c_longlong(pix.shape[0]), p)
+    return out
+
+
 def env_shade_trace_pixel(x, y, z, n):
     """Per-sample record [2 n^2, 6] = (dir xyz, pdf_light, pdf_bsdf, visible) of one pixel of the LAST launch."""
     out, p = _out((2 * n * n, 6))

@@ -257,6 +257,47 @@ def any_hit_bruteforce(org, dirs, verts, tris, chunk=256):
     return hit
 
 
+_AH_LIB = None
+
+
+def _ah_lib():
+    global _AH_LIB
+    if _AH_LIB is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_c", "anyhit_c.so")
+        if not os.path.isfile(path):
+            raise RuntimeError(f"{path} is not built: run `make -C oracle`")
+        _AH_LIB = ctypes.CDLL(path)
+    return _AH_LIB
+
+
+def any_hit_c(org, dirs, verts, tris, grid=True, stats=None):
+    """`any_hit_bruteforce` evaluated by oracle/anyhit_c.c: the same float32 predicate (no contraction) over every triangle
+    (`grid=False`: the definition, pinned to the numpy loop above by tests/test_oracle_anyhit_cpu.py) or over the candidates of a
+    conservative uniform grid (`grid=True`: what the config-size tests use -- 10^6+ rays against 10^5+ triangles in seconds; asserted
+    identical to the definition by the same test file).  `stats`: a dict that receives the number of predicate evaluations."""
+    import ctypes
+    org = np.ascontiguousarray(org, dtype=f32).reshape(-1, 3)
+    dirs = np.ascontiguousarray(dirs, dtype=f32).reshape(-1, 3)
+    verts = np.ascontiguousarray(verts, dtype=f32).reshape(-1, 3)
+    tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+    assert org.shape == dirs.shape
+    assert tris.size == 0 or (tris.min() >= 0 and tris.max() < verts.shape[0])
+    out = np.zeros(org.shape[0], np.uint8)
+    st = np.zeros(1, np.int64)
+    rc = _ah_lib().ah_any_hit(ctypes.c_void_p(org.ctypes.data), ctypes.c_void_p(dirs.ctypes.data), ctypes.c_longlong(org.shape[0]),
+                              ctypes.c_void_p(verts.ctypes.data), ctypes.c_void_p(tris.ctypes.data), ctypes.c_longlong(tris.shape[0]),
+                              ctypes.c_int(1 if grid else 0), ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(st.ctypes.data))
+    assert rc == 0, rc
+    if stats is not None:
+        stats["tests"] = int(st[0])
+    return out.astype(bool)
+
+
+ANY_HIT = any_hit_bruteforce        # what env_shade below traces its shadow rays with; the config-size chains set any_hit_c
+
+
 # ---- BSDF evaluation (torch, differentiable) ----------------------------------------------------------
 SPECULAR_EPSILON = 1e-4
 
@@ -372,7 +413,7 @@ def env_shade(mask, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, r
         else:
             spec_col = (0.04 * (1.0 - ks[:, 2:3]) + kd * ks[:, 2:3]) * (1.0 - ks[:, 0:1])
             s_ = pbr_specular(spec_col, nrm, wo_t, wi, alpha_t)
-        occl = any_hit_bruteforce(ro_s.detach().numpy().astype(f32), dirs, verts, tris)
+        occl = ANY_HIT(ro_s.detach().numpy().astype(f32), dirs, verts, tris)
         Vis = torch.as_tensor(((~occl).astype(f32) * f32(shadow_scale) + (f32(1.0) - f32(shadow_scale))).astype(f32))[:, None]
         k = Vis * mis * float(frac)
         return d_ * light_col * k, s_ * light_col * k
