@@ -38,6 +38,21 @@ def _texel(d, Hl, Wl):
     return y * Wl + x, border
 
 
+def _texels_within(d, Hl, Wl, tol):
+    """every probe texel a float32 evaluation of kernel.cu:123-128, :195-201 may pick for direction d: the float64 texel and, where d lies
+    within `tol` texels of a border, the texel(s) across it (u wraps, v clamps) -> flat texel ids"""
+    d = d.astype(np.float64).reshape(-1, 3)
+    fx = (np.arctan2(d[:, 0], -d[:, 2]) / (2 * np.pi) + 0.5) * Wl
+    fy = np.arccos(np.clip(d[:, 1], -1, 1)) / np.pi * Hl
+    out = []
+    for ox in (-tol, 0.0, tol):
+        for oy in (-tol, 0.0, tol):
+            x = np.clip(np.floor(fx + ox).astype(np.int64), 0, Wl - 1)
+            y = np.clip(np.floor(fy + oy).astype(np.int64), 0, Hl - 1)
+            out.append(y * Wl + x)
+    return np.unique(np.concatenate(out)) if len(d) else np.zeros(0, np.int64)
+
+
 @pytest.mark.parametrize("bsdf,n", [(b, n) for b in BSDFS for n in (1, 4, 8)])
 def test_env_shade_equals_the_reference_kernel_sample_by_sample(bsdf, n):
     _compare_env_shade(_load(f"ref_envshade_{bsdf}_n{n}.npz"), f"{bsdf}_n{n}")
@@ -65,6 +80,42 @@ def test_env_shade_equals_the_reference_kernel_under_an_occluder():
 # within 2e-4 texels of a probe-texel border (a property of the golden, flagged conservatively: none has moved an output so far).
 MEASURED_FLAGS = {"pbr_n1": (0, 0), "pbr_n4": (0, 2), "pbr_n8": (0, 3), "diffuse_n1": (0, 0), "diffuse_n4": (0, 4), "diffuse_n8": (0, 4),
                   "white_n1": (0, 0), "white_n4": (0, 1), "white_n8": (0, 6), "pbr_n8_64x64": (25, 27), "pbr_n4_occluder": (2, 5)}
+
+
+def _kink_distance(g, pix, r_dir):
+    """per sample [n_cov, 2, S]: distance (in units of the cosine) of the sample to the nearest derivative discontinuity of the BSDF, float64"""
+    nrm = g["gb_normal"].reshape(-1, 3)[pix].astype(np.float64)
+    pos = g["gb_pos"].reshape(-1, 3)[pix].astype(np.float64)
+    vp = g["view_pos"].reshape(-1, 3).astype(np.float64)                     # [B or 1, 3]: one eye per view
+    view = vp[(np.asarray(pix) // (g["mask"].shape[1] * g["mask"].shape[2])) % vp.shape[0]]
+    wo = view - pos
+    wo /= np.maximum(np.linalg.norm(wo, axis=-1, keepdims=True), 1e-300)
+    wi = r_dir.astype(np.float64)
+    n_, wo_ = nrm[:, None, None, :], wo[:, None, None, :]
+    h = wo_ + wi
+    h /= np.maximum(np.linalg.norm(h, axis=-1, keepdims=True), 1e-300)
+    wiN, nH, woH = (n_ * wi).sum(-1), (n_ * h).sum(-1), (wo_ * h).sum(-1)
+    eps = 1e-4
+    d = np.abs(wiN)
+    for c in (wiN, nH, woH):
+        d = np.minimum(d, np.minimum(np.abs(c - eps), np.abs(c - (1.0 - eps))))
+    return d
+
+
+def _pixel_anatomy(g, p, pix, dirs, k, live, vis, ref, r_k, name, mine, refv, sc):
+    i = int(np.searchsorted(pix, p))
+    print(f"  UNEXPLAINED {name} pixel {p}: product {mine[p].tolist()} reference {refv[p].tolist()} (scale {sc:.4g}); kd {g['gb_kd'].reshape(-1, 3)[p].tolist()} "
+          f"ks {g['gb_ks'].reshape(-1, 3)[p].tolist()} n {g['gb_normal'].reshape(-1, 3)[p].tolist()}")
+    if i >= len(pix) or pix[i] != p:
+        print("    (not a covered pixel)")
+        return
+    kd = _kink_distance(g, pix[i:i + 1], ref[i:i + 1, ..., :3])[0]
+    dd = np.abs(dirs[i] - ref[i, ..., :3]).max(-1)
+    krel = np.abs(k[i] - r_k[i]) / np.maximum(np.abs(r_k[i]), 1e-30)
+    score = dd / 1e-6 + krel / 1e-5 + (vis[i] != (ref[i, ..., 5] > 0)) * live[i] * 1e3 + 1e-6 / np.maximum(kd, 1e-12)
+    for (w, j) in np.argwhere(score >= np.sort(score.reshape(-1))[-6]):
+        print(f"    {'light' if w == 0 else 'bsdf'} sample {int(j)}: dir diff {dd[w, j]:.2e}  k {k[i, w, j]:.6g} / {r_k[i, w, j]:.6g}  vis {bool(vis[i, w, j])}/{bool(ref[i, w, j, 5] > 0)} "
+              f"live {bool(live[i, w, j])}  kink distance {kd[w, j]:.2e}  dir {ref[i, w, j, :3].tolist()}")
 
 
 def _compare_env_shade(g, tag):
@@ -101,9 +152,14 @@ def _compare_env_shade(g, tag):
     tex_off = tex_flip | tex_near
     flagged = moved | k_off | vis_off | tex_off
     pix_flag = flagged.reshape(len(pix), -1).any(-1)
+    # a sample ON a kink of the BSDF (bsdf.h: max(n.wi, 0) of fwdLambert, the `> SPECULAR_EPSILON` front test and the clamps of the cosines to
+    # [1e-4, 1 - 1e-4] in the specular lobe): the VALUE is continuous there, its DERIVATIVE is not -- a last-ulp difference of the dot product
+    # switches a whole term of the gradient on or off.  Such samples are flagged for the gradient checks only (the forward stays strict).
+    kink = ~moved & (_kink_distance(g, pix, r_dir) < 2e-6)
+    pix_kink = pix_flag | kink.reshape(len(pix), -1).any(-1)
     n_samples = flagged.size
     causes = dict(sample_moved=int(moved.sum()), pdf_branch_or_texel=int(k_off.sum()), shadow_ray=int(vis_off.sum()), probe_texel_flip=int(tex_flip.sum()),
-                  probe_texel_border=int(tex_near.sum()))
+                  probe_texel_border=int(tex_near.sum()), gradient_kink=int((kink & ~flagged).sum()))
     n_flip = int((moved | k_off | vis_off | tex_flip).sum())
     n_border = int((tex_near & ~(k_off | vis_off)).sum())
 
@@ -111,14 +167,20 @@ def _compare_env_shade(g, tag):
     clean = np.zeros(B * H * W, bool)
     clean[pix[~pix_flag]] = True
     clean |= g["mask"].reshape(-1) <= 0                                     # uncovered pixels must be exactly zero
+    clean_grad = np.zeros(B * H * W, bool)
+    clean_grad[pix[~pix_kink]] = True
+    clean_grad |= g["mask"].reshape(-1) <= 0
     outside = {}
 
     def check_img(name, mine, refv, tol):
         mine, refv = mine.reshape(-1, 3), refv.reshape(-1, 3)
         sc = max(float(np.abs(refv).max()), 1e-30)
         bad = np.abs(mine - refv).max(-1) > tol * sc
-        outside[name] = int((bad & ~clean).sum())                           # pixels with a flagged sample that also moved the output
-        assert not (bad & clean).any(), (name, np.flatnonzero(bad & clean)[:8], float(np.abs(mine - refv).max() / sc))
+        ok = clean_grad if name.startswith("g_") else clean
+        outside[name] = int((bad & ~ok).sum())                              # pixels with a flagged sample that also moved the output
+        for p in np.flatnonzero(bad & ok)[:3]:                              # explain before failing: the raw per-sample comparison of the pixel
+            _pixel_anatomy(g, int(p), pix, dirs, k, live, vis, ref, r_k, name, mine, refv, sc)
+        assert not (bad & ok).any(), (name, np.flatnonzero(bad & ok)[:8], float(np.abs(mine - refv).max() / sc))
     check_img("diff", d.detach().cpu().numpy(), g["diff"], 1e-4)
     check_img("spec", s.detach().cpu().numpy(), g["spec"], 1e-4)
     unc = g["mask"].reshape(-1) <= 0
@@ -131,9 +193,10 @@ def _compare_env_shade(g, tag):
         # 2e-4: sums of O(2 n^2) cancelling float32 terms, each up to ~300 x the result for the normal gradient
         check_img(f"g_{nm}", leaf.grad.cpu().numpy(), refv, 2e-4)
     # light gradient: texels no flagged sample touches (on either side) must agree
+    # (a flagged border sample may land on EITHER side of its border in either build: both texels count as touched)
     touched = np.zeros(Hl * Wl, bool)
-    touched[tex_r[flagged]] = True
-    touched[tex_h[flagged]] = True
+    touched[_texels_within(r_dir[flagged], Hl, Wl, 4e-4)] = True
+    touched[_texels_within(dirs[flagged], Hl, Wl, 4e-4)] = True
     gl, gl_ref = leaves[4].grad.cpu().numpy().reshape(-1, 3), g["g_light"].reshape(-1, 3)
     sc = float(np.abs(gl_ref).max())
     bad = np.abs(gl - gl_ref).max(-1) > 1e-4 * sc
