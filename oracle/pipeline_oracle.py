@@ -55,9 +55,9 @@ def render_mesh(v_pos, faces, v_nrm, msdf, mvp, campos, light, background, noise
     H, W = resolution
     B = mvp.shape[0]
     tri_np = faces.numpy().astype(np.int32)
-    v_pos_clip = ro.xfm_points(v_pos[None], mvp)
+    v_pos_clip = ro.xfm_points_kernel_order(v_pos[None], mvp)
     # discrete decisions (coverage, sample placement) are always made from float32 values, whatever dtype the floats run in
-    ids = torch.tensor(ro.rasterize_ids_c(ro.xfm_points(v_pos.detach().float()[None], mvp.float()).numpy(), tri_np, H, W))     # oracle/raster_c.c
+    ids = torch.tensor(ro.rasterize_ids_c(ro.xfm_points_kernel_order(v_pos.detach().float()[None], mvp.float()).numpy(), tri_np, H, W))     # oracle/raster_c.c
     rast, rast_db = ro.rast_from_ids(v_pos_clip, faces, ids)
     visible = torch.unique(ids[ids >= 0])
     gb_pos = ro.interpolate(v_pos[None], rast, faces)

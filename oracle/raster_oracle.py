@@ -32,6 +32,17 @@ def xfm_points(points, matrix):
     return out
 
 
+def xfm_points_kernel_order(points, matrix):
+    """`xfm_points` with the sums in the CUDA kernel's order (renderutils/c_src/mesh.cu:43-46: x m0 + y m1 + z m2 + m3, left to right), each
+    product and sum rounded to the tensor's dtype (no contraction) -- what the end-to-end chains use, so that the clip-space coordinates the
+    oracle rasterises are bit for bit the ones the HIP path (compiled -ffp-contract=off) rasterises: the last bit of a clip coordinate decides
+    a handful of the 5 10^5 coverage tests of a 512 x 512 frame.  (nvcc contracts the same expression into fused multiply-adds, so the
+    reference's own last bits are a third variant; xfm_points above is the reference's python branch.)  points [1 or B, V, 3], matrix [B, 4, 4]."""
+    x, y, z = points[..., 0:1], points[..., 1:2], points[..., 2:3]              # [Bp, V, 1]
+    m = matrix[:, None, :, :]                                                   # [B, 1, 4(out), 4(in)]
+    return ((x * m[..., 0] + y * m[..., 1]) + z * m[..., 2]) + m[..., 3]
+
+
 def _project_fix(p, H, W):
     x, y, w = p[..., 0], p[..., 1], p[..., 3]
     with np.errstate(all="ignore"):

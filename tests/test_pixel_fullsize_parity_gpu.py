@@ -58,6 +58,8 @@ def test_xfm_rasterise_ids_bit_exact_and_rast_within_1e4(scene):
     # R1 at this size: the clip-space positions themselves
     ref_clip = ro.xfm_points(s['mesh'].v_pos.detach().cpu()[None], s['mvp'].cpu())
     assert float((s['clip_c'] - ref_clip).abs().max()) <= 1e-5 * float(ref_clip.abs().max())
+    # ... and bit for bit the kernel-order restatement the end-to-end oracle chains rasterise from (mesh.cu:43-46 without contraction)
+    assert torch.equal(s['clip_c'], ro.xfm_points_kernel_order(s['mesh'].v_pos.detach().cpu()[None], s['mvp'].cpu()))
     front = s['clip_c'][:, s['tri_c'].reshape(-1), 3].reshape(2, -1, 3) > 1e-6
     n_clip = (front.any(-1) & ~front.all(-1)).sum(-1)
     assert int(n_clip[0]) == 0 and int(n_clip[1]) > 200, n_clip     # view 1 exercises the near-clip path on hundreds of triangles
