@@ -99,6 +99,8 @@ struct H2Args {
     int n_layers;         // hidden-producing layers (first + n_hidden)
     int skip_layer;       // index (>= 1) of the layer whose input is [h | emb], or -1
     const h8* wfrag[MAX_LAYERS];    // fragment-major weights: [k-step][wave 8][piece 2][lane 64] x 16 B
+    const float* tailR;             // k_h1r_fwd: [n_layers][256] biases x c, [256] output weights / c   (c = 100 log2(e), see r1_act_a)
+    const h8* wfragR[MAX_LAYERS];   // k_h1r_fwd: [feature block 8][k-step][lane 64] x 16 B, high pieces, K in the register-resident order
     const float* bias[MAX_LAYERS];  // [256] fp32
     const float* w_out;             // [256] fp32 followed by the output bias
     float tau;                      // MODE_FIX: > 0 = also record status[ST_MAXREL] = max |new - old| / max(tau, |new|)  (status then has 3 words)
@@ -851,6 +853,303 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? GS_H1_WAVES : GS_H1_WAVES4)
     }
 }
 
+// ---- one-product forward, REGISTER-RESIDENT activations (round 5) -----------------------------------------------------------------------
+// k_h1_fwd above is operand-delivery bound: per MFMA it reads 1 KB of activations from LDS and 0.5 KB of weights through L1, both pipes at
+// their limit with the matrix pipe ~40 % busy (profiles/r03_h1_dissection.txt), and every 64-row tile re-reads the 0.65 MB weight image from
+// L2.  This kernel changes the ratio instead of the schedule:
+//   * ONE wave carries a 64-row tile through all layers and keeps its activations IN REGISTERS.  The transposed product D[feature][row] leaves
+//     lane (row n, half h) with features 32 mb + 4 h + 8 g + j (g, j < 4) of ITS row -- which is already a valid B operand of the next layer if
+//     k-slot (step s', half h, element i) of that layer is DEFINED as feature F(s', h, i) = 32 (s' / 2) + 4 h + 8 (2 (s' % 2) + i / 4) + i % 4:
+//     the K order of a GEMM is free, so the weights are packed in that order (k_h2_pack, third section) and no lane ever exchanges a value.
+//     bias -> accumulator init, softplus on the 16 + 16 accumulator values of a feature block, v_cvt_pk_f16_f32 into the next layer's fragments.
+//   * weights are the A operand, staged through LDS once per WORKGROUP (4 waves = 4 tiles = 256 rows) in chunks of one 32-feature block
+//     (16 KB, double buffered, one barrier per chunk) and each 1 KB fragment feeds both 32-row blocks of the wave: 0.5 KB of LDS per MFMA, no
+//     activation traffic at all, a quarter of the L2 weight traffic.
+//   * one wave per SIMD (~400 VGPRs): the matrix pipe is kept busy by the wave's own independent work -- the softplus of feature block mb - 1
+//     is issued between the MFMAs of block mb (sched_group_barrier pins the interleave).
+// Same arithmetic class as k_h1_fwd (fp16 operands, fp32 accumulation; the K order differs, so values differ in the last bits of fp32 sums);
+// the positional encoding uses v_sin_f32 / v_cos_f32 (absolute error ~1e-6, the fp16 rounding that follows is 5e-4).
+constexpr int R1_STEPS_MAX = D / 16 + EK / 16;                 // k-steps of a chunk at the skip layer
+constexpr int R1_STAGE = (R1_STEPS_MAX * 64 + 255) / 256;      // h8 per thread and chunk (5)
+constexpr int R1_CHUNK = R1_STAGE * 256;                       // h8 per LDS buffer (20 KB): EVERY chunk is staged as 1280 fragments -- a shorter
+                                                               // chunk drags the head of the next one (or of the fp32 tail) along, unread: no predicates
+constexpr int R1_BUFS = 3;                                     // ring: chunk c is read while c + 1 is already visible (its first fragments are
+                                                               // requested BEFORE the barrier that ends c) and c + 2 is being written
+constexpr int R1_ENC = 4 * 2 * (EK / 16) * 64;                 // h8: the four waves' encoding fragments [wave][row block 2][k-step 3][lane 64] (24 KB)
+constexpr size_t SMEM_H1R_BYTES = (size_t)(R1_BUFS * R1_CHUNK + R1_ENC) * sizeof(h8) + (size_t)(MAX_LAYERS + 1) * D * sizeof(float);
+
+// global -> LDS without staging registers: global_load_lds_dwordx4, lane i of the wave writes its 16 bytes at M0 + 16 i.  As ONE asm statement: a
+// DMA issued through the builtin is a pending LDS write on the compiler's books, so it waits `vmcnt(0)` in front of the next ds_read -- the whole
+// L2 round trip, every block.  An asm DMA is invisible to that bookkeeping; the kernel waits for it itself (r1_dma_wait) before the barrier that
+// publishes the chunk, one block of MFMAs later.  M0 is saved and restored inside the statement (it is compiler-reserved).
+__device__ __forceinline__ void r1_dma_chunk(const h8* __restrict__ src, h8* dst_buf, int tid) {
+    static_assert(R1_STAGE == 5, "five 4 KB pieces per chunk are written out below");
+    const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) h8*)(dst_buf + (tid & ~63)));
+    uint32_t off = (uint32_t)tid * 16u, keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "v_add_u32 %1, 0x1000, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "v_add_u32 %1, 0x1000, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "v_add_u32 %1, 0x1000, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "v_add_u32 %1, 0x1000, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "+v"(off)
+        : "s"(src), "s"(lds)
+        : "memory", "scc");
+}
+__device__ __forceinline__ void r1_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ int r1_steps(int l, int skip_layer) { return l == 0 ? EK / 16 : D / 16 + (l == skip_layer ? EK / 16 : 0); }
+
+#ifndef GS_H1R_ABL
+#define GS_H1R_ABL 0         // timing-only ablations, compiled only under GS_EXPERIMENT: 1 = no activation function, 2 = no MFMAs, 4 = no weight DMA, 8 = no fences
+#endif
+#if defined(GS_EXPERIMENT) && (GS_H1R_ABL & 2)
+#define R1_MFMA(a, b, c) (c)
+#else
+#define R1_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
+#ifndef GS_H1R_PD
+#define GS_H1R_PD 3          // weight fragments (LDS -> registers) in flight ahead of the MFMAs that use them
+#endif
+#if defined(GS_EXPERIMENT) && (GS_H1R_ABL & 8)
+#define R1_FENCE()
+#else
+#define R1_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// The activation function in the kernel's SCALED variables.  With c = 100 log2(e), softplus_100(z) = max(z, 0) + log2(1 + 2^-|c z|) / c, so in
+// z' = c z and a' = c a it reads  a' = max(z', 0) + log2(1 + 2^-|z'|): no multiplications.  The scaling is free: z' = W a' + c b for the ORIGINAL
+// W of every layer fed by activations (k_h2_pack scales the biases, the weights that multiply the encoding, and the output weights by 1 / c).
+// Two halves, so that each can be placed behind one of a k-step's two MFMAs: one wave per SIMD hides ~5 single-issue instructions per MFMA.
+struct R1Half { float z0, z1, l0, l1; };
+__device__ __forceinline__ R1Half r1_act_a(float z0, float z1) {
+    R1Half q;
+    q.z0 = z0; q.z1 = z1;
+#if defined(GS_EXPERIMENT) && (GS_H1R_ABL & 1)      // timing only (WRONG results): no activation function
+    q.l0 = 0.f; q.l1 = 0.f;
+#else
+    const float e0 = __builtin_amdgcn_exp2f(-fabsf(z0)) + 1.0f, e1 = __builtin_amdgcn_exp2f(-fabsf(z1)) + 1.0f;
+    q.l0 = __builtin_amdgcn_logf(e0);
+    q.l1 = __builtin_amdgcn_logf(e1);
+#endif
+    return q;
+}
+__device__ __forceinline__ f2 r1_act_b(const R1Half& q) {
+    float m0, m1;
+    // plain v_max_f32: fmaxf / fmed3 cost a canonicalising v_max on top (the unused second input keeps the asm behind the logarithm)
+    asm("v_max_f32 %0, 0, %1" : "=v"(m0) : "v"(q.z0), "v"(q.l0));
+    asm("v_max_f32 %0, 0, %1" : "=v"(m1) : "v"(q.z1), "v"(q.l1));
+    return f2{m0 + q.l0, m1 + q.l1};
+}
+
+struct R1State {
+    int c, n_chunks;          // next chunk to be COMPUTED, chunks in total
+    int cur, nxt, nx2;        // LDS buffer (h8 offset) of chunk c, c + 1, c + 2
+};
+
+// One layer of the register-resident forward.  FIRST: K = the encoding (3 k-steps); SKIP: 16 + 3 k-steps; LAST: the activation is multiplied by the
+// output weights and summed instead of becoming the next layer's fragments.  Everything is unrolled and BRANCH-FREE -- one basic block per layer: a
+// branch anywhere lets the compiler sink every block's activation function into the layer's last block, where its results are first used -- and the
+// order inside a k-step is pinned with scheduling fences: [fragment read, MFMA] [first half of a pair's activation] [MFMA] [second half].
+template <bool FIRST, bool SKIP, bool LAST>
+__device__ __forceinline__ void r1_layer(const H2Args& A, int l, R1State& S, h8* smem_w, const float* tailL, int tid, int lane, int h, const h8* Benc,
+                                         const h8 (&Bin)[D / 16][2], h8 (&Bout)[D / 16][2], f2 (&part)[2]) {
+    constexpr int NS = FIRST ? EK / 16 : D / 16 + (SKIP ? EK / 16 : 0);
+    constexpr int PD = GS_H1R_PD < NS ? GS_H1R_PD : NS - 1;
+    const float* bl = tailL + l * D + 4 * h;                    // this lane's bias entries: + 32 mb + 8 g
+    const float* wo = tailL + A.n_layers * D + 4 * h;           // (LAST) output weights / c
+    v16f accs[2][2];                  // block mb accumulates in accs[mb & 1] while the activation function reads accs[(mb - 1) & 1]
+    float4 wqs[2][4];                 // (LAST) the blocks' output weights, same parity
+    uint32_t pend[4];                 // packed activations of the fragment being assembled
+    h8 fr[PD + 1];                    // fragment ring; the first PD fragments of a chunk are requested at the end of the previous one
+    {
+        const h8* w0 = smem_w + S.cur + lane;
+#pragma unroll
+        for (int i = 0; i < PD; ++i) fr[i] = w0[i * 64];
+    }
+    R1_FENCE();
+#pragma unroll
+    for (int mb = 0; mb <= 8; ++mb) {
+        v16f (&acc)[2] = accs[mb & 1];
+        v16f (&accP)[2] = accs[(mb + 1) & 1];
+        float4 (&wq)[4] = wqs[mb & 1];
+        float4 (&wP)[4] = wqs[(mb + 1) & 1];
+        if (mb < 8) {
+            // chunk c + 2: L2 -> its buffer (last read two barriers ago); it lands during this block and is published by the barrier that ends it
+            // (unconditional: past the end the last chunk is fetched again into a buffer nobody reads)
+#if !(defined(GS_EXPERIMENT) && (GS_H1R_ABL & 4))
+            {
+                const int c2 = min(S.c + 2, S.n_chunks - 1), l2 = c2 >> 3;
+                r1_dma_chunk(A.wfragR[l2] + (int64_t)(c2 & 7) * (r1_steps(l2, A.skip_layer) * 64), smem_w + S.nx2, tid);
+            }
+#endif
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bl + mb * 32 + 8 * g);          // LDS (broadcast reads)
+                if (LAST) wq[g] = *reinterpret_cast<const float4*>(wo + mb * 32 + 8 * g);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) { acc[r][4 * g] = b4.x; acc[r][4 * g + 1] = b4.y; acc[r][4 * g + 2] = b4.z; acc[r][4 * g + 3] = b4.w; }
+            }
+            R1_FENCE();
+        }
+        // pair pp (0..15) of the previous block: r = pp / 8, accumulator elements 2 (pp % 8), + 1
+        auto pair_a = [&](int pp) { const int r = pp >> 3, v = 2 * (pp & 7); return r1_act_a(accP[r][v], accP[r][v + 1]); };
+        auto pair_b = [&](int pp, const R1Half& q) {
+            const int r = pp >> 3, v = 2 * (pp & 7), pb = mb > 0 ? mb - 1 : 0;
+            const f2 a = r1_act_b(q);
+            if (LAST) {
+                const float4 w4 = wP[v >> 2];
+                part[r].x = __builtin_fmaf(a.x, (v & 2) ? w4.z : w4.x, part[r].x);
+                part[r].y = __builtin_fmaf(a.y, (v & 2) ? w4.w : w4.y, part[r].y);
+            } else {
+                // four consecutive pairs are one fragment of the next layer: elements 8 s .. 8 s + 7 of feature block pb = k-step 2 pb + s.  The
+                // fragment is assembled from its four packed words and assigned ONCE: element-wise inserts into the fragment array made every
+                // insert a read-modify-write of a 128-bit tuple for the register allocator (1 500 spilled registers)
+                const h2 q2 = __builtin_convertvector(a, h2);
+                pend[pp & 3] = __builtin_bit_cast(uint32_t, q2);
+                if ((pp & 3) == 3) {
+                    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                    Bout[2 * pb + ((pp & 7) >> 2)][r] = __builtin_bit_cast(h8, u4{pend[0], pend[1], pend[2], pend[3]});
+                }
+            }
+        };
+        if (mb < 8) {
+            const h8* wl = smem_w + S.cur + lane;
+            const h8* wn = smem_w + S.nxt + lane;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                // request: this chunk's fragment s + PD, or (its last PD steps) the NEXT chunk's first fragments -- visible since the last barrier
+                // (fragment s of block mb lives in ring slot (mb NS + s) % (PD + 1): the ring runs on across the blocks of a layer)
+                const int q0 = mb * NS + s;
+                if (s + PD < NS) fr[(q0 + PD) % (PD + 1)] = wl[(s + PD) * 64];
+                else if (mb < 7) fr[(q0 + PD) % (PD + 1)] = wn[(s + PD - NS) * 64];
+                const h8 a = fr[q0 % (PD + 1)];
+                // (the encoding's fragments come from LDS: two layers read them, 24 registers would hold them for all seven)
+                const h8 b0 = (FIRST || s >= D / 16) ? Benc[(FIRST ? s : s - D / 16) * 64] : Bin[s < D / 16 ? s : 0][0];
+                const h8 b1 = (FIRST || s >= D / 16) ? Benc[((EK / 16) + (FIRST ? s : s - D / 16)) * 64] : Bin[s < D / 16 ? s : 0][1];
+                const bool epi = mb > 0 && NS >= 16 && s < 16;          // the previous block's 16 pairs ride on this block's first 16 k-steps
+                acc[0] = R1_MFMA(a, b0, acc[0]);
+                R1_FENCE();
+                R1Half q;
+                if (epi) { q = pair_a(s); R1_FENCE(); }
+                acc[1] = R1_MFMA(a, b1, acc[1]);
+                R1_FENCE();
+                if (epi) { pair_b(s, q); R1_FENCE(); }
+            }
+        }
+        if (mb > 0 && (mb == 8 || NS < 16)) {          // not interleaved: the first layer's short k-loop, and every layer's last block
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) {
+                pair_b(pp, pair_a(pp));
+                if (pp & 1) R1_FENCE();               // two pairs in flight, not sixteen
+            }
+        }
+        if (mb < 8) {
+            r1_dma_wait();        // this wave's pieces of chunk c + 2 have landed (requested a block of MFMAs ago)
+            __syncthreads();      // every wave is done with chunk c's buffer; chunk c + 2 is visible
+            ++S.c;
+            const int t = S.cur;
+            S.cur = S.nxt; S.nxt = S.nx2; S.nx2 = t;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 1) k_h1r_fwd(H2Args A) {
+    extern __shared__ __attribute__((aligned(16))) h8 smem_w[];           // [R1_BUFS][R1_CHUNK] | encoding fragments | scaled biases + output weights
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave, r0 = tile * 64;
+
+    // ---- weight chunks c = 8 l + mb: chunks 0, 1 -> LDS now, chunk c + 2 during chunk c
+    R1State S{0, A.n_layers * 8, 0, R1_CHUNK, 2 * R1_CHUNK};
+    auto chunk_src = [&](int c) { const int l = c >> 3; return A.wfragR[l] + (int64_t)(c & 7) * (r1_steps(l, A.skip_layer) * 64); };
+    r1_dma_chunk(chunk_src(0), smem_w, tid);            // n_chunks >= 8
+    r1_dma_chunk(chunk_src(1), smem_w + R1_CHUNK, tid);
+    float* tailL = reinterpret_cast<float*>(smem_w + R1_BUFS * R1_CHUNK + R1_ENC);
+    for (int i = tid; i < (A.n_layers + 1) * D; i += 256) tailL[i] = A.tailR[i];
+    r1_dma_wait();
+
+    // ---- positional encoding of the wave's two 32-row blocks, straight into B fragments: k-slot (s', h, i) = encoding entry 16 s' + 8 h + i
+    h8* Benc = smem_w + R1_BUFS * R1_CHUNK + wave * (2 * (EK / 16) * 64) + lane;        // [row block][k-step][lane]
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int64_t row = r0 + 32 * r + n;
+        float p[3] = {0.f, 0.f, 0.f};
+        if (row < A.N) { p[0] = A.x[3 * row]; p[1] = A.x[3 * row + 1]; p[2] = A.x[3 * row + 2]; }
+        float e[EK];
+#pragma unroll
+        for (int i = 0; i < EK; ++i) e[i] = 0.f;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) e[ax] = fminf(fmaxf(p[ax], -60000.0f), 60000.0f);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const float rev = p[ax] * ((float)(1 << k) * 0.15915494309189535f);          // v_sin / v_cos take revolutions
+                const bool on = k < A.n_freq && row < A.N;
+                e[3 + 6 * k + ax] = on ? __builtin_amdgcn_sinf(rev) : 0.f;
+                e[3 + 6 * k + 3 + ax] = on ? __builtin_amdgcn_cosf(rev) : 0.f;
+            }
+#pragma unroll
+        for (int s = 0; s < EK / 16; ++s) {
+            h8 f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = (_Float16)(h ? e[16 * s + 8 + i] : e[16 * s + i]);
+            Benc[(r * (EK / 16) + s) * 64] = f;
+        }
+    }
+    __syncthreads();
+
+    h8 Ba[D / 16][2], Bb[D / 16][2];          // the layers' input / output fragments, roles alternating (no copy between layers)
+    f2 part[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
+    for (int l = 0; l < A.n_layers; ++l) {
+        const bool last = l + 1 == A.n_layers, skip = l == A.skip_layer;
+#define R1_CALL(F, K, L_)                                                                                      \
+        do {                                                                                                   \
+            if (l & 1) r1_layer<F, K, L_>(A, l, S, smem_w, tailL, tid, lane, h, Benc, Bb, Ba, part);           \
+            else r1_layer<F, K, L_>(A, l, S, smem_w, tailL, tid, lane, h, Benc, Ba, Bb, part);                 \
+        } while (0)
+        if (l == 0) {
+            if (last) R1_CALL(true, false, true);
+            else R1_CALL(true, false, false);
+        } else if (last) {
+            if (skip) R1_CALL(false, true, true);
+            else R1_CALL(false, false, true);
+        } else {
+            if (skip) R1_CALL(false, true, false);
+            else R1_CALL(false, false, false);
+        }
+#undef R1_CALL
+    }
+    // ---- output layer: the two lane halves of a row hold disjoint feature sets
+    float s0 = part[0].x + part[0].y, s1 = part[1].x + part[1].y;
+    s0 += __shfl_xor(s0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    const float sv = (h ? s1 : s0) + A.w_out[D];          // lane l <-> row r0 + l
+    const int64_t row = r0 + lane;
+    const bool valid = row < A.N;
+    if (valid) A.out[row] = sv;
+    const uint64_t m = __ballot(valid && sv > 0.0f);
+    if (A.occ && lane == 0 && valid) A.occ[tile] = m;
+    if (A.status && __ballot(valid && !(fabsf(sv) < 3.0e38f)) != 0ull && lane == 0) atomicOr(&A.status[ST_NONFINITE], 1u);
+}
+
 // ---- backward chain ------------------------------------------------------------------------------------------------
 // Per 64-row tile, from the top: G = g_out (x) w_out;  for l = L-1 .. 0:  D_l = (dL/dz_l) from G and the saved activations
 // (elementwise, in the accumulator layout);  D_l -> HBM (fp32, for the weight-gradient kernel) and -> LDS as fp16 pairs;
@@ -1566,10 +1865,13 @@ struct PackLayout {
     int64_t frag_off[MAX_LAYERS];     // h8 units, forward fragments of layer l: [k-step][8 blocks][2 pieces][64 lanes]
     int64_t fragT_off[MAX_LAYERS];    // transposed fragments of layer l: [n-step 16][nblkT][2][64]
     int nblkT[MAX_LAYERS];
-    int64_t total_frags;              // forward + transposed
+    int64_t fragR_off[MAX_LAYERS];    // k_h1r_fwd's fragments of layer l: [feature block 8][k-step][64 lanes], ONE piece
+    int64_t total_frags;              // forward + transposed + register-resident
     int64_t tail_off_bytes;
 };
 
+int64_t tail_floats(int n_layers) { return (((int64_t)n_layers * D + D + 1) + 3) & ~(int64_t)3; }       // fp32 tail, padded to 16 bytes
+__host__ __device__ inline int64_t tail_r_off(const struct PackLayout& L);
 int layer_steps(int l, int skip_layer) { return l == 0 ? EK / 16 : D / 16 + (l == skip_layer ? EK / 16 : 0); }
 
 PackLayout make_layout(int n_freq, int n_hidden, int skip_layer) {
@@ -1585,10 +1887,16 @@ PackLayout make_layout(int n_freq, int n_hidden, int skip_layer) {
         L.fragT_off[l] = off;
         off += (int64_t)(D / 16) * L.nblkT[l] * 128;
     }
+    for (int l = 0; l < L.n_layers; ++l) {
+        L.fragR_off[l] = off;
+        off += (int64_t)8 * layer_steps(l, skip_layer) * 64;
+    }
     L.total_frags = off;
     L.tail_off_bytes = off * 16;
     return L;
 }
+
+__host__ __device__ inline int64_t tail_r_off(const PackLayout& L) { return ((((int64_t)L.n_layers * D + D + 1) + 3) & ~(int64_t)3); }   // floats from the tail's start
 
 struct PackArgs {
     const float* w[MAX_LAYERS + 1];   // torch Linear.weight [out, in] of every layer, output layer last
@@ -1597,6 +1905,7 @@ struct PackArgs {
     h8* frags;
     float* tail;
     uint32_t* status;                 // optional: ST_NONFINITE is raised for a weight beyond the fp16 range (split_h2 would clamp it)
+    int with_r;                       // also write k_h1r_fwd's fragment section and scaled tail
 };
 
 __global__ void __launch_bounds__(256) k_h2_pack(PackArgs P) {
@@ -1623,6 +1932,29 @@ __global__ void __launch_bounds__(256) k_h2_pack(PackArgs P) {
                 _Float16 hi, lo;
                 split_h2(v, hi, lo);
                 o[q] = piece ? lo : hi;
+            }
+        } else if (i >= L.fragR_off[0]) {      // k_h1r_fwd: rows = output features, K-slot (step, half, element) -> input index in ITS order
+            if (!P.with_r) return;
+            int l = 0;
+            while (l + 1 < L.n_layers && i >= L.fragR_off[l + 1]) ++l;
+            const int64_t j = i - L.fragR_off[l];
+            const int nsteps = l == 0 ? EK / 16 : D / 16 + (l == L.skip_layer ? EK / 16 : 0);
+            const int lane = (int)(j & 63), step = (int)((j >> 6) % nsteps), mb = (int)((j >> 6) / nsteps);
+            const int n = mb * 32 + (lane & 31), hh = lane >> 5;
+            const int Kin = l == 0 ? L.E : (l == L.skip_layer ? D + L.E : D);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                int src;
+                if (l == 0) { const int e = 16 * step + 8 * hh + q; src = e < L.E ? e : -1; }
+                else if (step < D / 16) src = 32 * (step >> 1) + 4 * hh + 8 * (2 * (step & 1) + (q >> 2)) + (q & 3);      // the accumulator layout of the layer below
+                else { const int e = 16 * (step - D / 16) + 8 * hh + q; src = e < L.E ? D + e : -1; }
+                // weights that multiply the (unscaled) encoding carry the kernel's activation scale c; those fed by scaled activations do not
+                const bool enc_in = l == 0 || step >= D / 16;
+                const float v = src >= 0 ? P.w[l][(int64_t)n * Kin + src] * (enc_in ? SP_C1 : 1.0f) : 0.f;
+                if (P.status && !(fabsf(v) <= 60000.0f)) atomicOr(&P.status[ST_NONFINITE], 1u);
+                _Float16 hi, lo;
+                split_h2(v, hi, lo);
+                o[q] = hi;
             }
         } else {                       // transposed: rows = INPUT index of the layer (h feature, or encoding entry), K = output feature n
             int l = 0;
@@ -1654,6 +1986,7 @@ __global__ void __launch_bounds__(256) k_h2_pack(PackArgs P) {
         else if (i < (int64_t)L.n_layers * D + D) v = P.w[L.n_layers][i - (int64_t)L.n_layers * D];
         else v = P.b[L.n_layers][0];
         P.tail[i] = v;
+        if (P.with_r && i < (int64_t)L.n_layers * D + D) P.tail[tail_r_off(L) + i] = i < (int64_t)L.n_layers * D ? v * SP_C1 : v * (1.0f / SP_C1);
     }
 }
 
@@ -1670,9 +2003,11 @@ void fill_fwd_args(H2Args& A, const void* packed, const PackLayout& L) {
     const float* tail = (const float*)((const char*)packed + L.tail_off_bytes);
     for (int l = 0; l < L.n_layers; ++l) {
         A.wfrag[l] = (const h8*)packed + L.frag_off[l];
+        A.wfragR[l] = (const h8*)packed + L.fragR_off[l];
         A.bias[l] = tail + (int64_t)l * D;
     }
     A.w_out = tail + (int64_t)L.n_layers * D;
+    A.tailR = tail + tail_r_off(L);
 }
 
 #ifndef GS_H2_DUAL
@@ -1755,9 +2090,12 @@ __global__ void __launch_bounds__(256) k_rr_loss(const float* __restrict__ gx, i
 
 }  // namespace
 
+static int g_h1_impl = 0;      // see gs_sdf_mlp_h1_impl below
+
 extern "C" int64_t gs_sdf_mlp_h2_packed_bytes(int n_freq, int n_hidden, int skip_layer) {
     PackLayout L = make_layout(n_freq, n_hidden, skip_layer);
-    return L.tail_off_bytes + ((int64_t)L.n_layers * D + D + 1) * 4;
+    // + one staging block: k_h1r_fwd stages every weight chunk as R1_CHUNK fragments, the last chunk's unread excess runs over the tail
+    return L.tail_off_bytes + (tail_r_off(L) + (int64_t)L.n_layers * D + D + 4) * 4 + (int64_t)R1_CHUNK * 16;
 }
 
 // weights / biases: HOST arrays of n_hidden + 2 DEVICE pointers (torch layout, Linear.weight [out, in] row-major; the
@@ -1777,6 +2115,7 @@ extern "C" int gs_sdf_mlp_h2_pack(const float* const* weights, const float* cons
     P.frags = (h8*)packed;
     P.tail = (float*)((char*)packed + P.L.tail_off_bytes);
     P.status = status;
+    P.with_r = g_h1_impl == 1;
     hipLaunchKernelGGL(k_h2_pack, dim3((unsigned)gs::cdiv(P.L.total_frags, 256)), dim3(256), 0, (hipStream_t)stream, P);
     GS_LAUNCH_CHECK();
     return 0;
@@ -1793,7 +2132,18 @@ extern "C" int gs_sdf_mlp_fwd_h2(const float* x, int64_t N, const void* packed, 
     return launch_fwd<MODE_GRID>(A, gs::cdiv(N, TM), (hipStream_t)stream);
 }
 
-// First pass of the two-pass forward: one fp16 product per algorithmic product (k_h1_fwd).  Same packed weights (high pieces).
+// which kernel gs_sdf_mlp_fwd_h1 launches: 0 = k_h1_fwd (activations in LDS, weights through L1; default), 1 = k_h1r_fwd (activations in registers,
+// weights through LDS: correct, but SLOWER on MI355X -- 5.6 ms against 2.35: a wave's VALU instructions are not hidden behind its OWN MFMAs, see
+// tools/micro/mfma_fillers.hip and DESIGN.md 7.2; kept selectable as the measured record of that design).  Same arithmetic class, different K
+// order: values agree to fp32 summation order.  impl < 0: query.  Returns the old value.  gs_sdf_mlp_h2_pack writes k_h1r_fwd's fragment section
+// only while impl == 1 is selected.
+extern "C" int gs_sdf_mlp_h1_impl(int impl) {
+    const int old = g_h1_impl;
+    if (impl == 0 || impl == 1) g_h1_impl = impl;
+    return old;
+}
+
+// First pass of the two-pass forward: one fp16 product per algorithmic product.  Same packed image (its own fragment section for k_h1r_fwd).
 extern "C" int gs_sdf_mlp_fwd_h1(const float* x, int64_t N, const void* packed, int n_freq, int n_hidden, int skip_layer, float* out,
                                  uint64_t* occ_bits, uint32_t* status, gs_stream_t stream) {
     if (N == 0) return 0;
@@ -1802,6 +2152,12 @@ extern "C" int gs_sdf_mlp_fwd_h1(const float* x, int64_t N, const void* packed, 
     H2Args A{};
     A.x = x; A.out = out; A.occ = occ_bits; A.status = status; A.N = N; A.n_freq = n_freq;
     fill_fwd_args(A, packed, make_layout(n_freq, n_hidden, skip_layer));
+    if (g_h1_impl == 1) {          // register-resident activations (round 5)
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h1r_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_H1R_BYTES));
+        hipLaunchKernelGGL(k_h1r_fwd, dim3((unsigned)gs::cdiv(N, 256)), dim3(256), SMEM_H1R_BYTES, (hipStream_t)stream, A);
+        GS_LAUNCH_CHECK();
+        return 0;
+    }
     constexpr size_t smem = smem_h1_bytes<GS_H1_RM>();
     GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h1_fwd<GS_H1_NW, GS_H1_RM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL((k_h1_fwd<GS_H1_NW, GS_H1_RM>), dim3((unsigned)gs::cdiv(N, 32 * GS_H1_RM)), dim3(64 * GS_H1_NW), smem, (hipStream_t)stream, A);

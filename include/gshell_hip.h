@@ -687,6 +687,12 @@ int gs_sdf_mlp_fwd_h2(const float* x, int64_t N, const void* packed, int n_freq,
  *   points of every sign-crossing edge -- all the reference consumes (gshell_tets.py:250, :277-290; gshell_tets_geometry.py:33-39). */
 int gs_sdf_mlp_fwd_h1(const float* x, int64_t N, const void* packed, int n_freq, int n_hidden,
                       int skip_layer, float* out, uint64_t* occ_bits, uint32_t* status, gs_stream_t stream);
+/* Kernel behind gs_sdf_mlp_fwd_h1: 0 (default) = the round-3 kernel (activations in LDS, weights through L1); 1 = activations register-resident
+ * across the layers, weights staged through LDS once per 256 rows (k_h1r_fwd, round 5: correct but slower on MI355X, kept as a measured record --
+ * DESIGN.md 7.2).  Same function and arithmetic class (geometry/mlp.py:32-40 with fp16 operands and fp32 accumulation); sums are taken in a
+ * different order.  Select BEFORE gs_sdf_mlp_h2_pack (the packer writes kernel 1's fragments only while it is selected).  impl < 0 only queries.
+ * Returns the previous setting. */
+int gs_sdf_mlp_h1_impl(int impl);
 int gs_sdf_mlp_h2_refine_rows(const float* x, const int32_t* rows, int64_t cap, const int64_t* count_dev,
                               const void* packed, int n_freq, int n_hidden, int skip_layer, float* out,
                               uint64_t* occ_bits, uint32_t* status /* [2], or [3] when tau > 0 */, float tau,

@@ -198,3 +198,37 @@ def test_flexicubes_getmesh_is_identical_with_the_two_pass_forward():
     assert ends.numel() > 500 and torch.equal(sa[ends], sb[ends])
     assert float((sa - sb).abs().max()) < mlp.SDF_TWO_PASS_TAU
     assert dict(mlp.FALLBACKS) == before, (before, dict(mlp.FALLBACKS))          # no evaluation of this test left the HIP kernels
+
+
+@pytest.mark.parametrize("n_rows", [70001, 64, 1])
+def test_register_resident_first_pass_kernel_computes_the_same_function(n_rows):
+    """gs_sdf_mlp_h1_impl(1): k_h1r_fwd (round 5; activations register-resident across the layers, weights through LDS, scaled variables z' = 100 log2(e) z,
+    hardware sin / cos) against the three-product kernel on random rows of a random network: the one-product error bound of the first pass (5e-4 = tau / 4),
+    sign words consistent with the values, rows past N untouched.  The kernel is not the default (slower on MI355X) -- this keeps it correct."""
+    from gshell_amd import _lib
+    from gshell_amd.geometry import mlp
+    from gshell_amd.geometry.mlp import MLP
+    torch.manual_seed(3)
+    net = MLP(n_freq=6, d_hidden=256, n_hidden=6, skip_in=[3]).to(DEV)
+    x = (torch.rand(n_rows, 3, device=DEV) * 2 - 1) * 1.05
+    L = _lib.lib()
+    old = L.gs_sdf_mlp_h1_impl(_lib.c_int(1))
+    try:
+        with torch.no_grad():
+            packed, n_hidden, skip = mlp.pack_weights_h2(net, status=torch.zeros(2, dtype=torch.int32, device=DEV))      # (status: always packs)
+            ref = torch.empty(n_rows, device=DEV)
+            _lib.check(L.gs_sdf_mlp_fwd_h2(_lib.ptr(x), _lib.c_int64(n_rows), _lib.ptr(packed), _lib.c_int(6), _lib.c_int(n_hidden), _lib.c_int(skip), _lib.ptr(ref),
+                                           _lib.c_void_p(0), _lib.c_void_p(0), _lib.stream()))
+            y = torch.full((n_rows + 64,), 7.0, device=DEV)
+            occ = torch.zeros((n_rows + 63) // 64, dtype=torch.int64, device=DEV)
+            st = torch.zeros(4, dtype=torch.int32, device=DEV)
+            _lib.check(L.gs_sdf_mlp_fwd_h1(_lib.ptr(x), _lib.c_int64(n_rows), _lib.ptr(packed), _lib.c_int(6), _lib.c_int(n_hidden), _lib.c_int(skip), _lib.ptr(y),
+                                           _lib.ptr(occ), _lib.ptr(st), _lib.stream()))
+    finally:
+        L.gs_sdf_mlp_h1_impl(_lib.c_int(old))
+        net.__dict__.pop("_gs_packed_cache", None)
+    assert float((y[:n_rows] - ref).abs().max()) < 5e-4
+    assert bool((y[n_rows:] == 7.0).all())
+    bits = ((occ[:, None] >> torch.arange(64, device=DEV)[None]) & 1).reshape(-1)[:n_rows].bool()
+    assert torch.equal(bits, y[:n_rows] > 0)
+    assert st.tolist()[0] == 0
