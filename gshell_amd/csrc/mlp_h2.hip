@@ -1800,11 +1800,11 @@ __global__ void __launch_bounds__(NT, 2) k_h2_wgrad(WgradArgs W) {
 // caller can size the planes by a bound (2 x crossing edges) instead of waiting for the exact count (a host sync costs
 // ~1.5 ms of launch-ahead per iteration).  count[1] is set when the bound was too small (checked by the caller off the hot path).
 constexpr int CZ_TILE = 1024;
-__global__ void __launch_bounds__(256) k_cnz_count(const float* __restrict__ g, int64_t N, int32_t* __restrict__ partial) {
+__global__ void __launch_bounds__(256) k_cnz_count(const float* __restrict__ g, int64_t stride, int64_t N, int32_t* __restrict__ partial) {
     __shared__ int lds[4];
     const int64_t base = (int64_t)blockIdx.x * CZ_TILE + threadIdx.x * 4;
     int c = 0;
-    for (int j = 0; j < 4; ++j) c += (base + j < N && g[base + j] != 0.0f) ? 1 : 0;
+    for (int j = 0; j < 4; ++j) c += (base + j < N && g[(base + j) * stride] != 0.0f) ? 1 : 0;
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -1830,14 +1830,14 @@ __global__ void __launch_bounds__(256) k_cnz_scan(int32_t* __restrict__ partial,
     int64_t run = s_sum[tid];
     for (int64_t b = lo; b < hi; ++b) { const int32_t v = partial[b]; partial[b] = (int32_t)min(run, (int64_t)0x7fffffff); run += v; }
 }
-__global__ void __launch_bounds__(256) k_cnz_write(const float* __restrict__ g, int64_t N, const int32_t* __restrict__ partial, int64_t cap,
+__global__ void __launch_bounds__(256) k_cnz_write(const float* __restrict__ g, int64_t stride, int64_t N, const int32_t* __restrict__ partial, int64_t cap,
                                                    int32_t* __restrict__ rows, float* __restrict__ g_rows) {
     __shared__ int lds[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t base = (int64_t)blockIdx.x * CZ_TILE + threadIdx.x * 4;
     float v[4];
     int c = 0;
-    for (int j = 0; j < 4; ++j) { v[j] = base + j < N ? g[base + j] : 0.0f; c += v[j] != 0.0f; }
+    for (int j = 0; j < 4; ++j) { v[j] = base + j < N ? g[(base + j) * stride] : 0.0f; c += v[j] != 0.0f; }
     int inc = c;
     for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
     if (lane == 63) lds[wave] = inc;
@@ -2191,17 +2191,21 @@ extern "C" int64_t gs_compact_rows_scratch_bytes(int64_t N) { return gs::cdiv(N,
 
 // rows [cap] i32 = ascending indices with g[i] != 0, g_rows [>= cap] f32 = those values (the caller zero-fills the tail),
 // count_dev [2] i64 = (min(count, cap), count > cap) -- all on the device, no synchronisation.
-extern "C" int gs_compact_rows(const float* g, int64_t N, int64_t cap, void* scratch, int32_t* rows, float* g_rows, int64_t* count_dev,
-                               gs_stream_t stream_) {
+extern "C" int gs_compact_rows_strided(const float* g, int64_t stride, int64_t N, int64_t cap, void* scratch, int32_t* rows, float* g_rows,
+                                       int64_t* count_dev, gs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    GS_REQUIRE(g && scratch && rows && count_dev && cap >= 0, "gs_compact_rows: null pointer");      // g_rows may be NULL (indices only)
+    GS_REQUIRE(g && scratch && rows && count_dev && cap >= 0 && stride >= 1, "gs_compact_rows: null pointer");      // g_rows may be NULL (indices only)
     const int64_t nb = gs::cdiv(N, CZ_TILE);
     if (nb == 0) { GS_HIP_CHECK(hipMemsetAsync(count_dev, 0, 16, stream)); return 0; }
-    hipLaunchKernelGGL(k_cnz_count, dim3((unsigned)nb), dim3(256), 0, stream, g, N, (int32_t*)scratch);
+    hipLaunchKernelGGL(k_cnz_count, dim3((unsigned)nb), dim3(256), 0, stream, g, stride, N, (int32_t*)scratch);
     hipLaunchKernelGGL(k_cnz_scan, dim3(1), dim3(256), 0, stream, (int32_t*)scratch, nb, cap, count_dev);
-    hipLaunchKernelGGL(k_cnz_write, dim3((unsigned)nb), dim3(256), 0, stream, g, N, (const int32_t*)scratch, cap, rows, g_rows);
+    hipLaunchKernelGGL(k_cnz_write, dim3((unsigned)nb), dim3(256), 0, stream, g, stride, N, (const int32_t*)scratch, cap, rows, g_rows);
     GS_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int gs_compact_rows(const float* g, int64_t N, int64_t cap, void* scratch, int32_t* rows, float* g_rows, int64_t* count_dev,
+                               gs_stream_t stream) {
+    return gs_compact_rows_strided(g, 1, N, cap, scratch, rows, g_rows, count_dev, stream);
 }
 
 extern "C" int gs_sdf_mlp_h2_save_fwd(int mode, const float* x, const int32_t* rows, int64_t n, const int64_t* n_dev, const void* packed, int n_freq,

@@ -80,6 +80,44 @@ def set_random_perm(n_samples_x, table):
     _random_perm[(n_samples_x, str(table.device))] = table.int().contiguous()
 
 
+class CoveredPixels:
+    """The covered-pixel list of a rasterised frame, requested AHEAD of its use: `rast` [B,H,W,4] -> ascending linear indices of the pixels with a
+    triangle (channel 3 > 0), compacted on the device (gs_compact_rows_strided, no channel copy); the COUNT travels to a pinned host word by an
+    asynchronous copy and is read where the shader needs it (`resolve`).  The reference pays a synchronisation for the same quantity at the same
+    place (its mask-dependent launches); here the request is issued right after rasterisation, so that by the time the shader asks, the count has
+    long arrived and the host never drains the queue (the GPU used to idle ~100 us behind that read-back: profiles/r04_gpu_gaps.txt)."""
+    _pinned = {}
+
+    def __init__(self, rast):
+        L = _lib.lib()
+        B, H, W, C = rast.shape
+        assert C == 4 and rast.is_contiguous() and rast.dtype == torch.float32
+        dev = rast.device
+        n = B * H * W
+        self.key = (rast.data_ptr(), rast._version, (B, H, W))
+        self.rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        self.count_dev = torch.empty(2, dtype=torch.int64, device=dev)
+        scratch = torch.empty(int(L.gs_compact_rows_scratch_bytes(c_int64(n))) // 4 + 4, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.gs_compact_rows_strided(c_void_p(rast.data_ptr() + 12), c_int64(4), c_int64(n), c_int64(n), ptr(scratch), ptr(self.rows), c_void_p(0),
+                                            ptr(self.count_dev), stream()), "gs_compact_rows_strided")
+            host = CoveredPixels._pinned.get(str(dev))
+            if host is None:
+                host = CoveredPixels._pinned[str(dev)] = torch.zeros(2, dtype=torch.int64).pin_memory()
+            self.count_host = host
+            host.copy_(self.count_dev, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+
+    def matches(self, mask, dims):
+        return (mask.data_ptr() == self.key[0] + 12 and tuple(dims) == self.key[2] and mask.dim() == 3 and mask.stride() == (dims[1] * dims[2] * 4, dims[2] * 4, 4))
+
+    def resolve(self):
+        self.event.synchronize()
+        return self.rows[: int(self.count_host[0])]
+
+
+PENDING_PIXELS = None           # the CoveredPixels request of the frame being rendered (render.render_mesh issues it right after rasterisation)
 last_covered_pixels = None      # covered pixels of the last optix_env_shade call (bench.py: rays per second)
 SAVED_SAMPLES = True      # backward from the forward pass's saved ray buffer (gs_env_shade_bwd_saved) instead of replaying the sampler.
                           # The buffer (40 B per ray: ~0.8 GB at 4 x 512^2, n = 8, 15 % coverage) stays alive from forward to backward;
@@ -111,8 +149,14 @@ class _optix_env_shade_func(torch.autograd.Function):
 
         def c3(t):
             return t.detach().expand(full).contiguous().float()
-        # covered pixels, ascending (one host sync for the count, like the reference's mask-dependent launches)
-        pix = torch.nonzero(mask.detach().expand(B, H, W).reshape(-1) > 0).reshape(-1).int()
+        # covered pixels, ascending.  The count is needed on the host (scratch sizes, grids) like in the reference's mask-dependent launches; when the
+        # frame's list was requested ahead (CoveredPixels, issued by render_mesh right after rasterisation) it has arrived by now: no queue drain
+        global PENDING_PIXELS
+        pend, PENDING_PIXELS = PENDING_PIXELS, None
+        if pend is not None and pend.matches(mask, (B, H, W)):
+            pix = pend.resolve()
+        else:
+            pix = torch.nonzero(mask.detach().expand(B, H, W).reshape(-1) > 0).reshape(-1).int()
         global last_covered_pixels
         last_covered_pixels = int(pix.shape[0])
         t = dict(ro=None if ro is None else c3(ro), pos=c3(gb_pos), nrm=c3(gb_normal))      # ro None: gb_pos + gb_normal * 0.001 inside the kernel

@@ -424,6 +424,9 @@ def render_mesh(FLAGS, ctx, mesh, mtx_in, view_pos, lgt, resolution, spp=1, num_
 
     v_pos_clip = ru.xfm_points(mesh.v_pos[None, ...], mtx_in)
     rast, db, vis = dr.rasterize(ctx, v_pos_clip, tri, full_res, return_visible=True)
+    if spp == 1 and optix_ctx is not None and rast.is_cuda and getattr(FLAGS, "async_pixel_list", True):
+        # the shader's covered-pixel list: requested now, its count read ~0.5 ms of queued work later (optixutils.CoveredPixels)
+        ou.PENDING_PIXELS = ou.CoveredPixels(rast)
 
     buffers = render_layer(FLAGS, v_pos_clip, rast, db, mesh, view_pos, lgt, resolution, spp, msaa, optix_ctx, bsdf, denoiser, shadow_scale,
                            use_uv=use_uv, finetune_normal=finetune_normal, extra_dict=extra_dict, xfm_lgt=xfm_lgt, shade_data=shade_data, _defer=True)

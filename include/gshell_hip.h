@@ -719,6 +719,10 @@ int64_t gs_sdf_mlp_h2_rows_padded(int mode, int64_t n);
 int64_t gs_compact_rows_scratch_bytes(int64_t N);
 int gs_compact_rows(const float* g, int64_t N, int64_t cap, void* scratch, int32_t* rows, float* g_rows /* may be NULL */,
                     int64_t* count_dev /* [2]: min(count, cap), overflow flag */, gs_stream_t stream);
+/* The same over every `stride`-th float of g (element i = g[i * stride]): e.g. the triangle-id channel of a rasteriser output [B,H,W,4], stride 4 --
+ * the covered-pixel list of a frame without a channel copy and without a host synchronisation (the caller reads count_dev when it needs the count). */
+int gs_compact_rows_strided(const float* g, int64_t stride, int64_t N, int64_t cap, void* scratch, int32_t* rows,
+                            float* g_rows, int64_t* count_dev, gs_stream_t stream);
 int gs_sdf_mlp_h2_save_fwd(int mode, const float* x, const int32_t* rows, int64_t n, const int64_t* n_dev,
                            const void* packed, int n_freq, int n_hidden, int skip_layer, float* A_save,
                            float* EMB_save, float* out, gs_stream_t stream);

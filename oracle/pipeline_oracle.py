@@ -49,15 +49,18 @@ class ConstantTextureOracle:
 
 
 def render_mesh(v_pos, faces, v_nrm, msdf, mvp, campos, light, background, noise, texture, n_samples, seed, shadow_scale, perms, bsdf='pbr',
-                denoise_sigma=None, resolution=(32, 32)):
+                denoise_sigma=None, resolution=(32, 32), xfm=None):
     """All tensors torch CPU float32.  faces [T,3] long.  noise = {'jitter','texture','tangent'} as drawn by the product.
-    Returns the dict of composited + antialiased buffers (same keys as the reference)."""
+    Returns the dict of composited + antialiased buffers (same keys as the reference).
+    xfm: the point transform -- default raster_oracle.xfm_points (the reference's python branch, a matmul); the config-size chains pass
+    raster_oracle.xfm_points_kernel_order (the CUDA kernel's sum order without contraction = the HIP path's clip coordinates bit for bit)."""
+    xfm = xfm or ro.xfm_points
     H, W = resolution
     B = mvp.shape[0]
     tri_np = faces.numpy().astype(np.int32)
-    v_pos_clip = ro.xfm_points_kernel_order(v_pos[None], mvp)
+    v_pos_clip = xfm(v_pos[None], mvp)
     # discrete decisions (coverage, sample placement) are always made from float32 values, whatever dtype the floats run in
-    ids = torch.tensor(ro.rasterize_ids_c(ro.xfm_points_kernel_order(v_pos.detach().float()[None], mvp.float()).numpy(), tri_np, H, W))     # oracle/raster_c.c
+    ids = torch.tensor(ro.rasterize_ids_c(xfm(v_pos.detach().float()[None], mvp.float()).numpy(), tri_np, H, W))     # oracle/raster_c.c
     rast, rast_db = ro.rast_from_ids(v_pos_clip, faces, ids)
     visible = torch.unique(ids[ids >= 0])
     gb_pos = ro.interpolate(v_pos[None], rast, faces)

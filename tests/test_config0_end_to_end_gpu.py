@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import mtets_oracle, pipeline_oracle as pl, pixel_oracle as po, tick_oracle
+from oracle import mtets_oracle, pipeline_oracle as pl, pixel_oracle as po, raster_oracle as ro_mod, tick_oracle
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -221,7 +221,8 @@ def _tick_chain_body(kind, res, iteration, seed, flag_overrides, textured, B, n,
     v.retain_grad()
     msdf_aug.retain_grad()
     out = pl.render_mesh(v, f, po.auto_normals(v, f), msdf_aug, target['mvp'].cpu(), target['campos'].cpu(), light, target['background'].cpu(), noise,
-                         tex_oracle, n, seed, shadow, perms.numpy(), bsdf='pbr', denoise_sigma=sigma, resolution=(H, W))
+                         tex_oracle, n, seed, shadow, perms.numpy(), bsdf='pbr', denoise_sigma=sigma, resolution=(H, W),
+                         xfm=ro_mod.xfm_points_kernel_order)
     d_o = {'buffers': out, 'imesh_faces': f, 'msdf': msdf_aug, 'msdf_boundary': ex['msdf_boundary'], 'n_verts_watertight': ex['n_verts_watertight'],
            'sdf': sdf, 'sampled_pts': d['sampled_pts'].detach().cpu()}
     tgt_o = {'img': target['img'].cpu()}
