@@ -166,10 +166,20 @@ def main():
                                 "what": "same iteration with SDF_TWO_PASS = False: every grid row through the three-product fp16-pair kernel (k_h2_fwd<GRID>)"}
         # (2) coverage sensitivity: S2 / R5 / S3 scale with the covered pixels; the headline camera leaves 86 % of the frame empty
         near = [workload.make_targets(trainer, [(it * B_global + v) % 72 for v in shard.local_views(B_global)], (H, W), radius=1.4) for it in range(2)]
-        dt2, _ = timed(a.schedule_it, 8, a.extra_steps, tgts=near)          # new tensor sizes: the caching allocator and the bin scratch settle in the warm-up (4 steps were not enough on every box)
+        # new tensor sizes (3 x the covered pixels: GBs of ray records, bin scratch): the headline run's cached blocks are returned first, the new
+        # sizes settle in 8 warm-up steps, and the figure is the better of two timed batches -- a first-size hipMalloc inside one batch of 5 steps
+        # made this line read 37 - 40 ms on some boxes and 25.6 on others
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        dt2, _ = timed(a.schedule_it, 8, a.extra_steps, tgts=near)
+        dt2b, _ = timed(a.schedule_it + 8 + a.extra_steps, 0, a.extra_steps, tgts=near)
+        dt2_all = [round(dt2 / a.extra_steps * 1e3, 3), round(dt2b / a.extra_steps * 1e3, 3)]
+        dt2 = min(dt2, dt2b)
         cov2 = _ou.last_covered_pixels
         side["coverage_sensitivity"] = {"camera_radius": 1.4, "ms_per_step": round(dt2 / a.extra_steps * 1e3, 3), "value": round(B_global * H * W * a.extra_steps / dt2 / 1e6, 4),
-                                        "covered_pixels_per_rank": cov2, "coverage": None if cov2 is None else round(cov2 / (B_local * H * W), 4), "steps": a.extra_steps}
+                                        "covered_pixels_per_rank": cov2, "coverage": None if cov2 is None else round(cov2 / (B_local * H * W), 4), "steps": a.extra_steps,
+                                        "batches_ms_per_step": dt2_all}
+        torch.cuda.empty_cache()
         # (3) BASELINE.json configs[3] (8 GPUs x 1 view = global batch 8) beside the weak-scaling line of a plain `--gpus 8`
         if world == 8 and a.global_batch is None:
             one = [workload.make_targets(trainer, [(it * 8 + v) % 72 for v in shard.local_views(8)], (H, W), radius=a.camera_radius) for it in range(2)]

@@ -853,29 +853,36 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? GS_H1_WAVES : GS_H1_WAVES4)
     }
 }
 
-// ---- one-product forward, REGISTER-RESIDENT activations (round 5) -----------------------------------------------------------------------
-// k_h1_fwd above is operand-delivery bound: per MFMA it reads 1 KB of activations from LDS and 0.5 KB of weights through L1, both pipes at
-// their limit with the matrix pipe ~40 % busy (profiles/r03_h1_dissection.txt), and every 64-row tile re-reads the 0.65 MB weight image from
-// L2.  This kernel changes the ratio instead of the schedule:
-//   * ONE wave carries a 64-row tile through all layers and keeps its activations IN REGISTERS.  The transposed product D[feature][row] leaves
-//     lane (row n, half h) with features 32 mb + 4 h + 8 g + j (g, j < 4) of ITS row -- which is already a valid B operand of the next layer if
-//     k-slot (step s', half h, element i) of that layer is DEFINED as feature F(s', h, i) = 32 (s' / 2) + 4 h + 8 (2 (s' % 2) + i / 4) + i % 4:
-//     the K order of a GEMM is free, so the weights are packed in that order (k_h2_pack, third section) and no lane ever exchanges a value.
-//     bias -> accumulator init, softplus on the 16 + 16 accumulator values of a feature block, v_cvt_pk_f16_f32 into the next layer's fragments.
-//   * weights are the A operand, staged through LDS once per WORKGROUP (4 waves = 4 tiles = 256 rows) in chunks of one 32-feature block
-//     (16 KB, double buffered, one barrier per chunk) and each 1 KB fragment feeds both 32-row blocks of the wave: 0.5 KB of LDS per MFMA, no
-//     activation traffic at all, a quarter of the L2 weight traffic.
-//   * one wave per SIMD (~400 VGPRs): the matrix pipe is kept busy by the wave's own independent work -- the softplus of feature block mb - 1
-//     is issued between the MFMAs of block mb (sched_group_barrier pins the interleave).
-// Same arithmetic class as k_h1_fwd (fp16 operands, fp32 accumulation; the K order differs, so values differ in the last bits of fp32 sums);
-// the positional encoding uses v_sin_f32 / v_cos_f32 (absolute error ~1e-6, the fp16 rounding that follows is 5e-4).
+// ---- one-product forward, REGISTER-RESIDENT activations (round 5; selectable with gs_sdf_mlp_h1_impl(1), NOT the default) ---------------------------
+// k_h1_fwd above is operand-delivery bound: per MFMA it reads 1 KB of activations from LDS and 0.5 KB of weights through L1, and every 64-row tile
+// re-reads the 0.65 MB weight image from L2.  This kernel changes the ratio instead of the schedule:
+//   * a wave carries a 32-row block through ALL layers and keeps its activations IN REGISTERS.  The transposed product D[feature][row] leaves lane
+//     (row n, half h) with features 32 mb + 4 h + 8 g + j (g, j < 4) of ITS row -- which is already a valid B operand of the next layer if k-slot
+//     (step s', half h, element i) of that layer is DEFINED as feature F(s', h, i) = 32 (s' / 2) + 4 h + 8 (2 (s' % 2) + i / 4) + i % 4: the K order
+//     of a GEMM is free, so the weights are packed in that order (k_h2_pack, third section) and no lane ever exchanges a value.  bias -> accumulator
+//     init, softplus in scaled variables on the 16 accumulator values of a feature block, v_cvt_pk_f16_f32 into the next layer's fragments.
+//   * weights are the A operand, staged through LDS once per WORKGROUP (8 waves = 256 rows) by LDS-DMA in chunks of one 32-feature block (triple
+//     buffered, one barrier per chunk): no activation traffic at all, a quarter of the L2 weight traffic.
+// What was measured on MI355X (tools/h1r_check.py, tools/micro/mfma_*.hip; wall clock -- clock64() ticks do NOT advance with wall time when several
+// waves share a SIMD):
+//   * first form, ONE wave per SIMD with 64 rows (~450 registers): 5.6 ms.  A wave's VALU instructions are not hidden behind its own MFMAs (6 v_fma
+//     between two MFMAs: 16.6 -> 25.5 ns per MFMA; a second wave on the SIMD hides about a third of them, four waves half), and hipcc needed 1 500
+//     spilled registers for the 400 live ones;
+//   * this form, TWO waves per SIMD with 32 rows each (256 registers, ~70 spilled): 2.38 ms against k_h1_fwd's 2.34 -- on par, not better.  Timing-only
+//     ablations: without the weight DMA 2.07 (three 8 KB LDS-DMA pieces per block and wave cost their issue slots), without the activation function
+//     2.10, without both 1.70; MFMAs alone would take 0.65.  With ~7 VALU instructions per MFMA of this network, MFMA + 0.5 x VALU puts the floor of
+//     ANY schedule at ~1.1 ms; neither kernel is near it, and the remaining distance is issue contention, barriers and operand delivery, not a
+//     missing trick.  Kept selectable as the measured record of the design; same arithmetic class as k_h1_fwd (different K order: values differ in
+//     the last bits of fp32 sums; positional encoding by v_sin_f32 / v_cos_f32).
+constexpr int R1_NW = 8;                                       // waves per workgroup = two per SIMD; each carries ONE 32-row block through all layers
+constexpr int R1_NT = 64 * R1_NW;
 constexpr int R1_STEPS_MAX = D / 16 + EK / 16;                 // k-steps of a chunk at the skip layer
-constexpr int R1_STAGE = (R1_STEPS_MAX * 64 + 255) / 256;      // h8 per thread and chunk (5)
-constexpr int R1_CHUNK = R1_STAGE * 256;                       // h8 per LDS buffer (20 KB): EVERY chunk is staged as 1280 fragments -- a shorter
-                                                               // chunk drags the head of the next one (or of the fp32 tail) along, unread: no predicates
+constexpr int R1_STAGE = (R1_STEPS_MAX * 64 + R1_NT - 1) / R1_NT;      // 16-byte pieces per thread and chunk (3)
+constexpr int R1_CHUNK = R1_STAGE * R1_NT;                     // h8 per LDS buffer (24 KB): EVERY chunk is staged as 1536 fragments -- a shorter chunk
+                                                               // drags the head of the next one (or of the fp32 tail) along, unread: no predicates
 constexpr int R1_BUFS = 3;                                     // ring: chunk c is read while c + 1 is already visible (its first fragments are
-                                                               // requested BEFORE the barrier that ends c) and c + 2 is being written
-constexpr int R1_ENC = 4 * 2 * (EK / 16) * 64;                 // h8: the four waves' encoding fragments [wave][row block 2][k-step 3][lane 64] (24 KB)
+                                                               // requested BEFORE the barrier that ends c) and c + 2 is landing
+constexpr int R1_ENC = R1_NW * (EK / 16) * 64;                 // h8: the waves' encoding fragments [wave][k-step 3][lane 64] (24 KB)
 constexpr size_t SMEM_H1R_BYTES = (size_t)(R1_BUFS * R1_CHUNK + R1_ENC) * sizeof(h8) + (size_t)(MAX_LAYERS + 1) * D * sizeof(float);
 
 // global -> LDS without staging registers: global_load_lds_dwordx4, lane i of the wave writes its 16 bytes at M0 + 16 i.  As ONE asm statement: a
@@ -883,7 +890,7 @@ constexpr size_t SMEM_H1R_BYTES = (size_t)(R1_BUFS * R1_CHUNK + R1_ENC) * sizeof
 // L2 round trip, every block.  An asm DMA is invisible to that bookkeeping; the kernel waits for it itself (r1_dma_wait) before the barrier that
 // publishes the chunk, one block of MFMAs later.  M0 is saved and restored inside the statement (it is compiler-reserved).
 __device__ __forceinline__ void r1_dma_chunk(const h8* __restrict__ src, h8* dst_buf, int tid) {
-    static_assert(R1_STAGE == 5, "five 4 KB pieces per chunk are written out below");
+    static_assert(R1_STAGE == 3 && R1_NT * 16 == 0x2000, "three 8 KB pieces per chunk are written out below");
     const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) h8*)(dst_buf + (tid & ~63)));
     uint32_t off = (uint32_t)tid * 16u, keep;
     asm volatile(
@@ -891,20 +898,12 @@ __device__ __forceinline__ void r1_dma_chunk(const h8* __restrict__ src, h8* dst
         "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
         "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_add_u32 m0, m0, 0x1000\n\t"
-        "v_add_u32 %1, 0x1000, %1\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\t"
+        "v_add_u32 %1, 0x2000, %1\n\t"
         "s_nop 0\n\t"
         "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_add_u32 m0, m0, 0x1000\n\t"
-        "v_add_u32 %1, 0x1000, %1\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_add_u32 m0, m0, 0x1000\n\t"
-        "v_add_u32 %1, 0x1000, %1\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_add_u32 m0, m0, 0x1000\n\t"
-        "v_add_u32 %1, 0x1000, %1\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\t"
+        "v_add_u32 %1, 0x2000, %1\n\t"
         "s_nop 0\n\t"
         "global_load_lds_dwordx4 %1, %2\n\t"
         "s_mov_b32 m0, %0"
@@ -917,7 +916,7 @@ __device__ __forceinline__ void r1_dma_wait() { asm volatile("s_waitcnt vmcnt(0)
 __device__ __forceinline__ int r1_steps(int l, int skip_layer) { return l == 0 ? EK / 16 : D / 16 + (l == skip_layer ? EK / 16 : 0); }
 
 #ifndef GS_H1R_ABL
-#define GS_H1R_ABL 0         // timing-only ablations, compiled only under GS_EXPERIMENT: 1 = no activation function, 2 = no MFMAs, 4 = no weight DMA, 8 = no fences
+#define GS_H1R_ABL 0         // timing-only ablations, compiled only under GS_EXPERIMENT: 1 = no activation function, 2 = no MFMAs, 4 = no weight DMA
 #endif
 #if defined(GS_EXPERIMENT) && (GS_H1R_ABL & 2)
 #define R1_MFMA(a, b, c) (c)
@@ -925,18 +924,22 @@ __device__ __forceinline__ int r1_steps(int l, int skip_layer) { return l == 0 ?
 #define R1_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #endif
 #ifndef GS_H1R_PD
-#define GS_H1R_PD 3          // weight fragments (LDS -> registers) in flight ahead of the MFMAs that use them
+#define GS_H1R_PD 1          // weight fragments (LDS -> registers) in flight ahead of the MFMAs that use them (measured 1 / 2 / 3: 2.38 / 2.44 / 2.52 ms:
+                             // the second wave of the SIMD covers the LDS latency, the ring's registers cost spills)
 #endif
-#if defined(GS_EXPERIMENT) && (GS_H1R_ABL & 8)
-#define R1_FENCE()
-#else
+#ifndef GS_H1R_FENCE
+#define GS_H1R_FENCE 1       // 1: scheduling fences pin [fragment read, MFMA, half a pair's activation function] per k-step
+#endif
+#if GS_H1R_FENCE
 #define R1_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define R1_FENCE()
 #endif
 
 // The activation function in the kernel's SCALED variables.  With c = 100 log2(e), softplus_100(z) = max(z, 0) + log2(1 + 2^-|c z|) / c, so in
 // z' = c z and a' = c a it reads  a' = max(z', 0) + log2(1 + 2^-|z'|): no multiplications.  The scaling is free: z' = W a' + c b for the ORIGINAL
 // W of every layer fed by activations (k_h2_pack scales the biases, the weights that multiply the encoding, and the output weights by 1 / c).
-// Two halves, so that each can be placed behind one of a k-step's two MFMAs: one wave per SIMD hides ~5 single-issue instructions per MFMA.
+// Two halves, one behind each of two consecutive MFMAs.
 struct R1Half { float z0, z1, l0, l1; };
 __device__ __forceinline__ R1Half r1_act_a(float z0, float z1) {
     R1Half q;
@@ -963,20 +966,23 @@ struct R1State {
     int cur, nxt, nx2;        // LDS buffer (h8 offset) of chunk c, c + 1, c + 2
 };
 
-// One layer of the register-resident forward.  FIRST: K = the encoding (3 k-steps); SKIP: 16 + 3 k-steps; LAST: the activation is multiplied by the
-// output weights and summed instead of becoming the next layer's fragments.  Everything is unrolled and BRANCH-FREE -- one basic block per layer: a
-// branch anywhere lets the compiler sink every block's activation function into the layer's last block, where its results are first used -- and the
-// order inside a k-step is pinned with scheduling fences: [fragment read, MFMA] [first half of a pair's activation] [MFMA] [second half].
+// One layer of the register-resident forward for the wave's 32 rows.  FIRST: K = the encoding (3 k-steps); SKIP: 16 + 3 k-steps; LAST: the activation is
+// multiplied by the output weights and summed instead of becoming the next layer's fragments.  Everything is unrolled and BRANCH-FREE -- one basic
+// block per layer: a branch anywhere lets the compiler sink every block's activation function into the layer's last block, where its results are
+// first used.  The accumulator of feature block mb - 1 goes through the activation function while block mb's MFMAs run: one pair of values per two
+// k-steps.  A wave's own VALU work is NOT hidden behind its own MFMAs on this hardware (tools/micro/mfma_fillers.hip: 6 v_fma between two MFMAs cost
+// 20 of their own cycles) -- the second wave of the SIMD is what fills the matrix pipe meanwhile.
 template <bool FIRST, bool SKIP, bool LAST>
 __device__ __forceinline__ void r1_layer(const H2Args& A, int l, R1State& S, h8* smem_w, const float* tailL, int tid, int lane, int h, const h8* Benc,
-                                         const h8 (&Bin)[D / 16][2], h8 (&Bout)[D / 16][2], f2 (&part)[2]) {
+                                         const h8 (&Bin)[D / 16], h8 (&Bout)[D / 16], f2& part) {
     constexpr int NS = FIRST ? EK / 16 : D / 16 + (SKIP ? EK / 16 : 0);
     constexpr int PD = GS_H1R_PD < NS ? GS_H1R_PD : NS - 1;
     const float* bl = tailL + l * D + 4 * h;                    // this lane's bias entries: + 32 mb + 8 g
     const float* wo = tailL + A.n_layers * D + 4 * h;           // (LAST) output weights / c
-    v16f accs[2][2];                  // block mb accumulates in accs[mb & 1] while the activation function reads accs[(mb - 1) & 1]
+    v16f accs[2];                     // block mb accumulates in accs[mb & 1] while the activation function reads accs[(mb - 1) & 1]
     float4 wqs[2][4];                 // (LAST) the blocks' output weights, same parity
     uint32_t pend[4];                 // packed activations of the fragment being assembled
+    R1Half half;                      // a pair between its two halves
     h8 fr[PD + 1];                    // fragment ring; the first PD fragments of a chunk are requested at the end of the previous one
     {
         const h8* w0 = smem_w + S.cur + lane;
@@ -986,8 +992,8 @@ __device__ __forceinline__ void r1_layer(const H2Args& A, int l, R1State& S, h8*
     R1_FENCE();
 #pragma unroll
     for (int mb = 0; mb <= 8; ++mb) {
-        v16f (&acc)[2] = accs[mb & 1];
-        v16f (&accP)[2] = accs[(mb + 1) & 1];
+        v16f& acc = accs[mb & 1];
+        v16f& accP = accs[(mb + 1) & 1];
         float4 (&wq)[4] = wqs[mb & 1];
         float4 (&wP)[4] = wqs[(mb + 1) & 1];
         if (mb < 8) {
@@ -1003,20 +1009,19 @@ __device__ __forceinline__ void r1_layer(const H2Args& A, int l, R1State& S, h8*
             for (int g = 0; g < 4; ++g) {
                 const float4 b4 = *reinterpret_cast<const float4*>(bl + mb * 32 + 8 * g);          // LDS (broadcast reads)
                 if (LAST) wq[g] = *reinterpret_cast<const float4*>(wo + mb * 32 + 8 * g);
-#pragma unroll
-                for (int r = 0; r < 2; ++r) { acc[r][4 * g] = b4.x; acc[r][4 * g + 1] = b4.y; acc[r][4 * g + 2] = b4.z; acc[r][4 * g + 3] = b4.w; }
+                acc[4 * g] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
             }
             R1_FENCE();
         }
-        // pair pp (0..15) of the previous block: r = pp / 8, accumulator elements 2 (pp % 8), + 1
-        auto pair_a = [&](int pp) { const int r = pp >> 3, v = 2 * (pp & 7); return r1_act_a(accP[r][v], accP[r][v + 1]); };
-        auto pair_b = [&](int pp, const R1Half& q) {
-            const int r = pp >> 3, v = 2 * (pp & 7), pb = mb > 0 ? mb - 1 : 0;
-            const f2 a = r1_act_b(q);
+        // pair pp (0..7) of the previous block: accumulator elements 2 pp, 2 pp + 1
+        auto pair_a = [&](int pp) { half = r1_act_a(accP[2 * pp], accP[2 * pp + 1]); };
+        auto pair_b = [&](int pp) {
+            const int v = 2 * pp, pb = mb > 0 ? mb - 1 : 0;
+            const f2 a = r1_act_b(half);
             if (LAST) {
                 const float4 w4 = wP[v >> 2];
-                part[r].x = __builtin_fmaf(a.x, (v & 2) ? w4.z : w4.x, part[r].x);
-                part[r].y = __builtin_fmaf(a.y, (v & 2) ? w4.w : w4.y, part[r].y);
+                part.x = __builtin_fmaf(a.x, (v & 2) ? w4.z : w4.x, part.x);
+                part.y = __builtin_fmaf(a.y, (v & 2) ? w4.w : w4.y, part.y);
             } else {
                 // four consecutive pairs are one fragment of the next layer: elements 8 s .. 8 s + 7 of feature block pb = k-step 2 pb + s.  The
                 // fragment is assembled from its four packed words and assigned ONCE: element-wise inserts into the fragment array made every
@@ -1025,7 +1030,7 @@ __device__ __forceinline__ void r1_layer(const H2Args& A, int l, R1State& S, h8*
                 pend[pp & 3] = __builtin_bit_cast(uint32_t, q2);
                 if ((pp & 3) == 3) {
                     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-                    Bout[2 * pb + ((pp & 7) >> 2)][r] = __builtin_bit_cast(h8, u4{pend[0], pend[1], pend[2], pend[3]});
+                    Bout[2 * pb + (pp >> 2)] = __builtin_bit_cast(h8, u4{pend[0], pend[1], pend[2], pend[3]});
                 }
             }
         };
@@ -1040,24 +1045,22 @@ __device__ __forceinline__ void r1_layer(const H2Args& A, int l, R1State& S, h8*
                 if (s + PD < NS) fr[(q0 + PD) % (PD + 1)] = wl[(s + PD) * 64];
                 else if (mb < 7) fr[(q0 + PD) % (PD + 1)] = wn[(s + PD - NS) * 64];
                 const h8 a = fr[q0 % (PD + 1)];
-                // (the encoding's fragments come from LDS: two layers read them, 24 registers would hold them for all seven)
-                const h8 b0 = (FIRST || s >= D / 16) ? Benc[(FIRST ? s : s - D / 16) * 64] : Bin[s < D / 16 ? s : 0][0];
-                const h8 b1 = (FIRST || s >= D / 16) ? Benc[((EK / 16) + (FIRST ? s : s - D / 16)) * 64] : Bin[s < D / 16 ? s : 0][1];
-                const bool epi = mb > 0 && NS >= 16 && s < 16;          // the previous block's 16 pairs ride on this block's first 16 k-steps
-                acc[0] = R1_MFMA(a, b0, acc[0]);
+                // (the encoding's fragments come from LDS: two layers read them, 12 registers would hold them for all seven)
+                const h8 b = (FIRST || s >= D / 16) ? Benc[(FIRST ? s : s - D / 16) * 64] : Bin[s < D / 16 ? s : 0];
+                acc = R1_MFMA(a, b, acc);
                 R1_FENCE();
-                R1Half q;
-                if (epi) { q = pair_a(s); R1_FENCE(); }
-                acc[1] = R1_MFMA(a, b1, acc[1]);
-                R1_FENCE();
-                if (epi) { pair_b(s, q); R1_FENCE(); }
+                if (mb > 0 && NS >= 16 && s < 16) {        // the previous block's 8 pairs ride on this block's first 16 k-steps
+                    if (s & 1) pair_b(s >> 1); else pair_a(s >> 1);
+                    R1_FENCE();
+                }
             }
         }
         if (mb > 0 && (mb == 8 || NS < 16)) {          // not interleaved: the first layer's short k-loop, and every layer's last block
 #pragma unroll
-            for (int pp = 0; pp < 16; ++pp) {
-                pair_b(pp, pair_a(pp));
-                if (pp & 1) R1_FENCE();               // two pairs in flight, not sixteen
+            for (int pp = 0; pp < 8; ++pp) {
+                pair_a(pp);
+                pair_b(pp);
+                R1_FENCE();
             }
         }
         if (mb < 8) {
@@ -1070,11 +1073,11 @@ __device__ __forceinline__ void r1_layer(const H2Args& A, int l, R1State& S, h8*
     }
 }
 
-__global__ void __launch_bounds__(256, 1) k_h1r_fwd(H2Args A) {
+__global__ void __launch_bounds__(R1_NT, 2) k_h1r_fwd(H2Args A) {
     extern __shared__ __attribute__((aligned(16))) h8 smem_w[];           // [R1_BUFS][R1_CHUNK] | encoding fragments | scaled biases + output weights
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wave, r0 = tile * 64;
+    const int64_t tile = (int64_t)blockIdx.x * R1_NW + wave, r0 = tile * 32;
 
     // ---- weight chunks c = 8 l + mb: chunks 0, 1 -> LDS now, chunk c + 2 during chunk c
     R1State S{0, A.n_layers * 8, 0, R1_CHUNK, 2 * R1_CHUNK};
@@ -1082,14 +1085,13 @@ __global__ void __launch_bounds__(256, 1) k_h1r_fwd(H2Args A) {
     r1_dma_chunk(chunk_src(0), smem_w, tid);            // n_chunks >= 8
     r1_dma_chunk(chunk_src(1), smem_w + R1_CHUNK, tid);
     float* tailL = reinterpret_cast<float*>(smem_w + R1_BUFS * R1_CHUNK + R1_ENC);
-    for (int i = tid; i < (A.n_layers + 1) * D; i += 256) tailL[i] = A.tailR[i];
+    for (int i = tid; i < (A.n_layers + 1) * D; i += R1_NT) tailL[i] = A.tailR[i];
     r1_dma_wait();
 
-    // ---- positional encoding of the wave's two 32-row blocks, straight into B fragments: k-slot (s', h, i) = encoding entry 16 s' + 8 h + i
-    h8* Benc = smem_w + R1_BUFS * R1_CHUNK + wave * (2 * (EK / 16) * 64) + lane;        // [row block][k-step][lane]
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int64_t row = r0 + 32 * r + n;
+    // ---- positional encoding of the wave's 32 rows, as B fragments: k-slot (s', h, i) = encoding entry 16 s' + 8 h + i
+    h8* Benc = smem_w + R1_BUFS * R1_CHUNK + wave * ((EK / 16) * 64) + lane;        // [k-step][lane]
+    {
+        const int64_t row = r0 + n;
         float p[3] = {0.f, 0.f, 0.f};
         if (row < A.N) { p[0] = A.x[3 * row]; p[1] = A.x[3 * row + 1]; p[2] = A.x[3 * row + 2]; }
         float e[EK];
@@ -1111,13 +1113,13 @@ __global__ void __launch_bounds__(256, 1) k_h1r_fwd(H2Args A) {
             h8 f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) f[i] = (_Float16)(h ? e[16 * s + 8 + i] : e[16 * s + i]);
-            Benc[(r * (EK / 16) + s) * 64] = f;
+            Benc[s * 64] = f;
         }
     }
     __syncthreads();
 
-    h8 Ba[D / 16][2], Bb[D / 16][2];          // the layers' input / output fragments, roles alternating (no copy between layers)
-    f2 part[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
+    h8 Ba[D / 16], Bb[D / 16];          // the layers' input / output fragments, roles alternating (no copy between layers)
+    f2 part = f2{0.f, 0.f};
     for (int l = 0; l < A.n_layers; ++l) {
         const bool last = l + 1 == A.n_layers, skip = l == A.skip_layer;
 #define R1_CALL(F, K, L_)                                                                                      \
@@ -1137,16 +1139,16 @@ __global__ void __launch_bounds__(256, 1) k_h1r_fwd(H2Args A) {
         }
 #undef R1_CALL
     }
-    // ---- output layer: the two lane halves of a row hold disjoint feature sets
-    float s0 = part[0].x + part[0].y, s1 = part[1].x + part[1].y;
-    s0 += __shfl_xor(s0, 32, 64);
-    s1 += __shfl_xor(s1, 32, 64);
-    const float sv = (h ? s1 : s0) + A.w_out[D];          // lane l <-> row r0 + l
-    const int64_t row = r0 + lane;
-    const bool valid = row < A.N;
+    // ---- output layer: the two lane halves of a row hold disjoint feature sets; lane l < 32 <-> row r0 + l
+    float sv = part.x + part.y;
+    sv += __shfl_xor(sv, 32, 64);
+    sv += A.w_out[D];
+    const int64_t row = r0 + n;
+    const bool valid = row < A.N && h == 0;
     if (valid) A.out[row] = sv;
     const uint64_t m = __ballot(valid && sv > 0.0f);
-    if (A.occ && lane == 0 && valid) A.occ[tile] = m;
+    // the occupancy words are 64 rows wide: this wave owns the low (even tile) or high (odd tile) 32 bits
+    if (A.occ && lane == 0 && r0 < A.N) reinterpret_cast<uint32_t*>(A.occ)[tile] = (uint32_t)m;
     if (A.status && __ballot(valid && !(fabsf(sv) < 3.0e38f)) != 0ull && lane == 0) atomicOr(&A.status[ST_NONFINITE], 1u);
 }
 
@@ -2154,7 +2156,7 @@ extern "C" int gs_sdf_mlp_fwd_h1(const float* x, int64_t N, const void* packed, 
     fill_fwd_args(A, packed, make_layout(n_freq, n_hidden, skip_layer));
     if (g_h1_impl == 1) {          // register-resident activations (round 5)
         GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h1r_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_H1R_BYTES));
-        hipLaunchKernelGGL(k_h1r_fwd, dim3((unsigned)gs::cdiv(N, 256)), dim3(256), SMEM_H1R_BYTES, (hipStream_t)stream, A);
+        hipLaunchKernelGGL(k_h1r_fwd, dim3((unsigned)gs::cdiv(N, 32 * R1_NW)), dim3(R1_NT), SMEM_H1R_BYTES, (hipStream_t)stream, A);
         GS_LAUNCH_CHECK();
         return 0;
     }
