@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--set", action="append", default=[], metavar="FLAG=VALUE", help="override a training flag (python literal), e.g. --set eikonal_side_stream=False")
     ap.add_argument("--state-file", default=None, help="save the fitted set-up state here / load it if the file exists (profiling runs skip the set-up kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant-ok", action="store_true", help="measure a library built with non-default compile-time variants (GSHELL_HIP_LIB=...; the line then carries "
+                    "`build_flags` and is not a headline)")
     ap.add_argument("--op-times", action="store_true", help="also print per-op HIP-event times (adds sync points)")
     return ap.parse_args()
 
@@ -98,7 +100,10 @@ def main():
         world = dist.get_world_size()             # what RCCL actually sees
     from gshell_amd import _lib, workload
     from gshell_amd.train import ViewShard
-    _lib.lib()                                     # fail loudly if the HIP library is missing
+    build_flags = _lib.lib().gs_build_flags().decode()          # fails loudly if the HIP library is missing
+    if build_flags and not a.variant_ok:
+        # several compile-time switches are timing-only ablations with wrong results: no number without an explicit opt-in
+        raise SystemExit(f"bench.py: the loaded library was built with non-default variants ({build_flags}); pass --variant-ok to measure it anyway")
     shard = ViewShard(rank, world)
     if a.global_batch is not None:
         if a.global_batch % world:
@@ -208,6 +213,7 @@ def main():
                        f"with the pair arithmetic; sign margin used by the first pass {margin_used}" if two_pass_ran else "; one pass over every row") + ")")
                      if ("gs_sdf_mlp_fwd_h1" in op_times or "gs_sdf_mlp_fwd_h2" in op_times) else "f32",
             "data": "synthetic",
+            **({"build_flags": build_flags} if build_flags else {}),
             "config": {"workload": f"{'G-FlexiCubes res' if a.geometry == 'flexicubes' else 'tet-res'}{a.res} ({'voxel grid' if a.geometry == 'flexicubes' else 'BCC'} {N} verts / {Ftets} cells), {B_local} views/GPU x {H}x{W}, n_samples={a.n_samples} "
                                    f"({2 * a.n_samples ** 2} shadow rays/px/pass), full train iteration fwd+bwd+3xAdam",
                        "global_batch": B_global, "views_per_gpu": B_local, "schedule_it": a.schedule_it,

@@ -365,3 +365,7 @@ extern "C" int gs_bvh_any_hit(const gs_bvh* b, const float* origins, const float
     GS_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- compile-time variants of this file (common.hpp): non-default values announce themselves through gs_build_flags(); switches that give
+// wrong results (timing-only ablations) compile only under -DGS_EXPERIMENT
+GS_TUNABLE(GS_BVH_HILBERT, 1)

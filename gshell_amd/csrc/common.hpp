@@ -31,4 +31,34 @@ void set_error(const std::string& msg);
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- compile-time variants --------------------------------------------------------------------------------------------------------------------------
+// Every tunable of a kernel file is declared as
+//     #ifndef GS_FOO
+//     #define GS_FOO 3
+//     #endif
+//     GS_TUNABLE(GS_FOO, 3)
+// and registers itself at load time when the library was built with another value (tools/build_variant.sh -DGS_FOO=5): gs_build_flags() then
+// lists "GS_FOO=5", and bench.py refuses to print a number for such a library unless told that a variant is being measured.  Switches that give
+// WRONG results (timing-only ablations) compile only under -DGS_EXPERIMENT, which is itself reported.  The shipped target (csrc/Makefile) accepts
+// no extra defines at all.
+void report_flag(const char* name, long long value, long long dflt);
+struct FlagReporter {
+    FlagReporter(const char* name, long long value, long long dflt) { if (value != dflt) report_flag(name, value, dflt); }
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GS_TUNABLE(name, dflt)
+#define GS_TUNABLE_F(name, dflt)
+#else
+#define GS_TUNABLE(name, dflt) static const ::gs::FlagReporter gs_flag_reporter_##name(#name, (long long)(name), (long long)(dflt));
+#define GS_TUNABLE_F(name, dflt) static const ::gs::FlagReporter gs_flag_reporter_##name(#name " x 1e6", (long long)((name) * 1e6), (long long)((dflt) * 1e6));
+#endif
+#ifdef GS_EXPERIMENT
+#define GS_EXPERIMENT_ONLY(name)
+#if !defined(__HIP_DEVICE_COMPILE__)
+static const ::gs::FlagReporter gs_flag_reporter_experiment("GS_EXPERIMENT(" __FILE__ ")", 1, 0);      // one entry per file built that way
+#endif
+#else
+#define GS_EXPERIMENT_ONLY(name) static_assert(false, #name " gives wrong results (timing-only ablation): it compiles only with -DGS_EXPERIMENT");
+#endif
+
 }  // namespace gs

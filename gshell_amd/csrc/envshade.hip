@@ -1383,3 +1383,18 @@ extern "C" int gs_bilateral_bwd_masked(const float* nrm, const float* zdz, const
     GS_REQUIRE(nrm && zdz && g_out && g_col && sigma > 0.f, "gs_bilateral_bwd_masked: null pointer / sigma <= 0");
     return launch_bilateral<true>(nullptr, nrm, zdz, mask, B, H, W, sigma, nullptr, g_out, g_col, (hipStream_t)stream);
 }
+
+// ---- compile-time variants of this file (common.hpp): non-default values announce themselves through gs_build_flags(); switches that give
+// wrong results (timing-only ablations) compile only under -DGS_EXPERIMENT
+GS_TUNABLE(GS_SAMPLES_WAVES, 4)
+GS_TUNABLE(GS_GRAD_WAVES, 3)
+GS_TUNABLE(GS_LG_SLICES, 16)
+GS_TUNABLE(GS_LIGHT_BINNED, 1)
+GS_TUNABLE(TRACE_REFILL, 16)
+GS_TUNABLE(TRACE_INNER, 4)
+GS_TUNABLE(TRACE_INNER_BREAK, 1)
+GS_TUNABLE(TRACE_WAVES, 1)
+GS_TUNABLE(GS_BILATERAL_DUAL, 1)
+#ifdef GS_EXPERIMENT_NO_LIGHT_GRAD
+GS_EXPERIMENT_ONLY(GS_EXPERIMENT_NO_LIGHT_GRAD)
+#endif

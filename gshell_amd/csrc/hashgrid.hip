@@ -168,7 +168,7 @@ struct EncArgs {
     int img_w, img_h;
     const int32_t* rows; const int64_t* count_dev;     // forward: optional compact list of the points to encode (count on the device)
     // backward, binned table gradient (below): per-bin fill counters, per-bin record arrays of `bin_cap` records, first bin of a level (-1: atomics)
-    uint32_t* bin_count; struct BinRec* bin_rec; uint32_t bin_cap; int bin_base[MAX_LEVELS];
+    uint32_t* bin_count; uint32_t* spill; struct BinRec* bin_rec; uint32_t bin_cap; int bin_base[MAX_LEVELS];
 };
 // Binned table gradient.  The hashed levels (res^3 > table size) scatter a tile's updates pseudo-randomly over the level's table: no
 // sharing to combine, one fabric atomic per (pixel, corner) -- 3/4 of the kernel's atomics.  Instead the table of such a level is cut
@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(256) k_encode_bin_reduce(GridMeta M, EncArgs A
     if (n == 0u) return;                                    // (a counter that overflowed is > 0, so it is reset below)
     // records that did not fit took the atomic path: counted in the word after the last bin's counter (never reset here), so that a caller
     // can see that its capacity is too small for its frames
-    if (tid == 0 && A.bin_count[b] > A.bin_cap) atomicAdd(&A.bin_count[gridDim.x], A.bin_count[b] - A.bin_cap);
+    if (tid == 0 && A.spill && A.bin_count[b] > A.bin_cap) atomicAdd(A.spill, A.bin_count[b] - A.bin_cap);
     int l = 0;
     for (int k = 0; k < M.n_levels; ++k)
         if (A.bin_base[k] >= 0 && A.bin_base[k] <= b) l = k;
@@ -725,8 +725,8 @@ extern "C" int gs_hashgrid_encode_fwd_rows(int n_levels, int F, int log2_T, int 
 
 static int encode_bwd_impl(int n_levels, int F, int log2_T, int base_res, float per_level_scale, const float* pos, const float* aabb, const float* mask,
                            int64_t N, const float* params, const float* g_feat_level_major, float* g_params, float* g_pos, float grad_scale,
-                           float table_scale, int64_t img_w, int64_t img_h, uint32_t* bin_count, void* bin_records, int64_t bin_capacity,
-                           gs_stream_t stream, const char* who) {
+                           float table_scale, int64_t img_w, int64_t img_h, uint32_t* bin_count, uint32_t* spill_count, void* bin_records,
+                           int64_t bin_capacity, gs_stream_t stream, const char* who) {
     GridMeta M;
     int rc = make_meta(M, n_levels, F, log2_T, base_res, per_level_scale);
     if (rc) return rc;
@@ -742,7 +742,7 @@ static int encode_bwd_impl(int n_levels, int F, int log2_T, int base_res, float 
         GS_REQUIRE(bin_count && bin_capacity > 0 && bin_capacity < (1ll << 31), "gs_hashgrid_encode_bwd_binned: bin counters / capacity missing");
         n_bins = bin_layout(M, A.bin_base);
         if (n_bins > 0) {
-            A.bin_count = bin_count; A.bin_rec = static_cast<BinRec*>(bin_records); A.bin_cap = (uint32_t)bin_capacity;
+            A.bin_count = bin_count; A.spill = spill_count; A.bin_rec = static_cast<BinRec*>(bin_records); A.bin_cap = (uint32_t)bin_capacity;
         }
     }
     const bool tiled = img_w > 0 && img_h > 0 && img_w % 16 == 0 && img_h % 16 == 0 && N % (img_w * img_h) == 0 && N / (img_w * img_h) < 65536 &&
@@ -760,7 +760,7 @@ extern "C" int gs_hashgrid_encode_bwd(int n_levels, int F, int log2_T, int base_
                                       const float* mask, int64_t N, const float* params, const float* g_feat_level_major, float* g_params,
                                       float* g_pos, float grad_scale, float table_scale, int64_t img_w, int64_t img_h, gs_stream_t stream) {
     return encode_bwd_impl(n_levels, F, log2_T, base_res, per_level_scale, pos, aabb, mask, N, params, g_feat_level_major, g_params, g_pos, grad_scale,
-                           table_scale, img_w, img_h, nullptr, nullptr, 0, stream, "gs_hashgrid_encode_bwd");
+                           table_scale, img_w, img_h, nullptr, nullptr, nullptr, 0, stream, "gs_hashgrid_encode_bwd");
 }
 
 extern "C" int64_t gs_hashgrid_bin_count(int n_levels, int F, int log2_T, int base_res, float per_level_scale) {
@@ -775,7 +775,17 @@ extern "C" int64_t gs_hashgrid_bin_entries(void) { return BIN_ENTRIES; }
 extern "C" int gs_hashgrid_encode_bwd_binned(int n_levels, int F, int log2_T, int base_res, float per_level_scale, const float* pos, const float* aabb,
                                              const float* mask, int64_t N, const float* params, const float* g_feat_level_major, float* g_params,
                                              float* g_pos, float grad_scale, float table_scale, int64_t img_w, int64_t img_h, uint32_t* bin_count,
-                                             void* bin_records, int64_t bin_capacity, gs_stream_t stream) {
+                                             uint32_t* spill_count, void* bin_records, int64_t bin_capacity, gs_stream_t stream) {
     return encode_bwd_impl(n_levels, F, log2_T, base_res, per_level_scale, pos, aabb, mask, N, params, g_feat_level_major, g_params, g_pos, grad_scale,
-                           table_scale, img_w, img_h, bin_count, bin_records, bin_capacity, stream, "gs_hashgrid_encode_bwd_binned");
+                           table_scale, img_w, img_h, bin_count, spill_count, bin_records, bin_capacity, stream, "gs_hashgrid_encode_bwd_binned");
 }
+
+// ---- compile-time variants of this file (common.hpp): non-default values announce themselves through gs_build_flags(); switches that give
+// wrong results (timing-only ablations) compile only under -DGS_EXPERIMENT
+GS_TUNABLE(GS_HG_LOG_SLOTS, 10)
+GS_TUNABLE(GS_HG_BIN_LOG, 12)
+GS_TUNABLE(GS_HG_WAVES, 4)
+GS_TUNABLE(GS_HG_RUNS, 8)
+GS_TUNABLE(GS_HG_ALTERNATE, 1)
+GS_TUNABLE(GS_HG_WAVETAB, 0)
+GS_TUNABLE(GS_HG_DIRECT_PAIR, 1)

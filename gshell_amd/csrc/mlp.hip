@@ -216,3 +216,8 @@ extern "C" int gs_sdf_mlp_fwd(const float* x, int64_t N, const float* packed, in
     GS_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- compile-time variants of this file (common.hpp): non-default values announce themselves through gs_build_flags(); switches that give
+// wrong results (timing-only ablations) compile only under -DGS_EXPERIMENT
+GS_TUNABLE(GS_MLP_SUB, 2)
+GS_TUNABLE(GS_MLP_INPLACE, 1)

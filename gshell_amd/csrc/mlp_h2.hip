@@ -2406,3 +2406,53 @@ extern "C" int gs_sdf_eikonal_rr_bwd(int64_t n, const void* packed, int n_freq, 
     GS_LAUNCH_CHECK();
     return wgrad_launch(MODE_RR, g_all, 2 * Rpad, 2 * Rpad, nullptr, n_freq, n_hidden, skip_layer, A_all, EMB_all, D_all, dW, db, exact_fp32, st);
 }
+
+// ---- compile-time variants of this file (common.hpp): non-default values announce themselves through gs_build_flags(); switches that give
+// wrong results (timing-only ablations) compile only under -DGS_EXPERIMENT
+GS_TUNABLE(GS_H2_FLUSH, 0)
+GS_TUNABLE(GS_H2_BPF, 0)
+GS_TUNABLE(GS_H2_ORDER, 0)
+GS_TUNABLE(GS_H2_PRIO, 0)
+GS_TUNABLE(GS_H2_PD, 1)
+GS_TUNABLE(GS_H1_PD, 2)
+GS_TUNABLE(GS_H1_ASM, 0)
+GS_TUNABLE(GS_H1_PRE, 0)
+GS_TUNABLE(GS_H1_POLY, 0)
+GS_TUNABLE(GS_H1_WAVES, 6)
+GS_TUNABLE(GS_H1_NW, 8)
+GS_TUNABLE(GS_H1_RM, 2)
+GS_TUNABLE(GS_H1R_ABL, 0)
+GS_TUNABLE(GS_H1R_PD, 1)
+GS_TUNABLE(GS_H1R_FENCE, 1)
+GS_TUNABLE(GS_H2_ABL, 0)
+GS_TUNABLE(GS_WG_PIPE, 0)
+GS_TUNABLE(GS_WG_CONTIG, 1)
+GS_TUNABLE(GS_WG_ABL, 0)
+GS_TUNABLE(GS_WG_DEPTH, 1)
+GS_TUNABLE(GS_H2_DUAL, 0)
+GS_TUNABLE(GS_WG_STRIPS, 80)
+GS_TUNABLE_F(GS_WG_W0, 0.6)
+#if GS_H1R_ABL != 0
+GS_EXPERIMENT_ONLY(GS_H1R_ABL)
+#endif
+#if GS_H2_ABL != 0
+GS_EXPERIMENT_ONLY(GS_H2_ABL)
+#endif
+#ifdef GS_H2_EMU1
+GS_EXPERIMENT_ONLY(GS_H2_EMU1)
+#endif
+#ifdef GS_H2_NOBAR
+GS_EXPERIMENT_ONLY(GS_H2_NOBAR)
+#endif
+#ifdef GS_H2_NOEPI
+GS_EXPERIMENT_ONLY(GS_H2_NOEPI)
+#endif
+#ifdef GS_H2_NOLDS
+GS_EXPERIMENT_ONLY(GS_H2_NOLDS)
+#endif
+#ifdef GS_H2_NOW
+GS_EXPERIMENT_ONLY(GS_H2_NOW)
+#endif
+#if GS_WG_ABL != 0
+GS_EXPERIMENT_ONLY(GS_WG_ABL)
+#endif

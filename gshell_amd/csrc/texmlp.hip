@@ -408,3 +408,11 @@ extern "C" int gs_texmlp_bwd_rows(const float* x_level_major, const int32_t* row
     if (cap == 0) return 0;
     return texmlp_bwd(x_level_major, 1, rows, count_dev, cap, nullptr, N, w1, w2, w3, C, lo, hi, g_out, g_x_level_major, g_w1, g_w2, g_w3, stream);
 }
+
+// ---- compile-time variants of this file (common.hpp): non-default values announce themselves through gs_build_flags(); switches that give
+// wrong results (timing-only ablations) compile only under -DGS_EXPERIMENT
+GS_TUNABLE(GS_TEX_ABL, 0)
+GS_TUNABLE(GS_TEX_MFMA, 1)
+#if GS_TEX_ABL != 0
+GS_EXPERIMENT_ONLY(GS_TEX_ABL)
+#endif

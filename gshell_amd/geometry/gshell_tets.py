@@ -117,11 +117,14 @@ class _MarchingTetsFn(torch.autograd.Function):
                 check(L.gs_mtets_tangents(c_int64(V), c_int64(M1), c_int64(M2), c_int64(topo.F), ptr(verts_wt), ptr(faces_wt),
                                           ptr(msdf_aug), ptr(poly), ptr(topo.uv_lin), c_int64(topo.Nuv), ptr(scratch),
                                           ptr(v_tng_aug), stream()), "gs_mtets_tangents")
-        ctx.save_for_backward(pos_c, sdf_c, msdf_c, verts_wt, msdf_aug, vert_ab, used_wt, poly, cut_code)
+        # (the tangent pass's tensors -- the OUTPUT v_tng_aug among them -- go through save_for_backward too: as plain attributes of ctx they formed an
+        # output -> grad_fn -> ctx -> output cycle that only the cyclic GC frees, and escaped autograd's in-place-modification check)
+        tng = (faces_wt, scratch, v_tng_aug, topo.uv_lin) if scratch is not None else ()
+        ctx.save_for_backward(pos_c, sdf_c, msdf_c, verts_wt, msdf_aug, vert_ab, used_wt, poly, cut_code, *tng)
         ctx.dims = (topo.N, V, M1, M2)
         ctx.in_shapes = (pos.shape, sdf.shape, msdf.shape)
         # tangents: differentiable (compute_tangents + auto_normals + boundary interpolation, gshell_tets.py:9-78, :318-319, :375-380)
-        ctx.tng = (faces_wt, scratch, v_tng_aug, topo.uv_lin, topo.Nuv) if scratch is not None else None
+        ctx.tng = topo.Nuv if scratch is not None else None          # (an int; the tensors are saved above)
         ctx.mark_non_differentiable(faces_wt, faces_aug, faces_i32, tet_id)
         if scratch is None:
             ctx.mark_non_differentiable(v_tng_aug)
@@ -130,7 +133,7 @@ class _MarchingTetsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_verts_aug, g_msdf_aug, g_verts_wt, g_faces_aug=None, g_faces_wt=None, g_faces_i32=None, g_tng_aug=None, *_unused):
-        pos, sdf, msdf, verts_wt, msdf_aug, vert_ab, used_wt, poly, cut_code = ctx.saved_tensors
+        pos, sdf, msdf, verts_wt, msdf_aug, vert_ab, used_wt, poly, cut_code = ctx.saved_tensors[:9]
         N, V, M1, M2 = ctx.dims
         dev = pos.device
         flat = torch.zeros((5 * N,), dtype=torch.float32, device=dev)          # one fill, three views
@@ -143,7 +146,8 @@ class _MarchingTetsFn(torch.autograd.Function):
             ga, gm, gw = prep(g_verts_aug), prep(g_msdf_aug), prep(g_verts_wt)
             g_mv = None
             if g_tng_aug is not None:
-                faces_wt, acc, v_tng_aug, uv_lin, Nuv = ctx.tng
+                faces_wt, acc, v_tng_aug, uv_lin = ctx.saved_tensors[9:13]
+                Nuv = ctx.tng
                 gt = prep(g_tng_aug)
                 g_vw_t = torch.empty((V, 3), dtype=torch.float32, device=dev)
                 g_mv = torch.empty((V,), dtype=torch.float32, device=dev)

@@ -261,8 +261,11 @@ def pack_weights_h2(net, status=None):
     # backward: two of three launches and their host time -- right after the extraction's sync, where the GPU waits for the host).  Key: storage
     # and version counter of every parameter (torch's in-place updates and HipAdam.step both bump the version).  A call that asks for the
     # fp16-range check (`status`) always packs.
-    key = tuple((p.data_ptr(), p._version) for m in lin for p in (m.weight, m.bias))
-    cached = net.__dict__.get("_gs_packed_cache")
+    # INVARIANT for every writer of the parameters: a write must bump the version counter (any torch in-place op does; a raw-pointer kernel or a
+    # write through `.data` -- HipAdam.step, ViewShard.broadcast -- calls torch.autograd.graph.increment_version) or call invalidate_packed(net).
+    # The cache lives OUTSIDE the module (weak table): copy.deepcopy(net) / state_dict round trips never carry a stale image along.
+    key = tuple((p.data_ptr(), p._version) for m in lin for p in (m.weight, m.bias)) + (int(_lib.lib().gs_sdf_mlp_h1_impl(c_int(-1))),)
+    cached = _PACKED.get(net)
     if status is None and cached is not None and cached[0] == key:
         return cached[1], n_hidden, skip
     L = _lib.lib()
@@ -279,8 +282,17 @@ def pack_weights_h2(net, status=None):
     with torch.cuda.device(dev):
         check(L.gs_sdf_mlp_h2_pack(PtrArr(*[t.data_ptr() for t in ws]), PtrArr(*[t.data_ptr() for t in bs]), c_int(nf), c_int(n_hidden), c_int(skip),
                                    ptr(packed), ptr(status), stream()), "gs_sdf_mlp_h2_pack")
-    net.__dict__["_gs_packed_cache"] = (key, packed)
+    _PACKED[net] = (key, packed)
     return packed, n_hidden, skip
+
+
+import weakref      # noqa: E402
+_PACKED = weakref.WeakKeyDictionary()      # net -> (key, packed image)
+
+
+def invalidate_packed(net):
+    """Drop the cached packed image of `net`: for a writer of its parameters that does not bump their version counters."""
+    _PACKED.pop(net, None)
 
 
 class ForwardStatus:

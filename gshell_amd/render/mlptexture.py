@@ -96,7 +96,10 @@ def _bins(cfg, N, device):
     if nb <= 0:
         return None
     per_level = max(1, (1 << cfg[2]) // int(_lib.lib().gs_hashgrid_bin_entries()))      # bins of a full-size (hashed) level
-    active = ACTIVE_ROWS_HINT[0] if ACTIVE_ROWS_HINT[0] is not None else BIN_COVERAGE * N
+    # the hint belongs to ONE coming call: consumed here (a later backward that does not come from shade() -- another frame size, a bake, a test --
+    # must not size its bins from a stale frame)
+    hint, ACTIVE_ROWS_HINT[0] = ACTIVE_ROWS_HINT[0], None
+    active = hint if hint is not None else BIN_COVERAGE * N
     want = int(1.25 * min(active, N) * 8 / per_level) + 1024
     key = (str(device), nb)
     cur = _bin_scratch.get(key)
@@ -104,6 +107,7 @@ def _bins(cfg, N, device):
         cap = want if cur is None else max(want, int(1.5 * cur[2]))
         spilled = 0 if cur is None else int(cur[0][nb])
         _bin_scratch.pop(key, None)
+        cur = None                       # the old record array is released BEFORE the larger one is allocated (peak = new, not old + new)
         counters = torch.zeros(nb + 1, dtype=torch.int32, device=device)
         counters[nb] = spilled
         _bin_scratch[key] = (counters, torch.empty(nb * cap * 3, dtype=torch.int32, device=device), cap)
@@ -207,6 +211,7 @@ class _FieldFn(torch.autograd.Function):
                     check(L.gs_hashgrid_encode_bwd_binned(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4]), ptr(pos_c), ptr(ab),
                                                           ptr(m_c), c_int64(N), ptr(p_c), ptr(g_feat), ptr(g_params), ptr(g_pos),
                                                           c_float(mlp_scale * enc_scale), c_float(mlp_scale), c_int64(W), c_int64(H), ptr(bins[0]),
+                                                          _lib.c_void_p(bins[0].data_ptr() + 4 * (bins[0].numel() - 1)),      # spill word = the last one
                                                           ptr(bins[1]), c_int64(bins[2]), stream()), "gs_hashgrid_encode_bwd_binned")
                 else:
                     check(L.gs_hashgrid_encode_bwd(c_int(cfg[0]), c_int(cfg[1]), c_int(cfg[2]), c_int(cfg[3]), c_float(cfg[4]), ptr(pos_c), ptr(ab),

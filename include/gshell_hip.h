@@ -32,6 +32,10 @@ typedef void* gs_stream_t; /* hipStream_t */
 
 const char* gs_last_error(void);
 int gs_version(void);
+/* "" for the shipped library.  A library built with non-default compile-time variants (tools/build_variant.sh) lists them, e.g.
+ * "GS_WG_STRIPS=64 GS_EXPERIMENT(mlp_h2.hip)=1" -- several switches are timing-only ablations that give wrong results; bench.py refuses to
+ * report a number for a library whose string is not empty. */
+const char* gs_build_flags(void);
 /* async device-to-device copy on `stream` (used to export library-owned tables) */
 int gs_memcpy_d2d(void* dst, const void* src, int64_t bytes, gs_stream_t stream);
 
@@ -438,9 +442,9 @@ int gs_hashgrid_encode_bwd(int n_levels, int F, int log2_T, int base_res, float 
  * table is cut into bins of 4096 entries, k_encode_bwd writes (entry, d pair) records into per-bin arrays of `bin_capacity`
  * 12-byte records (one returning atomic per workgroup, level and bin reserves the run), a second launch sums every bin in LDS
  * and adds it to g_params.  A reservation past `bin_capacity` takes the atomic path, so the result is correct for ANY capacity;
- * uniform hashing puts ~ 8 * (rows with mask > 0) / 128 records in a bin.  `bin_count` [gs_hashgrid_bin_count() + 1] uint32, zero
- * before the first call (the reducer leaves the per-bin words zero; the LAST word accumulates the number of records that spilled to
- * the atomic path and is never reset by the library); `bin_records` [bins * bin_capacity * 12 bytes] scratch. */
+ * uniform hashing puts ~ 8 * (rows with mask > 0) / 128 records in a bin.  `bin_count` [gs_hashgrid_bin_count()] uint32, zero
+ * before the first call (the reducer leaves the words zero); `spill_count` (ONE uint32, may be NULL): += the number of records that
+ * spilled to the atomic path, never reset by the library; `bin_records` [bins * bin_capacity * 12 bytes] scratch. */
 int64_t gs_hashgrid_bin_count(int n_levels, int F, int log2_T, int base_res, float per_level_scale);
 int64_t gs_hashgrid_bin_entries(void);     /* table entries per bin */
 int gs_hashgrid_encode_bwd_binned(int n_levels, int F, int log2_T, int base_res, float per_level_scale,
@@ -448,7 +452,8 @@ int gs_hashgrid_encode_bwd_binned(int n_levels, int F, int log2_T, int base_res,
                                   const float* params, const float* g_feat_level_major,
                                   float* g_params, float* g_pos, float grad_scale, float table_scale,
                                   int64_t img_w, int64_t img_h, uint32_t* bin_count,
-                                  void* bin_records, int64_t bin_capacity, gs_stream_t stream);
+                                  uint32_t* spill_count /* may be NULL */, void* bin_records,
+                                  int64_t bin_capacity, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Softplus with first and second derivative   (the activation of geometry/mlp.py:19-33, nn.Softplus(beta=100);

@@ -187,7 +187,7 @@ def test_binned_table_gradient_equals_the_atomic_path_for_any_capacity(capacity)
     assert scale > 0
     for rep in range(2):
         gp_b, gx_b = torch.zeros(n_par, device=DEV), torch.empty_like(pos)
-        check(L.gs_hashgrid_encode_bwd_binned(*head, ptr(gp_b), ptr(gx_b), *tail, ptr(count), ptr(rec), c_int64(capacity), stream()), "binned")
+        check(L.gs_hashgrid_encode_bwd_binned(*head, ptr(gp_b), ptr(gx_b), *tail, ptr(count), _lib.c_void_p(count.data_ptr() + 4 * nb), ptr(rec), c_int64(capacity), stream()), "binned")
         assert int(count[:nb].abs().max()) == 0, "the reducer must leave the bin counters at zero"
         spilled = int(count[nb])                    # the word after the counters: records that took the atomic path, summed over the calls
         assert (spilled > 0) == (capacity < 1000) and (rep == 0 or spilled % 2 == 0), (capacity, spilled)

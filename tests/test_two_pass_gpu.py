@@ -226,7 +226,7 @@ def test_register_resident_first_pass_kernel_computes_the_same_function(n_rows):
                                            _lib.ptr(occ), _lib.ptr(st), _lib.stream()))
     finally:
         L.gs_sdf_mlp_h1_impl(_lib.c_int(old))
-        net.__dict__.pop("_gs_packed_cache", None)
+        mlp.invalidate_packed(net)
     assert float((y[:n_rows] - ref).abs().max()) < 5e-4
     assert bool((y[n_rows:] == 7.0).all())
     bits = ((occ[:, None] >> torch.arange(64, device=DEV)[None]) & 1).reshape(-1)[:n_rows].bool()
