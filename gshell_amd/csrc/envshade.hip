@@ -916,6 +916,13 @@ __global__ void __launch_bounds__(TRACE_NT, 6) k_shade_trace(ShadeArgs A, int64_
         A.vis_bits[(chunk0 >> 6) + lane] = (uint64_t)s_vis[wave][2 * lane] | ((uint64_t)s_vis[wave][2 * lane + 1] << 32);
 }
 
+// Tried and removed (round 5, VERDICT r4 item 5 i): ONE QUEUE for the whole launch instead of a 1024-ray chunk per wave -- a persistent grid (one wave
+// per wave slot of the chip) claiming 64 rays at a time with an atomic on a launch-wide counter, visibility bits pre-set by a memset and cleared by
+// 64-bit global atomics on a hit.  Bit-identical visibility (tests/test_ray_stage_fullsize_parity_gpu.py green), but gs_env_shade_fwd 4.65 ms against
+// 3.39 with the chunks (same box, same call; the iteration 16.1 - 16.3 against 14.75): a claim stalls ALL of a wave's rays for the atomic's round
+// trip 16 times as often as a chunk ends, and the chunks' sequential ray-record reads are gone.  The per-chunk tail it was meant to remove is the
+// smaller cost.  With the shared-origin prefix and the two-launch split below, the ray stage has had its three structural variants; the chunked
+// kernel stays.
 // Tried and removed (round 4, profiles/r04_trace_variants.txt): a SHARED-ORIGIN variant for 2 n^2 % 64 == 0 -- the 64 rays a wave stages belong
 // to one pixel, so the nodes whose box contains that origin (about 7 of the ~15 a miss visits) were found once per batch (lane k tests
 // child k) and then slab-tested by all lanes in lock step, the divergent traversal starting below them from per-ray child masks (12 bytes per
