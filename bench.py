@@ -258,16 +258,33 @@ ROOFLINE_CANDIDATES = {"gs_env_shade_fwd", "gs_sdf_mlp_fwd_h1", "gs_sdf_mlp_fwd_
                        "gs_sdf_mlp_h2_save_fwd", "gs_sdf_eikonal_rr_fwd", "gs_sdf_eikonal_rr_bwd", "gs_flexi_vd_bwd", "gs_flexi_vd_fwd"}
 
 
+EVIDENCE_ROUND = "r05"          # bench.py reads ONLY this round's PMC files (profiles/r05_*, written by tools/collect_r05.sh + tools/assemble_r05.py)
+
+
+def _evidence(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", f"{EVIDENCE_ROUND}_{name}")) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def _head_commit():
+    try:
+        import subprocess
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_traffic.json; collected with
-    rocprofv3 --pmc in separate runs, corrected as MI355X_MICROARCH.md prescribes) -- None if not measured."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                return float(json.load(f)[kernel]["bytes"])
-        except Exception:
-            continue
-    return None
+    """HBM bytes per launch of `kernel` from THIS round's committed PMC passes (profiles/r05_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
+    WRITE_SIZE in separate runs, bytes = 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950) -- None if not measured."""
+    d = _evidence("pmc_traffic.json")
+    try:
+        return float(d[kernel]["bytes"])
+    except Exception:
+        return None
 
 
 def algorithmic_bytes(N, Ftets, V_aug, T, B, H, W):
@@ -322,15 +339,19 @@ def rooflines(op_times, N, Ftets, V_aug, T, B, H, W, n, trainer):
 
 
 def binding_metric(key):
-    """What the rocprofv3 --pmc passes committed under profiles/ say binds a kernel family: the resource and its
-    measured utilisation.  profiles/r04_binding.json is written by tools/pmc_binding.py from the round's PMC runs."""
-    for name in ("r04_binding.json",):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f).get(key)
-        except Exception:
-            continue
-    return None
+    """What this round's rocprofv3 --pmc passes say binds a kernel family: the resource and its measured utilisation (profiles/r05_binding.json,
+    written by tools/assemble_r05.py).  The record names the commit it was collected at; `stale_vs_head` is set when the source tree has moved on
+    since -- kernel times in the line are live, the utilisation figures are then those of the named commit."""
+    d = _evidence("binding.json")
+    if not d or key not in d:
+        return None
+    b = dict(d[key])
+    at = (d.get("_meta") or {}).get("collected_at_commit")
+    b["collected_at_commit"] = at
+    head = _head_commit()
+    if at and head and at != head:
+        b["stale_vs_head"] = head[:12]
+    return b
 
 
 def roofline_of(name, rec, op_times, N, Ftets, V_aug, T, B, H, W, n, trainer):
@@ -348,6 +369,8 @@ def roofline_of(name, rec, op_times, N, Ftets, V_aug, T, B, H, W, n, trainer):
         gbps = alg_bytes / t / 1e9
         out = {"kernel": kernel, "bound": "hbm", "achieved": round(gbps, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 5),
                "traffic": pmc_traffic(pmc_key or name) if N == 2282489 else None, "avg_launch_ms": round(ms, 4), "algorithmic_bytes": int(alg_bytes)}
+        if out["traffic"]:
+            out["traffic_over_algorithmic"] = round(out["traffic"] / alg_bytes, 2)        # wasted re-reads / implementation buffers, per launch
         out.update(extra)
         b = binding_metric(name)
         if b:

@@ -683,6 +683,9 @@ __device__ __forceinline__ void gemm_seg1(v16f (&acc)[NB][RM], const _Float16* _
 // g is replaced by a degree-8 polynomial in v = u / 5 - 1 on u in [0, 10] (max error 6.2e-5, i.e. 4e-7 on the activation -- the
 // fp16 rounding of the activation that follows is 2^-11 relative) and held at its end value beyond (g(10) = 1.4e-3: 1e-5 on the
 // activation; the exact kernel switches to the identity at t > 28.9).  All of it packed fp32 FMAs: 17 full-rate instructions per pair.
+#ifndef GS_H1_ASMMAX
+#define GS_H1_ASMMAX 1
+#endif
 #ifndef GS_H1_POLY
 #define GS_H1_POLY 0       // 0: the exact softplus100_pair (default: measured FASTER -- 2.45 ms against 2.74 (degree 8) / 2.68 (degree 7): the
                            // transcendental unit runs beside the VALU, the 17 packed instructions do not)
@@ -698,7 +701,17 @@ __device__ __forceinline__ f2 softplus100_pair_poly(f2 z) {
     f2 e = {__builtin_amdgcn_exp2f(-fabsf(t.x)), __builtin_amdgcn_exp2f(-fabsf(t.y))};
     e = e + 1.0f;
     const f2 l = {__builtin_amdgcn_logf(e.x), __builtin_amdgcn_logf(e.y)};
-    return pk_fma(l, f2{SP_C2, SP_C2}, f2{__builtin_amdgcn_fmed3f(z.x, 0.0f, __builtin_inff()), __builtin_amdgcn_fmed3f(z.y, 0.0f, __builtin_inff())});   // max(z, 0) in ONE instruction (fmaxf adds a canonicalising v_max)
+#if GS_H1_ASMMAX
+    // max(z, 0) as ONE v_max_f32: fmaxf, and fmed3(z, 0, inf) which the compiler folds back into it, both come with a canonicalising v_max(z, z) in
+    // front -- 4 of the epilogue's 12 instructions per pair.  (The unused second input keeps the asm behind the logarithm it is added to: hoisted, a
+    // tile's worth of results would sit in registers.)
+    f2 m;
+    asm("v_max_f32 %0, 0, %1" : "=v"(m.x) : "v"(z.x), "v"(l.x));
+    asm("v_max_f32 %0, 0, %1" : "=v"(m.y) : "v"(z.y), "v"(l.y));
+    return pk_fma(l, f2{SP_C2, SP_C2}, m);
+#else
+    return pk_fma(l, f2{SP_C2, SP_C2}, f2{__builtin_amdgcn_fmed3f(z.x, 0.0f, __builtin_inff()), __builtin_amdgcn_fmed3f(z.y, 0.0f, __builtin_inff())});
+#endif
 #else
     const f2 t = z * SP_C1;
     const f2 u = f2{fminf(fabsf(t.x), 10.0f), fminf(fabsf(t.y), 10.0f)};
@@ -809,23 +822,34 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? GS_H1_WAVES : GS_H1_WAVES4)
         f2 part[RM];
 #pragma unroll
         for (int r = 0; r < RM; ++r) part[r] = f2{0.f, 0.f};
+        // (`last` is tested ONCE per layer, not per element: as a branch inside the loops it cut the epilogue into one basic block per two pairs,
+        //  and nothing could be scheduled across them)
+        if (last) {
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            const int n_base = (blk0 + q) * 32 + 4 * (lane >> 5);
+            for (int q = 0; q < NB; ++q)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f2 wj[2] = {f2{bnext[q][g].x, bnext[q][g].y}, f2{bnext[q][g].z, bnext[q][g].w}};       // (last layer: the output weights)
+                for (int g = 0; g < 4; ++g) {
+                    const f2 wj[2] = {f2{bnext[q][g].x, bnext[q][g].y}, f2{bnext[q][g].z, bnext[q][g].w}};       // the output weights
 #pragma unroll
-                for (int r = 0; r < RM; ++r) {
-                    const f2 v0 = softplus100_pair_poly(f2{acc[q][r][4 * g], acc[q][r][4 * g + 1]});
-                    const f2 v1 = softplus100_pair_poly(f2{acc[q][r][4 * g + 2], acc[q][r][4 * g + 3]});
-                    if (last) {
+                    for (int r = 0; r < RM; ++r) {
+                        const f2 v0 = softplus100_pair_poly(f2{acc[q][r][4 * g], acc[q][r][4 * g + 1]});
+                        const f2 v1 = softplus100_pair_poly(f2{acc[q][r][4 * g + 2], acc[q][r][4 * g + 3]});
                         part[r] = part[r] + v0 * wj[0] + v1 * wj[1];
-                    } else {
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int n_base = (blk0 + q) * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < RM; ++r) {
+                        const f2 v0 = softplus100_pair_poly(f2{acc[q][r][4 * g], acc[q][r][4 * g + 1]});
+                        const f2 v1 = softplus100_pair_poly(f2{acc[q][r][4 * g + 2], acc[q][r][4 * g + 3]});
                         const h2 a0 = __builtin_convertvector(v0, h2), a1 = __builtin_convertvector(v1, h2);
                         *reinterpret_cast<h4*>(H1 + (32 * r + m_lane) * LDH + n_base + 8 * g) = h4{a0.x, a0.y, a1.x, a1.y};
                     }
-                }
             }
         }
         if (last) {
@@ -2418,6 +2442,7 @@ GS_TUNABLE(GS_H1_PD, 2)
 GS_TUNABLE(GS_H1_ASM, 0)
 GS_TUNABLE(GS_H1_PRE, 0)
 GS_TUNABLE(GS_H1_POLY, 0)
+GS_TUNABLE(GS_H1_ASMMAX, 1)
 GS_TUNABLE(GS_H1_WAVES, 6)
 GS_TUNABLE(GS_H1_NW, 8)
 GS_TUNABLE(GS_H1_RM, 2)
