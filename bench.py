@@ -269,12 +269,21 @@ def _evidence(name):
         return None
 
 
-def _head_commit():
-    try:
-        import subprocess
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
-    except Exception:
-        return None
+def source_hash():
+    """sha256 over the product's sources (gshell_amd/**/*.py|hip|hpp, include/*.h): what the PMC evidence is stamped with (tools/assemble_r05.py) and
+    compared against here -- a commit id would go stale the moment the evidence itself is committed."""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for base in ("gshell_amd", "include"):
+        for dp, dn, fn in os.walk(os.path.join(ROOT, base)):
+            dn[:] = [d for d in dn if d not in ("__pycache__", "lib", ".pytest_cache")]
+            files += [os.path.join(dp, f) for f in fn if f.endswith((".py", ".hip", ".hpp", ".h")) or f == "Makefile"]
+    for f in sorted(files):
+        h.update(os.path.relpath(f, ROOT).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel):
@@ -340,17 +349,17 @@ def rooflines(op_times, N, Ftets, V_aug, T, B, H, W, n, trainer):
 
 def binding_metric(key):
     """What this round's rocprofv3 --pmc passes say binds a kernel family: the resource and its measured utilisation (profiles/r05_binding.json,
-    written by tools/assemble_r05.py).  The record names the commit it was collected at; `stale_vs_head` is set when the source tree has moved on
-    since -- kernel times in the line are live, the utilisation figures are then those of the named commit."""
+    written by tools/assemble_r05.py).  The record names the hash of the product sources it was collected on; `stale_sources_now` is set when they have
+    changed since -- kernel times in the line are live, the utilisation figures are then those of the named source state."""
     d = _evidence("binding.json")
     if not d or key not in d:
         return None
     b = dict(d[key])
-    at = (d.get("_meta") or {}).get("collected_at_commit")
-    b["collected_at_commit"] = at
-    head = _head_commit()
-    if at and head and at != head:
-        b["stale_vs_head"] = head[:12]
+    at = (d.get("_meta") or {}).get("source_hash")
+    b["collected_at_source_hash"] = at
+    now = source_hash()
+    if at and at != now:
+        b["stale_sources_now"] = now
     return b
 
 

@@ -264,7 +264,7 @@ def pack_weights_h2(net, status=None):
     # INVARIANT for every writer of the parameters: a write must bump the version counter (any torch in-place op does; a raw-pointer kernel or a
     # write through `.data` -- HipAdam.step, ViewShard.broadcast -- calls torch.autograd.graph.increment_version) or call invalidate_packed(net).
     # The cache lives OUTSIDE the module (weak table): copy.deepcopy(net) / state_dict round trips never carry a stale image along.
-    key = tuple((p.data_ptr(), p._version) for m in lin for p in (m.weight, m.bias)) + (int(_lib.lib().gs_sdf_mlp_h1_impl(c_int(-1))),)
+    key = tuple((p.data_ptr(), p._version) for m in lin for p in (m.weight, m.bias)) + (int(_lib._real_lib_fn().gs_sdf_mlp_h1_impl(c_int(-1))),)          # (the raw library: not an op to be timed)
     cached = _PACKED.get(net)
     if status is None and cached is not None and cached[0] == key:
         return cached[1], n_hidden, skip

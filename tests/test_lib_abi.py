@@ -29,3 +29,12 @@ def test_product_path_refuses_cpu_tensors():
     import torch
     with pytest.raises(_lib.GShellHipError):
         _lib.ptr(torch.zeros(4), torch.float32, "x")
+
+
+def test_the_in_tree_library_is_the_shipped_build():
+    """gs_build_flags() lists every GS_TUNABLE that is off its default and every GS_EXPERIMENT block compiled in (csrc/common.hpp);
+    the library that travels to the GPU box must report none.  Host-side registry: no device call."""
+    L = _lib.lib()
+    flags = L.gs_build_flags().decode()
+    assert flags == "", f"libgshell_hip.so was built with non-default compile-time flags: {flags}"
+    assert len(_lib.declared_symbols()) >= 130

@@ -30,8 +30,9 @@ def sq_record(tag, desc, **extra):
 
 
 def main():
-    head = commit()
-    stamp = {"collected_at_commit": head, "collected_by": "tools/collect_r05.sh (one gpurun call)"}
+    sys.path.insert(0, ROOT)
+    import bench
+    stamp = {"source_hash": bench.source_hash(), "collected_by": "tools/collect_r05.sh (one gpurun call on the tree with this source hash)"}
     for name in ("bench_default.log", "bench_op_times.log", "iteration_res256_kernel_stats.csv", "torch_kernel_regions.txt", "torch_kernel_ops.txt", "chain_time.txt",
                  "bvh_stats.txt", "gpu_gaps.txt", "pixel_parity_512.txt"):
         if os.path.isfile(os.path.join(SRC, name)):

@@ -1,14 +1,16 @@
 #!/bin/bash
 # HBM traffic (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes) of a kernel FAMILY of the training iteration: for every kernel whose
 # name contains one of the given substrings, the counters of its LAST dispatch; the family total is their sum.  GPU box.
+# --extra-steps 0: without it the LAST dispatch of every kernel belongs to bench.py's close-camera side run (41 % coverage), not to the
+# headline camera the algorithmic bytes are quoted for.
 #   usage: tools/pmc_family_traffic.sh <tag> <substr1> [<substr2> ...]       -> gpurun_out/pmc_<tag>/traffic.json
 tag="$1"; shift
 root="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 out="$root/gpurun_out/pmc_$tag"; rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-python "$root/bench.py" --no-cpu-baseline --early-steps 0 --steps 1 --warmup 0 --state-file "$out/state.pt" > "$out/setup.log" 2>&1 </dev/null
+python "$root/bench.py" --no-cpu-baseline --early-steps 0 --extra-steps 0 --steps 1 --warmup 0 --state-file "$out/state.pt" > "$out/setup.log" 2>&1 </dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $c --kernel-trace -d "$out/$c" -o r --output-format csv -- python "$root/bench.py" --no-cpu-baseline --early-steps 0 --steps 2 --warmup 1 --state-file "$out/state.pt" > "$out/$c.log" 2>&1 </dev/null
+  timeout 400 rocprofv3 --pmc $c --kernel-trace -d "$out/$c" -o r --output-format csv -- python "$root/bench.py" --no-cpu-baseline --early-steps 0 --extra-steps 0 --steps 2 --warmup 1 --state-file "$out/state.pt" > "$out/$c.log" 2>&1 </dev/null
   f=$(find "$out/$c" -name "*counter_collection.csv" | head -1)
   python - "$f" "$out/$c.json" "$@" <<'PY'
 import csv, sys, json, re
