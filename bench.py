@@ -245,6 +245,10 @@ def main():
             out["op_calls_per_step"] = {k: v["n"] / a.steps for k, v in op_times.items()}
         if not a.no_cpu_baseline and world == 1:      # reported at N=1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(a.res if a.geometry == "tets" else 256)
+            try:
+                out["cpu_baseline"].setdefault("stages", {})["env_shade_reference_kernel"] = cpu_reference_env_shade(trainer, a, H, W, op_times, B_local)
+            except Exception as e:           # pragma: no cover
+                out["cpu_baseline"].setdefault("stages", {})["env_shade_reference_kernel"] = {"error": f"{type(e).__name__}: {e}"}
             ref = gpu_reference_formulation(trainer)
             if ref:
                 out["gpu_reference_formulation"] = ref
@@ -504,6 +508,59 @@ def cpu_stage_times(res):
     st["extraction_fwd"] = {"s": round(time.perf_counter() - t0, 3), "tets": int(tets.shape[0]), "faces": int(ex["faces_aug"].shape[0]),
                             "what": "oracle/mtets_oracle (edge unique + gathers, the formulation of geometry/gshell_tets.py:245-443), torch CPU"}
     return st
+
+
+def cpu_reference_env_shade(trainer, a, H, W, op_times, B_local):
+    """The dominant kernel family on the host, by the REFERENCE'S OWN CODE (`kind: reference`): render/optixutils/c_src/envsampling/kernel.cu
+    compiled for the host (oracle/_ref/ref_envshade.so, built by oracle/Makefile from the reference tree; OpenMP over pixels, optixTrace answered
+    by oracle/anyhit_grid.h) on ONE view of the headline workload -- this run's mesh, its 512 x 512 g-buffer made by the product's stages, the same
+    probe, n_samples -- forward (`backward = 0`) and gradient launch (`backward = 1`), as optixutils/ops.py:81-108 issues them."""
+    import numpy as np
+    from oracle import refnative as rn
+    if not rn.available("ref_envshade"):
+        return {"error": "oracle/_ref/ref_envshade.so not built (needs /root/reference at build time)"}
+    from gshell_amd import workload
+    from gshell_amd.render import rast as dr, renderutils as ru
+    n = a.n_samples
+    dev = trainer.geometry.verts.device
+    with torch.no_grad():
+        m = trainer.geometry.getMesh(trainer.mat)['imesh']
+        mvp, campos = workload.views([0], dev, radius=a.camera_radius)
+        tri = m.faces_i32().contiguous()
+        rast, _ = dr.rasterize(None, ru.xfm_points(m.v_pos[None], mvp), tri, (H, W))
+        gb_pos, gb_nrm_s = dr.interpolate_groups([m.v_pos.contiguous(), m.v_nrm.contiguous()], rast, tri)
+        gb_geo = dr.face_normals(m.v_pos, tri, rast)
+        view = campos[:, None, None, :].contiguous()
+        tng = torch.cross(torch.nn.functional.normalize(torch.randn_like(gb_nrm_s), dim=-1), gb_nrm_s, dim=-1)
+        gb_nrm = ru.prepare_shading_normal(gb_pos, view, None, gb_nrm_s, tng, gb_geo, two_sided_shading=True, opengl=True).contiguous()
+        mask = (rast[..., 3] > 0).float()
+        tex = trainer.mat['kd_ks'].sample(gb_pos)
+        ro = (gb_pos + gb_nrm * 0.001).contiguous()
+        trainer.lgt.update_pdf()
+        lg = trainer.lgt
+        g = [mask, ro, gb_pos.contiguous(), gb_nrm, view, tex[..., 0:3].contiguous(), tex[..., 3:6].contiguous(), lg.base.detach(), lg._pdf, lg.rows[:, 0].contiguous(), lg.cols]
+        g = [t.detach().float().cpu().numpy() for t in g]
+        verts, tris = m.v_pos.detach().float().cpu().numpy(), tri.cpu().numpy()
+    gen = torch.Generator().manual_seed(21)
+    perms = torch.argsort(torch.rand(256, n * n, generator=gen), dim=-1).int().numpy()
+    tail = (perms, 0, n, 4242, 1.0, verts, tris)
+    rn.set_threads(0)
+    rn.set_anyhit_mode(True)
+    t0 = time.perf_counter()
+    rn.env_shade_fwd(*g, *tail)
+    t_f = time.perf_counter() - t0
+    dg = torch.rand(2, 1, H, W, 3, generator=gen).numpy()
+    t0 = time.perf_counter()
+    rn.env_shade_bwd(*g, *tail, dg[0], dg[1])
+    t_b = time.perf_counter() - t0
+    cov = int((g[0] > 0).sum())
+    out = {"kind": "reference", "what": "kernel.cu / bsdf.h compiled for the host (oracle/_ref/ref_envshade.so), OpenMP over pixels, grid-filtered any-hit with the kernels' fp32 predicate",
+           "sample": f"1 of the {B_local} views, {H}x{W}, n_samples={n} ({2 * n * n} shadow rays / covered pixel / launch), {int(tris.shape[0])} triangles, {cov} covered pixels",
+           "cores": int(os.cpu_count() or 1), "s_fwd_launch": round(t_f, 3), "s_bwd_launch": round(t_b, 3), "covered_Mpixels_per_s_fwd": round(cov / t_f / 1e6, 4)}
+    f, b = (op_times or {}).get("gs_env_shade_fwd"), (op_times or {}).get("gs_env_shade_bwd_saved")
+    if f and b:
+        out["gpu_ms_per_view_fwd_bwd"] = [round(f["ms"] / B_local, 4), round(b["ms"] / B_local, 4)]
+    return out
 
 
 def gpu_reference_formulation(trainer):
