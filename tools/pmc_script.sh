@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ / LDS / L1 counters of one kernel run by a small python script (separate rocprofv3 --pmc passes).  GPU box.
-#   usage: tools/pmc_script.sh <tag> <kernel-substring> <script.py> [args]     -> gpurun_out/pmc_<tag>/*.stdout
+#   usage: tools/pmc_script.sh <tag> <kernel-substring[,substring2,...]> <script.py> [args]     -> gpurun_out/pmc_<tag>/*.stdout
 tag="$1"; sub="$2"; shift 2
 root="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 out="$root/gpurun_out/pmc_$tag"; rm -rf "$out"; mkdir -p "$out"
@@ -11,13 +11,15 @@ pass() {
   f=$(find "$out/$p" -name "*counter_collection.csv" | head -1)
   python - "$f" "$sub" > "$out/$p.stdout" <<'PY'
 import csv, sys, collections
-agg = collections.defaultdict(lambda: collections.defaultdict(float))
-for r in csv.DictReader(open(sys.argv[1])):
-    if sys.argv[2] in r["Kernel_Name"]:
-        agg[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
-if agg:
-    d = max(agg)
-    print(d, dict(agg[d]))
+subs = sys.argv[2].split(",")            # several kernels from ONE set of passes: "k_a,k_b" -> one line per kernel, prefixed with its name
+for sub in subs:
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(sys.argv[1])):
+        if sub in r["Kernel_Name"]:
+            agg[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    if agg:
+        d = max(agg)
+        print(*([sub] if len(subs) > 1 else []), d, dict(agg[d]))
 PY
   cat "$out/$p.stdout"
   find "$out/$p" -name "*.csv" -delete
