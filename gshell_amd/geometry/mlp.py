@@ -252,9 +252,11 @@ def _layer_structure(net):
     return lin, len(lin) - 2, skip
 
 
-def pack_weights_h2(net, status=None):
+def pack_weights_h2(net, status=None, out=None):
     """Device buffer in the layout of gs_sdf_mlp_fwd_h2: ONE launch that reads the module's parameters in place.
-    status: optional int32 [2] device tensor (word 0 is raised for a weight beyond the fp16 range)."""
+    status: optional int32 [2] device tensor (word 0 is raised for a weight beyond the fp16 range).
+    out: pack into this int64 buffer instead of a fresh / cached one (tests: a pre-filled buffer shows which words the packer writes -- the section of
+    the kernel variant that is not selected and the staging pad behind the image stay untouched)."""
     import ctypes
     lin, n_hidden, skip = _layer_structure(net)
     # the packed image of the SAME parameter values is reused (an iteration packs for the grid pass, the eikonal term and the row-sparse
@@ -266,13 +268,15 @@ def pack_weights_h2(net, status=None):
     # The cache lives OUTSIDE the module (weak table): copy.deepcopy(net) / state_dict round trips never carry a stale image along.
     key = tuple((p.data_ptr(), p._version) for m in lin for p in (m.weight, m.bias)) + (int(_lib._real_lib_fn().gs_sdf_mlp_h1_impl(c_int(-1))),)          # (the raw library: not an op to be timed)
     cached = _PACKED.get(net)
-    if status is None and cached is not None and cached[0] == key:
+    if status is None and out is None and cached is not None and cached[0] == key:
         return cached[1], n_hidden, skip
     L = _lib.lib()
     nf = net.emb.N_freqs
     dev = lin[0].weight.device
     nbytes = int(L.gs_sdf_mlp_h2_packed_bytes(c_int(nf), c_int(n_hidden), c_int(skip)))
-    packed = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
+    packed = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.int64, device=dev) if out is None else out
+    if packed.numel() * 8 < nbytes or packed.dtype != torch.int64:
+        raise _lib.GShellHipError("pack_weights_h2: `out` must be an int64 buffer of gs_sdf_mlp_h2_packed_bytes bytes")
     ws = [m.weight.detach() for m in lin]
     bs = [m.bias.detach() for m in lin]
     for t in ws + bs:
@@ -282,7 +286,8 @@ def pack_weights_h2(net, status=None):
     with torch.cuda.device(dev):
         check(L.gs_sdf_mlp_h2_pack(PtrArr(*[t.data_ptr() for t in ws]), PtrArr(*[t.data_ptr() for t in bs]), c_int(nf), c_int(n_hidden), c_int(skip),
                                    ptr(packed), ptr(status), stream()), "gs_sdf_mlp_h2_pack")
-    _PACKED[net] = (key, packed)
+    if out is None:
+        _PACKED[net] = (key, packed)
     return packed, n_hidden, skip
 
 

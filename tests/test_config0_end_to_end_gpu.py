@@ -240,8 +240,9 @@ def _tick_chain_body(kind, res, iteration, seed, flag_overrides, textured, B, n,
     assert n_cov > (3000 if frame >= 256 else 1500)
     # samples placed / shadowed differently per sample: 9e-6 against the reference kernel on IDENTICAL g-buffers (tests/test_ray_stage_fullsize_
     # parity_gpu.py); here each side shades its own g-buffer (normals from float-atomic sums; with the hash-grid texture also kd / ks, which
-    # steer the lobe choice of every BSDF sample, from two float32 evaluations of the field): up to 3e-5
-    max_roots = 1 + int((3e-5 if textured else 1e-5) * n_cov * 2 * n * n)
+    # steer the lobe choice of every BSDF sample, from two float32 evaluations of the field): measured 2.5e-5 at configs[1]'s real size with the
+    # 16-level texture (60 footprints in 2.4 10^6 samples; 18 with 6 levels); the cap leaves 1.8 x for the run-to-run part (atomic order of the normals)
+    max_roots = 1 + int((4.5e-5 if textured else 1e-5) * n_cov * 2 * n * n)
     R = int(np.ceil(2.5 * sigma))                       # the bilateral filter's radius: one differently placed sample reaches (2R+1)^2 pixels
     failures, all_roots = [], []
     for key in out:
