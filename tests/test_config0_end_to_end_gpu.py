@@ -268,6 +268,28 @@ def _tick_chain_body(kind, res, iteration, seed, flag_overrides, textured, B, n,
             all_roots += [r for r in roots if r[:3] not in [q[:3] for q in all_roots]]
         if len(roots) > max_roots or (key not in ('shaded', 'diffuse_light', 'specular_light') and int(bad.sum()) > 2 * max_roots):
             failures.append(key)
+    # ---- informational: the same comparison WITHOUT the substitution -- each chain renders its OWN vertices, which differ by
+    # the float32 round-off of two SDF evaluations (dv above): what the extraction <-> render coupling costs when it is not taken out.  Forward
+    # only, small configs only (one more oracle render), never fails the test.
+    if res <= 64:
+        try:
+            with torch.no_grad():
+                v_own, m_own = ex['verts_aug'].detach(), ex['msdf'].detach()
+                own = pl.render_mesh(v_own, f, po.auto_normals(v_own, f), m_own, target['mvp'].cpu(), target['campos'].cpu(), light.detach(), target['background'].cpu(),
+                                     noise, tex_oracle, n, seed, shadow, perms.numpy(), bsdf='pbr', denoise_sigma=sigma, resolution=(H, W),
+                                     xfm=ro_mod.xfm_points_kernel_order)
+            cnt = []
+            for key in own:
+                if key == 'visible_triangles':
+                    continue
+                a, b = bufs[key].detach().cpu(), own[key].detach()
+                sc = float(b.abs().max()) or 1.0
+                cnt.append(f"{key} {int((((a - b).abs() - 1e-4 * b.abs()).amax(-1) / sc > 1e-4).sum())}")
+            same_vis = torch.equal(bufs['visible_triangles'].cpu(), own['visible_triangles'])
+            print(f"  WITHOUT the straight-through substitution (own vertices, max |dv| {dv:.1e}): pixels outside 1e-4: " + ", ".join(cnt)
+                  + f"; visible-triangle list {'identical' if same_vis else 'differs'}")
+        except Exception as e:                                   # pragma: no cover
+            print(f"  (informational run without the substitution did not complete: {type(e).__name__}: {e})")
     assert not failures, failures
 
     # ---- losses
