@@ -87,6 +87,7 @@ class CoveredPixels:
     place (its mask-dependent launches); here the request is issued right after rasterisation, so that by the time the shader asks, the count has
     long arrived and the host never drains the queue (the GPU used to idle ~100 us behind that read-back: profiles/r04_gpu_gaps.txt)."""
     _pinned = {}
+    RING = 8
 
     def __init__(self, rast):
         L = _lib.lib()
@@ -101,16 +102,20 @@ class CoveredPixels:
         with torch.cuda.device(dev):
             check(L.gs_compact_rows_strided(c_void_p(rast.data_ptr() + 12), c_int64(4), c_int64(n), c_int64(n), ptr(scratch), ptr(self.rows), c_void_p(0),
                                             ptr(self.count_dev), stream()), "gs_compact_rows_strided")
-            host = CoveredPixels._pinned.get(str(dev))
-            if host is None:
-                host = CoveredPixels._pinned[str(dev)] = torch.zeros(2, dtype=torch.int64).pin_memory()
-            self.count_host = host
-            host.copy_(self.count_dev, non_blocking=True)
+            # a ring of pinned count words per device: a request that is still unread when the next one is issued keeps its own word
+            ring = CoveredPixels._pinned.get(str(dev))
+            if ring is None:
+                ring = CoveredPixels._pinned[str(dev)] = [torch.zeros(CoveredPixels.RING, 2, dtype=torch.int64).pin_memory(), 0]
+            self.count_host = ring[0][ring[1] % CoveredPixels.RING]
+            ring[1] += 1
+            self.count_host.copy_(self.count_dev, non_blocking=True)
             self.event = torch.cuda.Event()
             self.event.record()
 
     def matches(self, mask, dims):
-        return (mask.data_ptr() == self.key[0] + 12 and tuple(dims) == self.key[2] and mask.dim() == 3 and mask.stride() == (dims[1] * dims[2] * 4, dims[2] * 4, 4))
+        """`mask` is channel 3 of the very tensor the request was made for, unmodified since (same storage, same version counter)"""
+        return (mask.data_ptr() == self.key[0] + 12 and mask._version == self.key[1] and tuple(dims) == self.key[2] and mask.dim() == 3
+                and mask.stride() == (dims[1] * dims[2] * 4, dims[2] * 4, 4))
 
     def resolve(self):
         self.event.synchronize()

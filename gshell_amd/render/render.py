@@ -424,12 +424,14 @@ def render_mesh(FLAGS, ctx, mesh, mtx_in, view_pos, lgt, resolution, spp=1, num_
 
     v_pos_clip = ru.xfm_points(mesh.v_pos[None, ...], mtx_in)
     rast, db, vis = dr.rasterize(ctx, v_pos_clip, tri, full_res, return_visible=True)
-    if spp == 1 and optix_ctx is not None and rast.is_cuda and getattr(FLAGS, "async_pixel_list", True):
-        # the shader's covered-pixel list: requested now, its count read ~0.5 ms of queued work later (optixutils.CoveredPixels)
-        ou.PENDING_PIXELS = ou.CoveredPixels(rast)
+    # the shader's covered-pixel list: requested now, its count read ~0.5 ms of queued work later (optixutils.CoveredPixels).  The request belongs to
+    # THIS frame: an unconsumed one of an earlier frame (a render that never shaded) is dropped here, and ours below once the layer is rendered --
+    # the caching allocator hands the next frame's `rast` the same address, so a stale request must never outlive its frame
+    ou.PENDING_PIXELS = ou.CoveredPixels(rast) if (spp == 1 and optix_ctx is not None and rast.is_cuda and getattr(FLAGS, "async_pixel_list", True)) else None
 
     buffers = render_layer(FLAGS, v_pos_clip, rast, db, mesh, view_pos, lgt, resolution, spp, msaa, optix_ctx, bsdf, denoiser, shadow_scale,
                            use_uv=use_uv, finetune_normal=finetune_normal, extra_dict=extra_dict, xfm_lgt=xfm_lgt, shade_data=shade_data, _defer=True)
+    ou.PENDING_PIXELS = None         # (the shader has run inside render_layer: consumed, or never needed)
 
     if background is not None:
         if spp > 1:
