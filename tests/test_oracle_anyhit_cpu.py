@@ -117,6 +117,47 @@ def test_grid_equals_every_triangle_on_surface_start_rays_against_a_thin_shell()
     np.testing.assert_array_equal(so.any_hit_c(o2, d2, verts, tris, grid=True), so.any_hit_c(o2, d2, verts, tris, grid=False))
 
 
+def test_grid_equals_every_triangle_on_the_mesh_of_a_real_extraction():
+    """the geometry of the config-size GPU tests, made on the CPU: the OPEN surface G-MarchingTets extracts from the suite's "skirt" field with the
+    "wavy" mSDF cut (oracle/mtets_oracle on BCC 26: ~10^4 triangles incl. the slivers and the cut boundary a marching scheme produces, which
+    the lat-long shell above does not have), rays from 1e-3 above and below the surface, cosine-distributed + grazing + into the surface."""
+    import torch
+    from gshell_amd import grid as ggrid
+    from oracle import fields, mtets_oracle
+    gv, tets = ggrid.bcc_grid(26)
+    vn_ = gv.numpy()
+    ex = mtets_oracle.extract(torch.tensor(vn_), torch.tensor(fields.make_sdf(vn_, "skirt", 3)), torch.tensor(fields.make_msdf(vn_, "wavy", 3)), tets, with_tangents=False)
+    verts = (ex["verts_aug"].detach().numpy() * 2.0).astype(f32)
+    tris = ex["faces_aug"].numpy().astype(np.int32)
+    assert 8000 < len(tris) < 13000
+    rng = np.random.default_rng(9)
+    pick = rng.integers(0, len(tris), 40000)
+    t = verts[tris[pick]]
+    w = rng.dirichlet((1, 1, 1), len(pick)).astype(f32)
+    p = (t * w[..., None]).sum(1)
+    n = np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0])
+    ok = np.linalg.norm(n, axis=1) > 0                                    # (exact-zero slivers have no normal: start those rays along x)
+    n[~ok] = [1.0, 0.0, 0.0]
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    n *= np.where(rng.random(len(n)) < 0.5, 1.0, -1.0)[:, None].astype(f32)  # an open surface is seen from both sides
+    org = (p + n * f32(0.001)).astype(f32)
+    d = rng.normal(size=p.shape).astype(f32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    flip = (d * n).sum(1) < 0
+    d[flip & (np.arange(len(d)) % 16 != 0)] *= -1                        # 1 in 32 goes into the surface
+    graze = np.arange(len(d)) % 5 == 0                                    # every fifth ray nearly tangent to its own triangle
+    d[graze] = d[graze] - n[graze] * (d[graze] * n[graze]).sum(1, keepdims=True) * f32(0.98)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    st_b, st_g = {}, {}
+    brute = so.any_hit_c(org, d.astype(f32), verts, tris, grid=False, stats=st_b)
+    grid = so.any_hit_c(org, d.astype(f32), verts, tris, grid=True, stats=st_g)
+    assert 0.02 < brute.mean() < 0.9, brute.mean()
+    np.testing.assert_array_equal(grid, brute)
+    assert st_g["tests"] < 0.05 * st_b["tests"]
+    o2, d2 = _special_rays(verts, tris, 8)
+    np.testing.assert_array_equal(so.any_hit_c(o2, d2, verts, tris, grid=True), so.any_hit_c(o2, d2, verts, tris, grid=False))
+
+
 @pytest.mark.parametrize("name", ["ref_envshade_pbr_n4.npz", "ref_envshade_pbr_n8_64x64.npz", "ref_envshade_pbr_n4_occluder.npz", "ref_envshade_white_n8.npz"])
 def test_checker_reproduces_the_visibility_column_of_the_goldens(name):
     """every sample record of the golden (direction + the any-hit outcome kernel.cu's shadow_test saw in the host build, minted with the
