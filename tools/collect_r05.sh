@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-5 evidence in ONE GPU call -> gpurun_out/r05/ ; tools/assemble_r05.py then writes profiles/r05_* from it (stamped with the commit).  GPU box.
-# Everything is collected at the SAME commit: bench line, per-op HIP-event times, rocprofv3 kernel stats, torch-issued kernels, idle gaps,
+# Round-5 evidence in ONE GPU call -> gpurun_out/r05/ ; tools/assemble_r05.py then writes profiles/r05_* from it (stamped with the source hash of the tree: bench.source_hash()).  GPU box.
+# Everything is collected on the SAME tree: bench line, per-op HIP-event times, rocprofv3 kernel stats, torch-issued kernels, idle gaps,
 # SQ counters of k_shade_trace / k_h1_fwd / the chain kernels, FETCH_SIZE / WRITE_SIZE of the five roofline families (separate --pmc passes,
 # --kernel-trace only), and the complete pixel-parity log at 512^2.
 root="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
