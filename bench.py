@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--set", action="append", default=[], metavar="FLAG=VALUE", help="override a training flag (python literal), e.g. --set eikonal_side_stream=False")
     ap.add_argument("--state-file", default=None, help="save the fitted set-up state here / load it if the file exists (profiling runs skip the set-up kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-config", action="store_true", help="skip the side record at the reference's own default workload (2 x 1024^2, n_samples 24)")
     ap.add_argument("--variant-ok", action="store_true", help="measure a library built with non-default compile-time variants (GSHELL_HIP_LIB=...; the line then carries "
                     "`build_flags` and is not a headline)")
     ap.add_argument("--op-times", action="store_true", help="also print per-op HIP-event times (adds sync points)")
@@ -192,6 +193,14 @@ def main():
             side["configs3_global_batch_8"] = {"ms_per_step": round(dt3 / a.extra_steps * 1e3, 3), "value": round(8 * H * W * a.extra_steps / dt3 / 1e6, 4),
                                                "iters_per_sec": round(a.extra_steps / dt3, 4), "scaling": "strong", "global_batch": 8, "views_per_gpu": 1, "steps": a.extra_steps,
                                                "what": f"BASELINE.json configs[3] partitioning: tet-res{a.res}, global batch 8 over 8 GPUs, 1 view of {H}^2 per GPU"}
+    if a.extra_steps > 0 and world == 1 and a.geometry == "tets" and a.res == 256 and not a.no_reference_config:
+        # (4) the reference's OWN published workload (configs/deepfashion_mc_256.json:7-8,17,19): batch 2 x 1024^2, n_samples 24 (1152 shadow rays per
+        # covered pixel and pass, kernel.cu:490-529), grid 256 -- on the same trainer / mesh, steady-state schedule
+        try:
+            side["reference_config"] = reference_config_run(trainer, timed, a, shard)
+        except Exception as e:           # pragma: no cover
+            side["reference_config"] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
     if _mlp.FALLBACKS:
         raise SystemExit(f"bench.py: the SDF network left the HIP kernels during the run ({_mlp.FALLBACKS}); no number is reported for a torch path")
     if rank == 0:
@@ -257,7 +266,49 @@ def main():
         dist.destroy_process_group()
 
 
-ROOFLINE_CANDIDATES = {"gs_env_shade_fwd", "gs_sdf_mlp_fwd_h1", "gs_sdf_mlp_fwd_h2", "gs_sdf_mlp_fwd", "gs_sdf_mlp_h2_refine_rows", "gs_mtets_flag_refine_rows",
+def reference_config_run(trainer, timed, a, shard, res=1024, views=2, n=24):
+    """One side record: the reference's default workload (configs/deepfashion_mc_256.json: batch 2, train_res 1024 x 1024, n_samples 24) on this
+    trainer.  The shader's per-sample records (40 B per ray) would be ~14 GB at this size: they go through ONE scratch of optixutils.SCRATCH_BOUND
+    bytes in chunks of covered pixels (bit-identical results, tests/test_shade_gpu.py), the backward replays the sampler from the cached visibility
+    bits.  `unbounded`: the same frames with the records kept (the path of the headline size), for the price of the bound."""
+    from gshell_amd import workload
+    from gshell_amd.render import optixutils as ou
+    F = trainer.FLAGS
+    old = (F.n_samples, list(F.train_res), F.batch)
+    out = {"workload": f"reference configs/deepfashion_mc_256.json: tet-res256, batch {views} x {res}x{res}, n_samples={n} ({2 * n * n} shadow rays/px/pass)", "steps": a.extra_steps}
+    try:
+        F.n_samples, F.train_res, F.batch = n, [res, res], views
+        tg = [workload.make_targets(trainer, [(it * views + v) % 72 for v in shard.local_views(views)], (res, res), radius=a.camera_radius) for it in range(2)]
+        for tag, bound in (("bounded", ou.SCRATCH_BOUND), ("unbounded", None)):
+            keep, ou.SCRATCH_BOUND = ou.SCRATCH_BOUND, bound
+            try:
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                torch.cuda.reset_peak_memory_stats()
+                timed(a.schedule_it, 3, 1, tgts=tg, gb=views)                    # first-size allocations settle
+                dt, _ = timed(a.schedule_it + 4, 0, a.extra_steps, tgts=tg, gb=views)
+                cov = ou.last_covered_pixels
+                rec = {"ms_per_step": round(dt / a.extra_steps * 1e3, 3), "value": round(views * res * res * a.extra_steps / dt / 1e6, 4), "unit": "Mpixels/s",
+                       "iters_per_sec": round(a.extra_steps / dt, 4), "covered_pixels": cov, "coverage": None if cov is None else round(cov / (views * res * res), 4),
+                       "shadow_rays_per_pass": None if cov is None else cov * 2 * n * n, "sample_record_bytes_unbounded": None if cov is None else cov * 2 * n * n * 40,
+                       "scratch_bound_bytes": bound, "took_bounded_path": bool(ou.last_bounded),
+                       "peak_torch_allocated_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 3), "peak_torch_reserved_GB": round(torch.cuda.max_memory_reserved() / 2 ** 30, 3),
+                       "bvh_bytes": int(trainer.geometry.optix_ctx.info().get("bytes", 0))}
+                if tag == "bounded":
+                    out.update(rec)
+                else:
+                    out["unbounded"] = rec
+            except Exception as e:       # pragma: no cover
+                (out if tag == "bounded" else out.setdefault("unbounded", {}))["error"] = f"{type(e).__name__}: {e}"
+            finally:
+                ou.SCRATCH_BOUND = keep
+    finally:
+        F.n_samples, F.train_res, F.batch = old
+        ou.random_perm(old[0], trainer.geometry.verts.device)
+    return out
+
+
+ROOFLINE_CANDIDATES = {"gs_env_shade_fwd", "gs_env_shade_fwd_bounded", "gs_env_shade_bwd", "gs_sdf_mlp_fwd_h1", "gs_sdf_mlp_fwd_h2", "gs_sdf_mlp_fwd", "gs_sdf_mlp_h2_refine_rows", "gs_mtets_flag_refine_rows",
                        "gs_env_shade_bwd_saved", "gs_hashgrid_encode_bwd", "gs_hashgrid_encode_bwd_binned", "gs_sdf_mlp_h2_wgrad", "gs_sdf_mlp_h2_bwd",
                        "gs_sdf_mlp_h2_save_fwd", "gs_sdf_eikonal_rr_fwd", "gs_sdf_eikonal_rr_bwd", "gs_flexi_vd_bwd", "gs_flexi_vd_fwd"}
 

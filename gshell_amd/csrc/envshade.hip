@@ -1237,32 +1237,66 @@ extern "C" int64_t gs_env_shade_scratch_bytes(int64_t n_cov, int n_samples_x) {
     return n_cov * 2 * n_samples_x * n_samples_x * (int64_t)(4 + 6) * 4 + 256;
 }
 
-extern "C" int gs_env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* ro, const float* gb_pos, const float* gb_normal,
-                                const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
-                                const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
-                                int64_t H, int64_t W, int64_t view_offset, int64_t view_stride, int bsdf, int n_samples_x, uint32_t rnd_seed,
-                                float shadow_scale, void* scratch, uint64_t* vis_bits, float* diff, float* spec, gs_stream_t stream_) {
+// Forward pass over the covered pixels in CHUNKS whose per-sample records (40 B per ray) fit `scratch_bytes` (< 0: one chunk).  Every pixel's
+// samples, shadow rays and sums are independent of its neighbours in the list (the RNG hashes the GLOBAL pixel index, a ray's visibility bit does
+// not depend on which rays travel with it), so the outputs are bit-identical for every chunk size; a chunk is a multiple of 64 pixels, which keeps
+// its visibility bits on whole words of `vis_bits`.  With more than one chunk the records of all but the last are gone afterwards: the caller
+// back-propagates with gs_env_shade_bwd (sampler replay from the cached bits), not gs_env_shade_bwd_saved.
+static int env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* ro, const float* gb_pos, const float* gb_normal,
+                         const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
+                         const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
+                         int64_t H, int64_t W, int64_t view_offset, int64_t view_stride, int bsdf, int n_samples_x, uint32_t rnd_seed,
+                         float shadow_scale, void* scratch, int64_t scratch_bytes, uint64_t* vis_bits, float* diff, float* spec, gs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (B * H * W == 0) return 0;
     if (diff) GS_HIP_CHECK(hipMemsetAsync(diff, 0, (size_t)B * H * W * 12, stream));
     if (spec) GS_HIP_CHECK(hipMemsetAsync(spec, 0, (size_t)B * H * W * 12, stream));
     if (n_cov == 0) return 0;
     GS_REQUIRE(scratch != nullptr, "gs_env_shade_fwd: null scratch");
-    ShadeArgs A{};
-    int rc = fill_args(A, bvh, pix, n_cov, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl, perms, P, B, H, W, view_offset,
-                       view_stride, bsdf, n_samples_x, rnd_seed, shadow_scale, vis_bits);
-    if (rc) return rc;
-    const int64_t S2 = 2ll * n_samples_x * n_samples_x, n_rays = n_cov * S2;
-    A.ray_dk = (float4*)scratch;
-    A.ray_contrib = (float*)(A.ray_dk + n_rays);
-    A.diff = diff;
-    A.spec = spec;
-    int64_t lanes = n_cov * A.G;
-    hipLaunchKernelGGL(k_shade_samples<false>, dim3((unsigned)gs::cdiv(lanes, 256)), dim3(256), 0, stream, A);
-    hipLaunchKernelGGL(k_shade_trace, dim3((unsigned)gs::cdiv(n_rays, TRACE_WAVES * TRACE_CHUNK)), dim3(TRACE_NT), 0, stream, A, n_rays, (int)S2);
-    if (diff && spec) hipLaunchKernelGGL(k_shade_accumulate, dim3((unsigned)gs::cdiv(lanes, 256)), dim3(256), 0, stream, A);
-    GS_LAUNCH_CHECK();
+    const int64_t S2 = 2ll * n_samples_x * n_samples_x;
+    int64_t chunk = n_cov;
+    if (scratch_bytes >= 0 && scratch_bytes < gs_env_shade_scratch_bytes(n_cov, n_samples_x)) {
+        chunk = (scratch_bytes - 256) / (S2 * 40) / 64 * 64;
+        GS_REQUIRE(chunk >= 64, "gs_env_shade_fwd_bounded: the scratch does not hold the records of 64 pixels");
+    }
+    for (int64_t off = 0; off < n_cov; off += chunk) {
+        const int64_t cnt = n_cov - off < chunk ? n_cov - off : chunk;
+        ShadeArgs A{};
+        int rc = fill_args(A, bvh, pix + off, cnt, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl, perms, P, B, H, W, view_offset,
+                           view_stride, bsdf, n_samples_x, rnd_seed, shadow_scale, vis_bits + off * S2 / 64);
+        if (rc) return rc;
+        const int64_t n_rays = cnt * S2;
+        A.ray_dk = (float4*)scratch;
+        A.ray_contrib = (float*)(A.ray_dk + n_rays);
+        A.diff = diff;
+        A.spec = spec;
+        int64_t lanes = cnt * A.G;
+        hipLaunchKernelGGL(k_shade_samples<false>, dim3((unsigned)gs::cdiv(lanes, 256)), dim3(256), 0, stream, A);
+        hipLaunchKernelGGL(k_shade_trace, dim3((unsigned)gs::cdiv(n_rays, TRACE_WAVES * TRACE_CHUNK)), dim3(TRACE_NT), 0, stream, A, n_rays, (int)S2);
+        if (diff && spec) hipLaunchKernelGGL(k_shade_accumulate, dim3((unsigned)gs::cdiv(lanes, 256)), dim3(256), 0, stream, A);
+        GS_LAUNCH_CHECK();
+    }
     return 0;
+}
+
+extern "C" int gs_env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* ro, const float* gb_pos, const float* gb_normal,
+                                const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
+                                const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
+                                int64_t H, int64_t W, int64_t view_offset, int64_t view_stride, int bsdf, int n_samples_x, uint32_t rnd_seed,
+                                float shadow_scale, void* scratch, uint64_t* vis_bits, float* diff, float* spec, gs_stream_t stream_) {
+    return env_shade_fwd(bvh, pix, n_cov, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl, perms, P, B, H, W, view_offset,
+                         view_stride, bsdf, n_samples_x, rnd_seed, shadow_scale, scratch, -1, vis_bits, diff, spec, stream_);
+}
+
+extern "C" int gs_env_shade_fwd_bounded(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* ro, const float* gb_pos, const float* gb_normal,
+                                        const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
+                                        const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
+                                        int64_t H, int64_t W, int64_t view_offset, int64_t view_stride, int bsdf, int n_samples_x, uint32_t rnd_seed,
+                                        float shadow_scale, void* scratch, int64_t scratch_bytes, uint64_t* vis_bits, float* diff, float* spec,
+                                        gs_stream_t stream_) {
+    GS_REQUIRE(scratch_bytes >= 0, "gs_env_shade_fwd_bounded: negative scratch size");
+    return env_shade_fwd(bvh, pix, n_cov, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl, perms, P, B, H, W, view_offset,
+                         view_stride, bsdf, n_samples_x, rnd_seed, shadow_scale, scratch, scratch_bytes, vis_bits, diff, spec, stream_);
 }
 
 static int env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* gb_pos, const float* gb_normal,

@@ -127,6 +127,11 @@ last_covered_pixels = None      # covered pixels of the last optix_env_shade cal
 SAVED_SAMPLES = True      # backward from the forward pass's saved ray buffer (gs_env_shade_bwd_saved) instead of replaying the sampler.
                           # The buffer (40 B per ray: ~0.8 GB at 4 x 512^2, n = 8, 15 % coverage) stays alive from forward to backward;
                           # the first backward overwrites it in place, a second one (retain_graph) replays the sampler instead.
+SCRATCH_BOUND = 2 << 30    # bytes of per-sample records one env-shade call may hold.  A frame above it (the reference's default workload,
+                          # configs/deepfashion_mc_256.json: 2 x 1024^2, n_samples 24 -> 1152 rays per covered pixel, ~14 GB of records) is shaded
+                          # in chunks of covered pixels through one scratch of this size (gs_env_shade_fwd_bounded: bit-identical outputs) and
+                          # back-propagated by sampler replay from the cached visibility bits (gs_env_shade_bwd) -- no records kept.
+last_bounded = False       # whether the last forward call took the bounded path (bench.py / tests)
 
 
 class _optix_env_shade_func(torch.autograd.Function):
@@ -135,7 +140,21 @@ class _optix_env_shade_func(torch.autograd.Function):
         L = _lib.lib()
         B, H, W = dims
         n_cov = pix.shape[0]
-        scratch = torch.empty((max(int(L.gs_env_shade_scratch_bytes(c_int64(n_cov), c_int(n))), 8) + 7) // 8, dtype=torch.int64, device=pix.device)
+        need = max(int(L.gs_env_shade_scratch_bytes(c_int64(n_cov), c_int(n))), 8)
+        global last_bounded
+        last_bounded = SCRATCH_BOUND is not None and need > SCRATCH_BOUND
+        if last_bounded:
+            # chunks of covered pixels through ONE scratch of SCRATCH_BOUND bytes; the records do not survive the call (-> None: replay backward)
+            min_bytes = 64 * 2 * n * n * 40 + 256
+            nbytes = max(int(SCRATCH_BOUND), min_bytes)
+            scratch = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=pix.device)
+            check(L.gs_env_shade_fwd_bounded(optix_ctx.handle, ptr(pix, torch.int32), c_int64(n_cov), ptr(t["ro"]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view),
+                                             t["kd_ptr"], t["ks_ptr"], ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]), c_int64(lgt.shape[1]),
+                                             ptr(perms, torch.int32), c_int64(perms.shape[0]), c_int64(B), c_int64(H), c_int64(W), c_int64(view_map[0]),
+                                             c_int64(view_map[1]), c_int(BSDF), c_int(n), c_uint32(seed & 0xFFFFFFFF), c_float(shadow_scale), ptr(scratch),
+                                             c_int64(nbytes), ptr(vis), ptr(diff), ptr(spec), stream()), "gs_env_shade_fwd_bounded")
+            return None
+        scratch = torch.empty((need + 7) // 8, dtype=torch.int64, device=pix.device)
         check(L.gs_env_shade_fwd(optix_ctx.handle, ptr(pix, torch.int32), c_int64(n_cov), ptr(t["ro"]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view),
                                  t["kd_ptr"], t["ks_ptr"], ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]), c_int64(lgt.shape[1]),
                                  ptr(perms, torch.int32), c_int64(perms.shape[0]), c_int64(B), c_int64(H), c_int64(W), c_int64(view_map[0]), c_int64(view_map[1]),
@@ -272,9 +291,14 @@ def optix_env_shade_samples(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos,
     S = n_samples_x * n_samples_x
     n_cov = int(pix.shape[0])
     vis = torch.zeros((int(L.gs_env_shade_vis_words(c_int64(n_cov), c_int(n_samples_x))),), dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
-        scratch = _optix_env_shade_func._launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, _BSDF_IDS.index(BSDF), n_samples_x,
-                                                    int(rnd_seed), shadow_scale, (B, H, W), vis, None, None, (int(view_offset), int(view_stride)))
+    global SCRATCH_BOUND
+    bound, SCRATCH_BOUND = SCRATCH_BOUND, None          # the records of EVERY pixel are what this call returns
+    try:
+        with torch.cuda.device(dev):
+            scratch = _optix_env_shade_func._launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, _BSDF_IDS.index(BSDF), n_samples_x,
+                                                        int(rnd_seed), shadow_scale, (B, H, W), vis, None, None, (int(view_offset), int(view_stride)))
+    finally:
+        SCRATCH_BOUND = bound
     dk = scratch.view(torch.float32)[: n_cov * 2 * S * 4].reshape(n_cov, 2, S, 4)
     bits = (vis[:, None] >> torch.arange(64, device=dev)[None, :]) & 1
     visible = bits.reshape(-1)[: n_cov * 2 * S].reshape(n_cov, 2, S).bool()

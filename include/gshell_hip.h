@@ -350,6 +350,21 @@ int gs_env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const
                      int64_t view_offset, int64_t view_stride, int bsdf,
                      int n_samples_x, uint32_t rnd_seed, float shadow_scale, void* scratch,
                      uint64_t* vis_bits, float* diff, float* spec, gs_stream_t stream);
+/* gs_env_shade_fwd with a BOUNDED scratch: the covered pixels are shaded in chunks (multiples of 64 pixels) whose per-sample records
+ * (40 B per ray) fit `scratch_bytes`; outputs and vis_bits are bit-identical to gs_env_shade_fwd for every bound (each pixel's samples hash its
+ * GLOBAL index, a ray's visibility does not depend on its batch).  For frames whose records would not fit a fixed budget -- the reference's
+ * own default workload, configs/deepfashion_mc_256.json:7-8,17 (2 x 1024^2, n_samples 24: 1152 rays per covered pixel, kernel.cu:490-529) needs
+ * ~14 GB of them.  After a call that took more than one chunk only the last chunk's records exist: back-propagate with gs_env_shade_bwd
+ * (sampler replay from the cached bits), not gs_env_shade_bwd_saved. */
+int gs_env_shade_fwd_bounded(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* ro,
+                             const float* gb_pos, const float* gb_normal, const float* view_pos,
+                             const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
+                             const float* rows, const float* cols, int64_t Hl, int64_t Wl,
+                             const int32_t* perms, int64_t P, int64_t B, int64_t H, int64_t W,
+                             int64_t view_offset, int64_t view_stride, int bsdf,
+                             int n_samples_x, uint32_t rnd_seed, float shadow_scale, void* scratch,
+                             int64_t scratch_bytes, uint64_t* vis_bits, float* diff, float* spec,
+                             gs_stream_t stream);
 int gs_env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* gb_pos,
                      const float* gb_normal, const float* view_pos, const float* gb_kd,
                      const float* gb_ks, const float* light, const float* pdf, const float* rows,

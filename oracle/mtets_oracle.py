@@ -76,7 +76,7 @@ def extract(pos, sdf, msdf, tets, topo=None, with_tangents=True):
         topo = build_topology(tets)
     edges, tet_edge = topo["edges"], topo["tet_edge"]
     dev = pos.device       # the restatement is plain torch: it also runs on the GPU box at the full BASELINE grid sizes
-    sdf = sdf.float().reshape(-1)
+    sdf = (sdf if sdf.dtype == torch.float64 else sdf.float()).reshape(-1)     # float64: the arbiter runs of oracle/make_golden_chain.py
     msdf = msdf.reshape(-1)
     F = tets.shape[0]
     occ = sdf > 0                                                   # ref :250 (strict)

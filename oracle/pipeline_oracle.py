@@ -26,6 +26,16 @@ class TextureOracle:
     def __init__(self, aabb, cfg, params, weights, mn, mx):
         self.aabb, self.cfg, self.params, self.weights, self.mn, self.mx = aabb, cfg, params, weights, mn, mx
 
+    def sample_covered(self, texc, covered):
+        """`sample` on the covered pixels only, zeros elsewhere.  The reference evaluates the field on every pixel and the composite then discards
+        the background ones (render.py:352-359: lerp(bg, fg, mask * alpha) with mask = 0 there), so values and gradients of everything the
+        frame shows are the same; what it saves is 6/7 of the hash-grid oracle's memory at the config-size frames (oracle/make_golden_chain.py)."""
+        rows = torch.nonzero(covered.reshape(-1)).reshape(-1)
+        flat = texc.reshape(-1, 3)
+        val = self.sample(flat[rows])
+        out = torch.zeros(flat.shape[0], val.shape[-1], dtype=val.dtype).index_put((rows,), val)
+        return out.reshape(*texc.shape[:-1], -1)
+
     def sample(self, texc):
         x = (texc.reshape(-1, 3) - self.aabb[0][None]) / (self.aabb[1][None] - self.aabb[0][None])
         h = ho.encode(torch.clamp(x, 0, 1), self.params, *self.cfg)
@@ -49,7 +59,7 @@ class ConstantTextureOracle:
 
 
 def render_mesh(v_pos, faces, v_nrm, msdf, mvp, campos, light, background, noise, texture, n_samples, seed, shadow_scale, perms, bsdf='pbr',
-                denoise_sigma=None, resolution=(32, 32), xfm=None):
+                denoise_sigma=None, resolution=(32, 32), xfm=None, covered_texture=False):
     """All tensors torch CPU float32.  faces [T,3] long.  noise = {'jitter','texture','tangent'} as drawn by the product.
     Returns the dict of composited + antialiased buffers (same keys as the reference).
     xfm: the point transform -- default raster_oracle.xfm_points (the reference's python branch, a matmul); the config-size chains pass
@@ -82,8 +92,12 @@ def render_mesh(v_pos, faces, v_nrm, msdf, mvp, campos, light, background, noise
     jitter = po.pixel_grid(W, H)[None] + noise['jitter']
     mask = (rast[..., -1:] > 0).to(rast.dtype)
     grad_weight = mask * po.texture_linear_clamp(mask, jitter)
-    all_jit = texture.sample(gb_pos + noise['texture'])
-    all_tex = texture.sample(gb_pos)
+    if covered_texture and hasattr(texture, 'sample_covered'):
+        all_jit = texture.sample_covered(gb_pos + noise['texture'], covered)
+        all_tex = texture.sample_covered(gb_pos, covered)
+    else:
+        all_jit = texture.sample(gb_pos + noise['texture'])
+        all_tex = texture.sample(gb_pos)
     kd, ks = all_tex[..., 0:3], all_tex[..., 3:6]
     kd_grad = (all_jit[..., 0:3] - kd).abs()
     ks_grad = (all_jit[..., 3:6] - ks).abs() * torch.tensor([0.0, 1.0, 1.0])

@@ -347,6 +347,10 @@ def pbr_specular(col, nrm, wo, wi, alpha, min_roughness=0.08):
     return torch.where(front, w, torch.zeros_like(w))
 
 
+DECISION_PIN = None      # {'mode': 'record' | 'replay', 'calls': [...]}: see env_shade
+CHECKPOINT = False       # activation checkpointing of the per-sample graphs of env_shade / the per-row graphs of bilateral (memory, not arithmetic)
+
+
 def env_shade(mask, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, perms, bsdf, n, seed, shadow_scale, verts, tris):
     """All image tensors torch [B,H,W,C] float32 (view_pos [B,1,1,3]); light [Hl,Wl,3]; pdf [Hl,Wl]; rows [Hl]; cols [Hl,Wl];
     perms [P, n*n] int; verts / tris = occluder mesh (numpy).  -> diff, spec [B,H,W,3] (differentiable)."""
@@ -367,6 +371,14 @@ def env_shade(mask, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, r
     view = view_pos.expand(B, H, W, 3).reshape(-1, 3)[pix]
     # numpy copies for the (non-differentiated) sampling decisions
     npos, nnrm, nkd, nks, nview = (x.detach().numpy().astype(f32) for x in (pos, nrm, kd, ks, view))
+    ro_n = ro_s.detach().numpy().astype(f32)
+    if DECISION_PIN is not None:
+        # float64 arbiter runs (oracle/make_golden_chain.py): sample placement, lobe choice and shadow rays are decided from the float32
+        # run's inputs, so the two runs evaluate the SAME samples and differ by arithmetic only
+        if DECISION_PIN["mode"] == "record":
+            DECISION_PIN["calls"].append((npos, nnrm, nkd, nks, nview, ro_n))
+        else:
+            npos, nnrm, nkd, nks, nview, ro_n = DECISION_PIN["calls"].pop(0)
     npdf, nrows, ncols = pdf.numpy().astype(f32), rows.numpy().astype(f32), cols.numpy().astype(f32)
     alpha_n = nks[:, 1] * nks[:, 1]
     wo_n = _normalize(nview - npos)
@@ -400,23 +412,30 @@ def env_shade(mask, ro, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, r
     Hl, Wl = npdf.shape
     acc_d, acc_s = torch.zeros(P, 3, dtype=dt), torch.zeros(P, 3, dtype=dt)
 
-    def process(dirs, pdf_sum):
-        u, v = _dir_to_tc(dirs)
-        lx = np.clip((u * f32(Wl)).astype(np.int64), 0, Wl - 1)
-        ly = np.clip((v * f32(Hl)).astype(np.int64), 0, Hl - 1)
-        light_col = light[torch.as_tensor(ly), torch.as_tensor(lx)]
-        mis = torch.as_tensor((f32(1.0) / np.maximum(pdf_sum, f32(0.0001))).astype(f32))[:, None]
-        wi = torch.as_tensor(dirs)
-        d_ = lambert(nrm, wi).expand(-1, 3)
+    def shade(light_, nrm_, kd_, ks_, wo_, alpha_, ly, lx, wi, k):
+        """the differentiable part of one batch of samples (one sample slot of every covered pixel)"""
+        light_col = light_[ly, lx]
+        d_ = lambert(nrm_, wi).expand(-1, 3)
         if bsdf in (1, 2):
             s_ = torch.zeros_like(d_)
         else:
-            spec_col = (0.04 * (1.0 - ks[:, 2:3]) + kd * ks[:, 2:3]) * (1.0 - ks[:, 0:1])
-            s_ = pbr_specular(spec_col, nrm, wo_t, wi, alpha_t)
-        occl = ANY_HIT(ro_s.detach().numpy().astype(f32), dirs, verts, tris)
+            spec_col = (0.04 * (1.0 - ks_[:, 2:3]) + kd_ * ks_[:, 2:3]) * (1.0 - ks_[:, 0:1])
+            s_ = pbr_specular(spec_col, nrm_, wo_, wi, alpha_)
+        return d_ * light_col * k, s_ * light_col * k
+
+    def process(dirs, pdf_sum):
+        u, v = _dir_to_tc(dirs)
+        lx = torch.as_tensor(np.clip((u * f32(Wl)).astype(np.int64), 0, Wl - 1))
+        ly = torch.as_tensor(np.clip((v * f32(Hl)).astype(np.int64), 0, Hl - 1))
+        mis = torch.as_tensor((f32(1.0) / np.maximum(pdf_sum, f32(0.0001))).astype(f32))[:, None]
+        occl = ANY_HIT(ro_n, dirs, verts, tris)
         Vis = torch.as_tensor(((~occl).astype(f32) * f32(shadow_scale) + (f32(1.0) - f32(shadow_scale))).astype(f32))[:, None]
         k = Vis * mis * float(frac)
-        return d_ * light_col * k, s_ * light_col * k
+        args = (light, nrm, kd, ks, wo_t, alpha_t, ly, lx, torch.as_tensor(dirs), k)
+        if CHECKPOINT:      # config-size chains (oracle/make_golden_chain.py): same arithmetic, the graph of ONE sample batch alive at a time
+            from torch.utils.checkpoint import checkpoint
+            return checkpoint(shade, *args, use_reentrant=False)
+        return shade(*args)
 
     ar = np.arange(P)
     for i in range(S):
@@ -454,20 +473,32 @@ def bilateral(col, nrm, zdz, sigma):
     var = sigma * sigma
     acc = torch.zeros_like(col)
     acc_w = torch.zeros(B, H, W, 1)
-    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
     for fy in range(-rad, rad + 1):
-        for fx in range(-rad, rad + 1):
-            yy, xx = ys + fy, xs + fx
-            valid = ((yy >= 0) & (yy < H) & (xx >= 0) & (xx < W))[None, ..., None]
-            yc, xc = yy.clamp(0, H - 1), xx.clamp(0, W - 1)
-            t_col, t_nrm, t_zdz = col[:, yc, xc], nrm[:, yc, xc], zdz[:, yc, xc]
-            dist_sqr = float(fx * fx + fy * fy)
-            dist = math.sqrt(dist_sqr)
-            with torch.no_grad():
-                w_xy = math.exp(-dist_sqr / (2.0 * var))
-                w_n = torch.clamp(t_dot(t_nrm, nrm), eps, 1.0) ** 128.0
-                w_d = torch.exp(-(torch.abs(t_zdz[..., 0:1] - zdz[..., 0:1]) / torch.clamp(zdz[..., 1:2] * dist, min=eps)))
-                w = torch.where(valid, w_xy * w_n * w_d, torch.zeros(()))
-            acc = acc + t_col * w
-            acc_w = acc_w + w
+        if CHECKPOINT:
+            from torch.utils.checkpoint import checkpoint
+            acc, acc_w = checkpoint(_bilateral_row, col, nrm, zdz, acc, acc_w, fy, rad, var, use_reentrant=False)
+        else:
+            acc, acc_w = _bilateral_row(col, nrm, zdz, acc, acc_w, fy, rad, var)
     return torch.cat([acc, torch.clamp(acc_w, min=eps)], -1)
+
+
+def _bilateral_row(col, nrm, zdz, acc, acc_w, fy, rad, var):
+    """the 2 rad + 1 taps of filter row fy added to the running sums, in the kernel's tap order"""
+    B, H, W, _ = col.shape
+    eps = 0.0001
+    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    for fx in range(-rad, rad + 1):
+        yy, xx = ys + fy, xs + fx
+        valid = ((yy >= 0) & (yy < H) & (xx >= 0) & (xx < W))[None, ..., None]
+        yc, xc = yy.clamp(0, H - 1), xx.clamp(0, W - 1)
+        t_col, t_nrm, t_zdz = col[:, yc, xc], nrm[:, yc, xc], zdz[:, yc, xc]
+        dist_sqr = float(fx * fx + fy * fy)
+        dist = math.sqrt(dist_sqr)
+        with torch.no_grad():
+            w_xy = math.exp(-dist_sqr / (2.0 * var))
+            w_n = torch.clamp(t_dot(t_nrm, nrm), eps, 1.0) ** 128.0
+            w_d = torch.exp(-(torch.abs(t_zdz[..., 0:1] - zdz[..., 0:1]) / torch.clamp(zdz[..., 1:2] * dist, min=eps)))
+            w = torch.where(valid, w_xy * w_n * w_d, torch.zeros(()))
+        acc = acc + t_col * w
+        acc_w = acc_w + w
+    return acc, acc_w

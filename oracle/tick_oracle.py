@@ -108,7 +108,7 @@ def tick(FLAGS, grid_res, sdf_net, all_edges, d, target, iteration, loss=('l1', 
 
     if FLAGS.use_mesh_msdf_reg:
         regscale = (64 / grid_res) ** 3
-        eps = torch.tensor([1e-3])
+        eps = torch.tensor([1e-3], dtype=d['msdf'].dtype)
         open_scale, close_scale = FLAGS.msdf_reg_open_scale, FLAGS.msdf_reg_close_scale
         if open_scale > 0:
             msdf_reg = open_scale * regscale * F.huber_loss(d['msdf'].clamp(min=-eps).squeeze(), -eps.expand(d['msdf'].size(0)), reduction='sum')

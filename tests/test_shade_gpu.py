@@ -151,6 +151,48 @@ def test_env_shade_backward_from_saved_samples_equals_the_replayed_sampler(bsdf,
     assert float((a[6] - b[6]).abs().max()) <= 1e-5 * float(b[6].abs().max())
 
 
+@pytest.mark.parametrize("bound_pixels", [64, 128, 1000])
+def test_env_shade_with_a_bounded_scratch_is_bit_identical(bound_pixels, monkeypatch):
+    """gs_env_shade_fwd_bounded: the covered pixels go through ONE scratch that holds the per-sample records of `bound_pixels` pixels (rounded
+    down to a multiple of 64) -- several chunks, the last one ragged.  Outputs and the cached visibility bits are bit-identical to the
+    one-chunk call, the per-pixel gradients too (the backward replays the sampler from the cached bits), the probe gradient up to float-atomic
+    order.  What bounds the records of the reference's default workload (2 x 1024^2, n_samples 24: kernel.cu:490-529) to a fixed budget."""
+    from gshell_amd.render import optixutils as ou
+    B, H, W, n = 2, 40, 36, 3
+    verts, tri, mask, gb_pos, gb_nrm, view, kd, ks = scenes.sheet_gbuffer(B, H, W, 5)
+    n_cov = int((mask > 0).sum())
+    assert n_cov > bound_pixels or bound_pixels == 1000          # 188 covered pixels: chunks of 64 + 64 + 60, 128 + 60, one chunk
+    gen = torch.Generator().manual_seed(3)
+    light = torch.rand(32, 64, 3, generator=gen) * 2 + 0.05
+    pdf, rows, cols = po.update_pdf(light)
+    wd, ws = torch.rand(B, H, W, 3, generator=gen).to(DEV), torch.rand(B, H, W, 3, generator=gen).to(DEV)
+    ctx = ou.OptiXContext()
+    ou.optix_build_bvh(ctx, torch.tensor(verts, device=DEV), torch.tensor(tri, device=DEV), rebuild=1)
+    res = []
+    for bound in (None, bound_pixels * 2 * n * n * 40 + 256):
+        monkeypatch.setattr(ou, "SCRATCH_BOUND", bound)
+        dl = [t.to(DEV).requires_grad_(True) for t in (gb_pos, gb_nrm, kd, ks, light)]
+        d, s = ou.optix_env_shade(ctx, mask.to(DEV), None, dl[0], dl[1], view.to(DEV), dl[2], dl[3], dl[4], pdf.to(DEV), rows[:, 0].to(DEV),
+                                  cols.to(DEV), BSDF="pbr", n_samples_x=n, rnd_seed=77, shadow_scale=0.8)
+        assert ou.last_bounded == (bound is not None and n_cov > bound_pixels)
+        vis = d.grad_fn.args[-1].clone() if hasattr(d.grad_fn, "args") else None
+        ((d * wd).sum() + (s * ws).sum()).backward()
+        res.append([d.detach(), s.detach(), vis] + [t.grad.clone() for t in dl])
+    a, b = res
+    assert float(a[0].abs().max()) > 0
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    if a[2] is not None:
+        n_rays = n_cov * 2 * n * n                           # one bit per ray; the words behind the last ray are never written
+        full = n_rays // 64
+        assert torch.equal(a[2][:full], b[2][:full])
+        if n_rays % 64:
+            m = (1 << (n_rays % 64)) - 1
+            assert (int(a[2][full]) & m) == (int(b[2][full]) & m)
+    for x, y, name in zip(a[3:7], b[3:7], ("g_pos", "g_nrm", "g_kd", "g_ks")):
+        assert torch.equal(x, y), (name, float((x - y).abs().max()))
+    assert float((a[7] - b[7]).abs().max()) <= 1e-5 * float(b[7].abs().max())
+
+
 def test_env_shade_second_backward_through_a_retained_graph_equals_the_first():
     """The forward pass's ray buffer is consumed (overwritten in place) by the first backward pass; a second backward through a
     retained graph falls back to the replaying kernel and must return the same gradients."""

@@ -1,8 +1,11 @@
 """SURVEY.md 8(e) on the REAL Trainer: a view-sharded 2-rank iteration must leave the gradient of the single-process
 iteration over the same global batch (B = 2) in every parameter -- same Monte-Carlo samples (the sampler hashes the
 GLOBAL view index), same jitter / texture / tangent noise, same eikonal samples (NoiseStream), the SDF-MLP rows split over
-the ranks with an all-gather of sdf[N], the energy-ratio regulariser formed from all-reduced sums.  Two processes share
-the one device of the GPU box and talk over gloo (RCCL refuses two ranks on one device); the collectives are the same calls."""
+the ranks with an all-gather of sdf[N], the energy-ratio regulariser formed from all-reduced sums.  On the one-device GPU box the
+processes share the device and talk over gloo (RCCL refuses two ranks on one device); the collectives are the same calls.  The `nccl`
+parametrisations (one rank per device over RCCL / xGMI: all_gather_into_tensor, reduce_scatter_tensor, the flat all-reduce) switch themselves
+on wherever >= 2 / >= 8 devices are visible, so the first multi-GPU box that runs this suite exercises RCCL (reference: the only thing
+train_gshelltet_deepfashion.py:597-606 does is init_process_group("nccl"))."""
 import os
 import socket
 
@@ -28,10 +31,14 @@ def _grads(trainer):
     return [None if p.grad is None else p.grad.detach().clone() for p in trainer.all_params()]
 
 
-def _worker(rank, world, port, shard_rows, out_q, B=2):
+def _worker(rank, world, port, shard_rows, out_q, B=2, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":          # one rank per device
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from gshell_amd import workload
     from gshell_amd.render import render
     from gshell_amd.train import ViewShard
@@ -73,14 +80,23 @@ def _worker(rank, world, port, shard_rows, out_q, B=2):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,B,shard_rows", [(2, 2, True), (2, 2, False), (8, 8, True)])
-def test_sharded_iteration_equals_single_process(world, B, shard_rows):
+def _n_devices():
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+@pytest.mark.parametrize("backend,world,B,shard_rows", [
+    ("gloo", 2, 2, True), ("gloo", 2, 2, False), ("gloo", 8, 8, True),
+    pytest.param("nccl", 2, 2, True, marks=pytest.mark.skipif(_n_devices() < 2, reason="RCCL needs one device per rank: < 2 devices here")),
+    pytest.param("nccl", 2, 4, False, marks=pytest.mark.skipif(_n_devices() < 2, reason="RCCL needs one device per rank: < 2 devices here")),
+    pytest.param("nccl", 8, 8, True, marks=pytest.mark.skipif(_n_devices() < 8, reason="RCCL needs one device per rank: < 8 devices here"))])
+def test_sharded_iteration_equals_single_process(backend, world, B, shard_rows):
     """(8, 8, True) = the partitioning of BASELINE.json configs[3]: 8 ranks, global batch 8 (one view per rank), the grid rows
-    (a count that 8 does not divide) split over the ranks, union visibility -- eight processes on the one device, over gloo."""
+    (a count that 8 does not divide) split over the ranks, union visibility -- gloo: eight processes on the one device; nccl: one rank per
+    device over RCCL."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shard_rows, q, B)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shard_rows, q, B, backend)) for r in range(world)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=600) for _ in range(world))
@@ -94,3 +110,21 @@ def test_sharded_iteration_equals_single_process(world, B, shard_rows):
         assert na is not None and nb is not None or (na in (None, 0.0) and nb in (None, 0.0)), (i, na, nb)
         # 1e-4 relative (north_star); float-atomic accumulation order is the only difference left between the two runs
         assert rel <= 1e-4, f"parameter {i}: |g_sharded| {na} |g_single| {nb} rel L2 {rel}"
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="bench.py --gpus 2 needs two devices")
+def test_bench_runs_two_ranks_over_rccl():
+    """`python bench.py --gpus 2 --steps 3`: bench.py re-launches itself under torch.distributed.run with backend nccl (= RCCL), one rank per
+    device, and rank 0 prints the one JSON line with n_gpus = 2 -- so SCALE cannot be the first time the multi-GPU path executes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--res", "64", "--fit-steps", "60", "--early-steps", "0", "--extra-steps", "0", "--no-cpu-baseline"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["value"] > 0 and r["scaling"] == "weak"
