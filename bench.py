@@ -268,9 +268,9 @@ def main():
 
 def reference_config_run(trainer, timed, a, shard, res=1024, views=2, n=24):
     """One side record: the reference's default workload (configs/deepfashion_mc_256.json: batch 2, train_res 1024 x 1024, n_samples 24) on this
-    trainer.  The shader's per-sample records (40 B per ray) would be ~14 GB at this size: they go through ONE scratch of optixutils.SCRATCH_BOUND
-    bytes in chunks of covered pixels (bit-identical results, tests/test_shade_gpu.py), the backward replays the sampler from the cached visibility
-    bits.  `unbounded`: the same frames with the records kept (the path of the headline size), for the price of the bound."""
+    trainer.  The shader's per-sample records (40 B per ray) are ~14 GB at this size.  Headline fields: through ONE scratch of 2 GiB in chunks of covered
+    pixels, forward and backward (gs_env_shade_*_bounded: bit-identical results, tests/test_shade_gpu.py) -- what a frame above optixutils.SCRATCH_BOUND
+    (16 GiB by default) takes.  `unbounded`: the same frames with the records kept, which is what the default bound does at this size."""
     from gshell_amd import workload
     from gshell_amd.render import optixutils as ou
     F = trainer.FLAGS
@@ -279,7 +279,7 @@ def reference_config_run(trainer, timed, a, shard, res=1024, views=2, n=24):
     try:
         F.n_samples, F.train_res, F.batch = n, [res, res], views
         tg = [workload.make_targets(trainer, [(it * views + v) % 72 for v in shard.local_views(views)], (res, res), radius=a.camera_radius) for it in range(2)]
-        for tag, bound in (("bounded", ou.SCRATCH_BOUND), ("unbounded", None)):
+        for tag, bound in (("bounded", 2 << 30), ("unbounded", None)):
             keep, ou.SCRATCH_BOUND = ou.SCRATCH_BOUND, bound
             try:
                 torch.cuda.synchronize()

@@ -1299,6 +1299,40 @@ extern "C" int gs_env_shade_fwd_bounded(const gs_bvh* bvh, const int32_t* pix, i
                          view_stride, bsdf, n_samples_x, rnd_seed, shadow_scale, scratch, scratch_bytes, vis_bits, diff, spec, stream_);
 }
 
+// Gradients of the pixels of A (n_cov of them) from their per-sample records at A.ray_dk: [n_rays] float4 (direction, k) | [n_rays] 6 floats (dead
+// contributions, reused as scratch).  g_light is ACCUMULATED, the per-pixel gradients are written.
+static void launch_saved_grad(ShadeArgs& A, int64_t n_cov, int n_samples_x, int64_t Hl, int64_t Wl, hipStream_t stream) {
+    // the forward scratch = [n_rays] float4 (direction, k) | [n_rays] 6 floats of unshadowed contributions (dead by now).
+    // Records go over the contributions, the sorted records over (direction, k) once the gradient kernel has read them; the
+    // histograms / offsets use the tail of the contribution region (8 bytes per ray are left).
+    const int64_t S2 = 2ll * n_samples_x * n_samples_x, n_rays = n_cov * S2;
+    const int64_t n_wg = gs::cdiv(n_cov * A.G, 256), rays_per_wg = (256 / A.G) * S2;
+    const int64_t n_texels = Hl * Wl, nbins = gs::cdiv(n_texels, LG_TEXELS);
+    const int64_t tail_bytes = n_rays * 8, need = (n_wg * nbins + 2 * nbins + 2) * 4;
+    const bool binned = GS_LIGHT_BINNED && nbins <= 1024 && need <= tail_bytes && n_rays < (1ll << 32);
+    const int64_t need_aligned = (need + 15) / 16 * 16, partial_bytes = (int64_t)LG_SLICES * nbins * LG_TEXELS * 3 * 4;
+    const bool partials = binned && need_aligned + partial_bytes <= tail_bytes;
+    if (binned) {
+        A.rec = (float4*)(A.ray_dk + n_rays);
+        A.hist = (uint32_t*)(A.rec + n_rays);
+        A.nbins = (int)nbins;
+        A.n_wg = n_wg;
+    }
+    hipLaunchKernelGGL(k_shade_grad, dim3((unsigned)n_wg), dim3(256), 0, stream, A);
+    if (binned) {
+        uint32_t* totals = A.hist + n_wg * nbins;
+        uint32_t* base = totals + nbins;
+        hipLaunchKernelGGL(k_light_scan, dim3((unsigned)nbins), dim3(256), 0, stream, A.hist, n_wg, (int)nbins, totals);
+        hipLaunchKernelGGL(k_light_base, dim3(1), dim3(64), 0, stream, totals, (int)nbins, base);
+        hipLaunchKernelGGL(k_light_scatter, dim3((unsigned)n_wg), dim3(256), 0, stream, A.rec, n_rays, rays_per_wg, A.hist, base, (int)nbins, A.ray_dk);
+        float* partial = partials ? (float*)((char*)A.hist + need_aligned) : nullptr;
+        hipLaunchKernelGGL(k_light_reduce, dim3((unsigned)nbins, LG_SLICES), dim3(LG_NT), 0, stream, A.ray_dk, base, n_texels, A.g_light, partial);
+        if (partial)
+            hipLaunchKernelGGL(k_light_sum, dim3((unsigned)gs::cdiv(n_texels * 3, 256)), dim3(256), 0, stream, partial, nbins * (int64_t)LG_TEXELS * 3,
+                               n_texels * 3, A.g_light);
+    }
+}
+
 static int env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* gb_pos, const float* gb_normal,
                          const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
                          const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
@@ -1322,36 +1356,8 @@ static int env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, c
     A.g_diff = g_diff; A.g_spec = g_spec; A.g_pos = g_pos; A.g_nrm = g_normal; A.g_kd = g_kd; A.g_ks = g_ks; A.g_light = g_light;
     A.g_tex_stride = g_tex6 ? 6 : 3;
     if (saved_rays) {
-        // the forward scratch = [n_rays] float4 (direction, k) | [n_rays] 6 floats of unshadowed contributions (dead by now).
-        // Records go over the contributions, the sorted records over (direction, k) once the gradient kernel has read them; the
-        // histograms / offsets use the tail of the contribution region (8 bytes per ray are left).
         A.ray_dk = (float4*)const_cast<void*>(saved_rays);
-        const int64_t S2 = 2ll * n_samples_x * n_samples_x, n_rays = n_cov * S2;
-        const int64_t n_wg = gs::cdiv(n_cov * A.G, 256), rays_per_wg = (256 / A.G) * S2;
-        const int64_t n_texels = Hl * Wl, nbins = gs::cdiv(n_texels, LG_TEXELS);
-        const int64_t tail_bytes = n_rays * 8, need = (n_wg * nbins + 2 * nbins + 2) * 4;
-        const bool binned = GS_LIGHT_BINNED && nbins <= 1024 && need <= tail_bytes && n_rays < (1ll << 32);
-        const int64_t need_aligned = (need + 15) / 16 * 16, partial_bytes = (int64_t)LG_SLICES * nbins * LG_TEXELS * 3 * 4;
-        const bool partials = binned && need_aligned + partial_bytes <= tail_bytes;
-        if (binned) {
-            A.rec = (float4*)(A.ray_dk + n_rays);
-            A.hist = (uint32_t*)(A.rec + n_rays);
-            A.nbins = (int)nbins;
-            A.n_wg = n_wg;
-        }
-        hipLaunchKernelGGL(k_shade_grad, dim3((unsigned)n_wg), dim3(256), 0, stream, A);
-        if (binned) {
-            uint32_t* totals = A.hist + n_wg * nbins;
-            uint32_t* base = totals + nbins;
-            hipLaunchKernelGGL(k_light_scan, dim3((unsigned)nbins), dim3(256), 0, stream, A.hist, n_wg, (int)nbins, totals);
-            hipLaunchKernelGGL(k_light_base, dim3(1), dim3(64), 0, stream, totals, (int)nbins, base);
-            hipLaunchKernelGGL(k_light_scatter, dim3((unsigned)n_wg), dim3(256), 0, stream, A.rec, n_rays, rays_per_wg, A.hist, base, (int)nbins, A.ray_dk);
-            float* partial = partials ? (float*)((char*)A.hist + need_aligned) : nullptr;
-            hipLaunchKernelGGL(k_light_reduce, dim3((unsigned)nbins, LG_SLICES), dim3(LG_NT), 0, stream, A.ray_dk, base, n_texels, A.g_light, partial);
-            if (partial)
-                hipLaunchKernelGGL(k_light_sum, dim3((unsigned)gs::cdiv(n_texels * 3, 256)), dim3(256), 0, stream, partial, nbins * (int64_t)LG_TEXELS * 3,
-                                   n_texels * 3, A.g_light);
-        }
+        launch_saved_grad(A, n_cov, n_samples_x, Hl, Wl, stream);
     } else {
         hipLaunchKernelGGL(k_shade_samples<true>, dim3((unsigned)gs::cdiv(n_cov * A.G, 256)), dim3(256), 0, stream, A);
     }
@@ -1380,6 +1386,52 @@ extern "C" int gs_env_shade_bwd_saved(const gs_bvh* bvh, const int32_t* pix, int
     return env_shade_bwd(bvh, pix, n_cov, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols, Hl, Wl, perms, P, B, H, W, view_offset,
                          view_stride, bsdf, n_samples_x, rnd_seed, shadow_scale, vis_bits, fwd_scratch, g_diff, g_spec, g_pos, g_normal, g_kd, g_ks, g_light,
                          stream_);
+}
+
+// Backward of a frame whose records do not fit a fixed budget (see gs_env_shade_fwd_bounded): per chunk of covered pixels (a multiple of 64, the
+// forward's rule) the sampler REGENERATES the chunk's records into `scratch` (k_shade_samples<false>: same RNG streams, no rays -- visibility comes
+// from the forward's cached bits) and the saved-samples gradient kernels run on them.  Per-pixel gradients bit-identical to gs_env_shade_bwd_saved,
+// the probe gradient up to float-atomic order.
+extern "C" int gs_env_shade_bwd_bounded(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* gb_pos, const float* gb_normal,
+                                        const float* view_pos, const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
+                                        const float* rows, const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P, int64_t B,
+                                        int64_t H, int64_t W, int64_t view_offset, int64_t view_stride, int bsdf, int n_samples_x, uint32_t rnd_seed,
+                                        float shadow_scale, const uint64_t* vis_bits, void* scratch, int64_t scratch_bytes, const float* g_diff,
+                                        const float* g_spec, float* g_pos, float* g_normal, float* g_kd, float* g_ks, float* g_light, gs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (B * H * W == 0) return 0;
+    GS_REQUIRE(g_diff && g_spec && g_pos && g_normal && g_kd && g_ks && g_light, "gs_env_shade_bwd_bounded: null pointer");
+    size_t nb = (size_t)B * H * W * 12;
+    GS_HIP_CHECK(hipMemsetAsync(g_pos, 0, nb, stream));
+    GS_HIP_CHECK(hipMemsetAsync(g_normal, 0, nb, stream));
+    const bool g_tex6 = g_ks == g_kd + 3;
+    GS_HIP_CHECK(hipMemsetAsync(g_kd, 0, g_tex6 ? 2 * nb : nb, stream));
+    if (!g_tex6) GS_HIP_CHECK(hipMemsetAsync(g_ks, 0, nb, stream));
+    if (n_cov == 0) return 0;
+    GS_REQUIRE(scratch != nullptr && scratch_bytes >= 0, "gs_env_shade_bwd_bounded: null scratch");
+    const int64_t S2 = 2ll * n_samples_x * n_samples_x;
+    int64_t chunk = n_cov;
+    if (scratch_bytes < gs_env_shade_scratch_bytes(n_cov, n_samples_x)) {
+        chunk = (scratch_bytes - 256) / (S2 * 40) / 64 * 64;
+        GS_REQUIRE(chunk >= 64, "gs_env_shade_bwd_bounded: the scratch does not hold the records of 64 pixels");
+    }
+    for (int64_t off = 0; off < n_cov; off += chunk) {
+        const int64_t cnt = n_cov - off < chunk ? n_cov - off : chunk;
+        ShadeArgs A{};
+        int rc = fill_args(A, bvh, pix + off, cnt, gb_pos /* ro: read by the trace kernel only */, gb_pos, gb_normal, view_pos, gb_kd, gb_ks, light, pdf, rows, cols,
+                           Hl, Wl, perms, P, B, H, W, view_offset, view_stride, bsdf, n_samples_x, rnd_seed, shadow_scale,
+                           const_cast<uint64_t*>(vis_bits) + off * S2 / 64);
+        if (rc) return rc;
+        A.g_diff = g_diff; A.g_spec = g_spec; A.g_pos = g_pos; A.g_nrm = g_normal; A.g_kd = g_kd; A.g_ks = g_ks; A.g_light = g_light;
+        A.g_tex_stride = g_tex6 ? 6 : 3;
+        const int64_t n_rays = cnt * S2;
+        A.ray_dk = (float4*)scratch;
+        A.ray_contrib = (float*)(A.ray_dk + n_rays);
+        hipLaunchKernelGGL(k_shade_samples<false>, dim3((unsigned)gs::cdiv(cnt * A.G, 256)), dim3(256), 0, stream, A);
+        launch_saved_grad(A, cnt, n_samples_x, Hl, Wl, stream);
+        GS_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 extern "C" int gs_bilateral_fwd(const float* col, const float* nrm, const float* zdz, int64_t B, int64_t H, int64_t W, float sigma, float* out,

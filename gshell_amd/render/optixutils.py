@@ -127,11 +127,22 @@ last_covered_pixels = None      # covered pixels of the last optix_env_shade cal
 SAVED_SAMPLES = True      # backward from the forward pass's saved ray buffer (gs_env_shade_bwd_saved) instead of replaying the sampler.
                           # The buffer (40 B per ray: ~0.8 GB at 4 x 512^2, n = 8, 15 % coverage) stays alive from forward to backward;
                           # the first backward overwrites it in place, a second one (retain_graph) replays the sampler instead.
-SCRATCH_BOUND = 2 << 30    # bytes of per-sample records one env-shade call may hold.  A frame above it (the reference's default workload,
-                          # configs/deepfashion_mc_256.json: 2 x 1024^2, n_samples 24 -> 1152 rays per covered pixel, ~14 GB of records) is shaded
-                          # in chunks of covered pixels through one scratch of this size (gs_env_shade_fwd_bounded: bit-identical outputs) and
-                          # back-propagated by sampler replay from the cached visibility bits (gs_env_shade_bwd) -- no records kept.
+SCRATCH_BOUND = 16 << 30   # bytes of per-sample records one env-shade call may hold (5.5 % of the MI355X's 288 GB).  A frame above it -- e.g. 4 views of
+                          # the reference's default render size, 1024^2 at n_samples 24 (configs/deepfashion_mc_256.json: 1152 rays per covered pixel
+                          # and pass, ~28 GB of records) -- is shaded in chunks of covered pixels through ONE scratch of this size
+                          # (gs_env_shade_fwd_bounded: bit-identical outputs) and back-propagated chunk by chunk too (gs_env_shade_bwd_bounded: the
+                          # sampler regenerates a chunk's records, no rays): no records kept.  Measured on MI355X at 2 x 1024^2, n = 24 (13.8 GB of
+                          # records): 83 ms / iteration with the records kept, 103 ms through a 2 GiB scratch (peak memory 20 GB -> 8 GB).
 last_bounded = False       # whether the last forward call took the bounded path (bench.py / tests)
+
+
+def _padded(n):
+    """allocation size for a coverage-dependent buffer of n elements: rounded up to 1/8 of its leading power of two (<= 12.5 % more), so that frames
+    whose covered-pixel counts differ by a few per cent ask torch's caching allocator for the SAME block sizes and no first-size hipMalloc lands in a
+    later iteration (round 5: one 5-step batch of the close-camera run read 50 ms per step instead of 25 on the driver's box)"""
+    n = max(int(n), 1)
+    g = 1 << max(n.bit_length() - 4, 0)
+    return (n + g - 1) // g * g
 
 
 class _optix_env_shade_func(torch.autograd.Function):
@@ -154,7 +165,7 @@ class _optix_env_shade_func(torch.autograd.Function):
                                              c_int64(view_map[1]), c_int(BSDF), c_int(n), c_uint32(seed & 0xFFFFFFFF), c_float(shadow_scale), ptr(scratch),
                                              c_int64(nbytes), ptr(vis), ptr(diff), ptr(spec), stream()), "gs_env_shade_fwd_bounded")
             return None
-        scratch = torch.empty((need + 7) // 8, dtype=torch.int64, device=pix.device)
+        scratch = torch.empty(_padded((need + 7) // 8), dtype=torch.int64, device=pix.device)
         check(L.gs_env_shade_fwd(optix_ctx.handle, ptr(pix, torch.int32), c_int64(n_cov), ptr(t["ro"]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view),
                                  t["kd_ptr"], t["ks_ptr"], ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]), c_int64(lgt.shape[1]),
                                  ptr(perms, torch.int32), c_int64(perms.shape[0]), c_int64(B), c_int64(H), c_int64(W), c_int64(view_map[0]), c_int64(view_map[1]),
@@ -199,7 +210,7 @@ class _optix_env_shade_func(torch.autograd.Function):
         perms = random_perm(n_samples_x, dev)
         diff = torch.empty(full, dtype=torch.float32, device=dev)
         spec = torch.empty(full, dtype=torch.float32, device=dev)
-        vis = torch.empty((int(L.gs_env_shade_vis_words(c_int64(pix.shape[0]), c_int(n_samples_x))),), dtype=torch.int64, device=dev)
+        vis = torch.empty((_padded(int(L.gs_env_shade_vis_words(c_int64(pix.shape[0]), c_int(n_samples_x)))),), dtype=torch.int64, device=dev)
         with torch.cuda.device(dev):
             scratch = _optix_env_shade_func._launch_fwd(optix_ctx, pix, t, view, lgt, t_pdf, t_rows, t_cols, perms, BSDF, n_samples_x, _rnd_seed,
                                                         shadow_scale, (B, H, W), vis, diff, spec, view_map)
@@ -238,7 +249,16 @@ class _optix_env_shade_func(torch.autograd.Function):
             else:
                 _rnd_seed = _fwd_seed      # same seed -> same rays -> the cached visibility bits are exact
                 scratch = ctx.scratch
-            fn, extra = ((_lib.lib().gs_env_shade_bwd_saved, (ptr(scratch),)) if scratch is not None else (_lib.lib().gs_env_shade_bwd, ()))
+            need = max(int(_lib.lib().gs_env_shade_scratch_bytes(c_int64(pix.shape[0]), c_int(n_samples_x))), 8)
+            if scratch is not None:
+                fn, extra = _lib.lib().gs_env_shade_bwd_saved, (ptr(scratch),)
+            elif SAVED_SAMPLES and SCRATCH_BOUND is not None and need > SCRATCH_BOUND:
+                # the frame was shaded in chunks (gs_env_shade_fwd_bounded): regenerate each chunk's records into one scratch of the same size
+                nbytes = max(int(SCRATCH_BOUND), 64 * 2 * n_samples_x * n_samples_x * 40 + 256)
+                scratch = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
+                fn, extra = _lib.lib().gs_env_shade_bwd_bounded, (ptr(scratch), c_int64(nbytes))
+            else:
+                fn, extra = _lib.lib().gs_env_shade_bwd, ()
             check(fn(optix_ctx.handle, ptr(pix), c_int64(pix.shape[0]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view), t["kd_ptr"],
                                               t["ks_ptr"], ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]),
                                               c_int64(lgt.shape[1]), ptr(perms), c_int64(perms.shape[0]), c_int64(B), c_int64(H), c_int64(W),

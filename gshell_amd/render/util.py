@@ -79,3 +79,11 @@ def perspective(fovy=0.7854, aspect=1.0, n=0.1, f=1000.0, device=None):
 
 def mse_to_psnr(mse):
     return -10.0 * math.log10(mse)
+
+
+def time_to_text(seconds):
+    """'1.50 h' / '2.00 m' / '3.00 s' (reference render/util.py:511-517; the training loops print the remaining time with it)"""
+    for unit, span in (("h", 3600.0), ("m", 60.0)):
+        if seconds > span:
+            return "%.2f %s" % (seconds / span, unit)
+    return "%.2f s" % seconds

@@ -354,8 +354,8 @@ int gs_env_shade_fwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const
  * (40 B per ray) fit `scratch_bytes`; outputs and vis_bits are bit-identical to gs_env_shade_fwd for every bound (each pixel's samples hash its
  * GLOBAL index, a ray's visibility does not depend on its batch).  For frames whose records would not fit a fixed budget -- the reference's
  * own default workload, configs/deepfashion_mc_256.json:7-8,17 (2 x 1024^2, n_samples 24: 1152 rays per covered pixel, kernel.cu:490-529) needs
- * ~14 GB of them.  After a call that took more than one chunk only the last chunk's records exist: back-propagate with gs_env_shade_bwd
- * (sampler replay from the cached bits), not gs_env_shade_bwd_saved. */
+ * ~14 GB of them.  After a call that took more than one chunk only the last chunk's records exist: back-propagate with gs_env_shade_bwd_bounded
+ * (records regenerated chunk by chunk) or gs_env_shade_bwd (sampler replay), not gs_env_shade_bwd_saved. */
 int gs_env_shade_fwd_bounded(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* ro,
                              const float* gb_pos, const float* gb_normal, const float* view_pos,
                              const float* gb_kd, const float* gb_ks, const float* light, const float* pdf,
@@ -374,6 +374,18 @@ int gs_env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const
                      float shadow_scale, const uint64_t* vis_bits, const float* g_diff,
                      const float* g_spec, float* g_pos, float* g_normal, float* g_kd, float* g_ks,
                      float* g_light, gs_stream_t stream);
+/* gs_env_shade_bwd_saved for a frame shaded by gs_env_shade_fwd_bounded: per chunk of covered pixels the sampler regenerates the chunk's records into
+ * `scratch` (same RNG streams; no rays -- visibility from vis_bits) and the saved-samples gradient kernels run on them.  Per-pixel gradients
+ * bit-identical to gs_env_shade_bwd_saved, g_light ACCUMULATED (equal up to float-atomic order). */
+int gs_env_shade_bwd_bounded(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* gb_pos,
+                             const float* gb_normal, const float* view_pos, const float* gb_kd,
+                             const float* gb_ks, const float* light, const float* pdf, const float* rows,
+                             const float* cols, int64_t Hl, int64_t Wl, const int32_t* perms, int64_t P,
+                             int64_t B, int64_t H, int64_t W, int64_t view_offset, int64_t view_stride,
+                             int bsdf, int n_samples_x, uint32_t rnd_seed, float shadow_scale,
+                             const uint64_t* vis_bits, void* scratch, int64_t scratch_bytes,
+                             const float* g_diff, const float* g_spec, float* g_pos, float* g_normal,
+                             float* g_kd, float* g_ks, float* g_light, gs_stream_t stream);
 /* The same gradients from the forward pass's SAVED samples: fwd_scratch = the scratch buffer of the gs_env_shade_fwd call
  * (kept alive by the caller; it holds every ray's direction and MIS weight, which the reference's backward treats as
  * constants too).  No RNG replay / CDF searches / BSDF sampling; bit-identical per-pixel gradients. */

@@ -144,3 +144,70 @@ def test_empty_mesh_renders_background():
     assert out['visible_triangles'].numel() == 0
     assert torch.equal(out['shaded'][..., :3], bg) and float(out['shaded'][..., 3].abs().max()) == 0.0
     assert float(out['msdf_image'].abs().max()) == 0.0
+
+
+def test_reference_default_workload_2x1024_n24_runs_in_bounded_scratch(scene):
+    """The reference's OWN published workload (configs/deepfashion_mc_256.json:7-8,17,19): grid 256, batch 2 x 1024^2, n_samples 24 = 1152 shadow rays
+    per covered pixel and pass (render/optixutils/c_src/envsampling/kernel.cu:490-529) -- ~3.4 10^8 rays per pass, whose 40 B records (~14 GB) go
+    through ONE scratch of 2 GiB (optixutils.SCRATCH_BOUND, set here) in chunks of covered pixels, forward and backward.  A whole tick + backward runs, every loss and gradient is
+    finite, the bounded path was taken, peak device memory stays far below the unbounded records alone; and on one 1024^2 view the bounded shader is
+    bit-identical to the one-chunk shader (outputs, per-pixel gradients; the probe gradient up to float-atomic order)."""
+    from gshell_amd import workload
+    from gshell_amd.render import optixutils as ou, rast as dr, renderutils as ru
+    tr, d = scene
+    F = tr.FLAGS
+    old = (F.n_samples, list(F.train_res), F.batch)
+    H = W = 1024
+    n = 24
+    try:
+        F.n_samples, F.train_res, F.batch = n, [H, W], 2
+        keep_bound, ou.SCRATCH_BOUND = ou.SCRATCH_BOUND, 2 << 30          # (the default, 16 GiB, would keep this frame's 12 GB of records)
+        target = workload.make_targets(tr, [0, 1], (H, W))
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        tr.it = 1500
+        img_loss, reg_loss = tr.step(target)
+        torch.cuda.synchronize()
+        cov = ou.last_covered_pixels
+        records = cov * 2 * n * n * 40
+        peak = torch.cuda.max_memory_allocated()
+        print(f"\n  2 x 1024^2, n = 24: {cov} covered pixels, {cov * 2 * n * n / 1e6:.0f} M shadow rays per pass, records unbounded {records / 2**30:.1f} GB; "
+              f"bounded path: {ou.last_bounded}; peak torch memory {peak / 2**30:.2f} GB; img_loss {float(img_loss):.4f} reg_loss {float(reg_loss):.4f}")
+        assert ou.last_bounded and records > ou.SCRATCH_BOUND
+        assert torch.isfinite(img_loss) and torch.isfinite(reg_loss)
+        for p in tr.all_params():
+            assert p.grad is None or torch.isfinite(p.grad).all()
+        assert peak < records                                   # the frame fits although its records alone would not
+        assert peak < 16 * 2 ** 30
+        # one view: bounded == one chunk
+        m = d['imesh']
+        mvp, cam = workload.views([0], DEV)
+        tri = m.faces_i32()
+        rast, _ = dr.rasterize(None, ru.xfm_points(m.v_pos[None], mvp), tri, (H, W))
+        gb = dr.interpolate(torch.cat([m.v_pos, m.v_nrm], -1)[None], rast, tri)[0]
+        pos, nrm = gb[..., :3].contiguous(), torch.nn.functional.normalize(gb[..., 3:6], dim=-1)
+        g = torch.Generator(device=DEV).manual_seed(0)
+        kd, ks = torch.rand(1, H, W, 3, device=DEV, generator=g), torch.rand(1, H, W, 3, device=DEV, generator=g)
+        wd, ws = torch.rand(1, H, W, 3, device=DEV, generator=g), torch.rand(1, H, W, 3, device=DEV, generator=g)
+        lgt = tr.lgt
+        res = []
+        for bound in (1 << 30, None):
+            keep, ou.SCRATCH_BOUND = ou.SCRATCH_BOUND, bound
+            try:
+                leaves = [t.clone().requires_grad_(True) for t in (pos, nrm, kd, ks, lgt.base.detach())]
+                dd, ss = ou.optix_env_shade(tr.geometry.optix_ctx, rast[..., 3], None, leaves[0], leaves[1], cam[:, None, None, :], leaves[2], leaves[3], leaves[4],
+                                            lgt._pdf, lgt.rows[:, 0].contiguous(), lgt.cols, BSDF='pbr', n_samples_x=n, rnd_seed=5, shadow_scale=1.0)
+                assert ou.last_bounded == (bound is not None)
+                ((dd * wd).sum() + (ss * ws).sum()).backward()
+                res.append([dd.detach(), ss.detach()] + [t.grad for t in leaves])
+            finally:
+                ou.SCRATCH_BOUND = keep
+        a, b = res
+        assert float(a[0].abs().max()) > 0
+        for x, y, name in zip(a[:6], b[:6], ("diff", "spec", "g_pos", "g_nrm", "g_kd", "g_ks")):
+            assert torch.equal(x, y), (name, float((x - y).abs().max()))
+        assert float((a[6] - b[6]).abs().max()) <= 1e-4 * float(b[6].abs().max())
+    finally:
+        F.n_samples, F.train_res, F.batch = old
+        ou.SCRATCH_BOUND = keep_bound
