@@ -54,6 +54,48 @@ def lib():
     return _lib
 
 
+def _load(path):
+    L = ctypes.CDLL(path)
+    L.gs_last_error.restype = ctypes.c_char_p
+    for name, ret in declared_prototypes().items():
+        fn = getattr(L, name)
+        fn.restype = {"int": c_int, "int64_t": c_int64}.get(ret, ctypes.c_char_p)
+    return L
+
+
+_variants = {}
+
+
+def variant_path(name):
+    return os.path.join(_HERE, "lib", "variants", f"{name}.so")
+
+
+class use_variant:
+    """`with use_variant("oracles"):` -- inside the block every entry point resolves in gshell_amd/lib/variants/<name>.so instead of the shipped library.
+    "oracles" = the same sources built with -DGS_ORACLE_KERNELS=1 (csrc/common.hpp): the exact-fp32 SDF forward, the register-resident one-product
+    forward, the tangent-row eikonal instantiations and the sampler-replay shading backward, which tests compare the shipped kernels with.  Objects made
+    by one library (BVH, topologies, packed weights) are plain device / host data of identical layout and may be handed to the other."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global _lib
+        path = variant_path(self.name)
+        if self.name not in _variants:
+            if not os.path.isfile(path):
+                raise GShellHipError(f"{path} not built (make -C gshell_amd/csrc builds it next to the shipped library)")
+            _variants[self.name] = _load(path)
+        lib()                                   # make sure the shipped library is what we swap back to
+        self._saved, _lib = _lib, _variants[self.name]
+        return _variants[self.name]
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
+
+
 def check(status, what=""):
     if status != 0:
         msg = lib().gs_last_error().decode("utf-8", "replace")

@@ -15,6 +15,8 @@ void report_flag(const char* name, long long value, long long) {
 }
 }  // namespace gs
 
+namespace gs { GS_TUNABLE(GS_ORACLE_KERNELS, 0) }
+
 extern "C" const char* gs_last_error(void) { return gs::g_err.c_str(); }
 extern "C" const char* gs_build_flags(void) { return gs::flag_registry().c_str(); }
 extern "C" int gs_version(void) { return 100; }

@@ -1359,7 +1359,11 @@ static int env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, c
         A.ray_dk = (float4*)const_cast<void*>(saved_rays);
         launch_saved_grad(A, n_cov, n_samples_x, Hl, Wl, stream);
     } else {
+#if GS_ORACLE_KERNELS
         hipLaunchKernelGGL(k_shade_samples<true>, dim3((unsigned)gs::cdiv(n_cov * A.G, 256)), dim3(256), 0, stream, A);
+#else
+        GS_ORACLE_ONLY("gs_env_shade_bwd (sampler-replay backward)");      // shipped: gs_env_shade_bwd_saved / gs_env_shade_bwd_bounded
+#endif
     }
     GS_LAUNCH_CHECK();
     return 0;

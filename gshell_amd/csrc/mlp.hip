@@ -25,6 +25,7 @@
 #include "../../include/gshell_hip.h"
 #include "common.hpp"
 
+#if GS_ORACLE_KERNELS
 namespace {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -181,7 +182,10 @@ constexpr size_t SMEM_BYTES = (size_t)((GS_MLP_INPLACE ? 1 : 2) * TM * LDX + TM 
 
 }  // namespace
 
+#endif  // GS_ORACLE_KERNELS
+
 extern "C" int64_t gs_sdf_mlp_packed_floats(int n_freq, int n_hidden, int skip_layer) {
+    constexpr int D = 256, KC = 8;      // the packed layout (python packs it; the kernel that reads it is an oracle kernel)
     int E = 3 * (2 * n_freq + 1);
     int Epad = (E + KC - 1) / KC * KC;
     int64_t n = (int64_t)Epad * D + D;                       // layer 0 weights + bias
@@ -191,6 +195,7 @@ extern "C" int64_t gs_sdf_mlp_packed_floats(int n_freq, int n_hidden, int skip_l
 
 // packed = [ Wt_0 (Epad x 256, k-major, zero padded) | b_0 | Wt_1 | b_1 | ... | w_out (256) | b_out ]
 // with Wt_l = transpose of torch's Linear.weight [256, K_l]; for the skip layer the K axis is [h (256) | emb (Epad)].
+#if GS_ORACLE_KERNELS
 extern "C" int gs_sdf_mlp_fwd(const float* x, int64_t N, const float* packed, int n_freq, int n_hidden, int skip_layer, float* out,
                               gs_stream_t stream) {
     if (N == 0) return 0;
@@ -216,8 +221,16 @@ extern "C" int gs_sdf_mlp_fwd(const float* x, int64_t N, const float* packed, in
     GS_LAUNCH_CHECK();
     return 0;
 }
+#else
+extern "C" int gs_sdf_mlp_fwd(const float* x, int64_t N, const float* packed, int n_freq, int n_hidden, int skip_layer, float* out,
+                              gs_stream_t stream) {
+    GS_ORACLE_ONLY("gs_sdf_mlp_fwd");
+}
+#endif
 
 // ---- compile-time variants of this file (common.hpp): non-default values announce themselves through gs_build_flags(); switches that give
 // wrong results (timing-only ablations) compile only under -DGS_EXPERIMENT
+#if GS_ORACLE_KERNELS
 GS_TUNABLE(GS_MLP_SUB, 2)
 GS_TUNABLE(GS_MLP_INPLACE, 1)
+#endif

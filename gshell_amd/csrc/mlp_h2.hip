@@ -1097,6 +1097,7 @@ __device__ __forceinline__ void r1_layer(const H2Args& A, int l, R1State& S, h8*
     }
 }
 
+#if GS_ORACLE_KERNELS      // (common.hpp: alternate design, built into lib/variants/oracles.so only)
 __global__ void __launch_bounds__(R1_NT, 2) k_h1r_fwd(H2Args A) {
     extern __shared__ __attribute__((aligned(16))) h8 smem_w[];           // [R1_BUFS][R1_CHUNK] | encoding fragments | scaled biases + output weights
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1175,6 +1176,7 @@ __global__ void __launch_bounds__(R1_NT, 2) k_h1r_fwd(H2Args A) {
     if (A.occ && lane == 0 && r0 < A.N) reinterpret_cast<uint32_t*>(A.occ)[tile] = (uint32_t)m;
     if (A.status && __ballot(valid && !(fabsf(sv) < 3.0e38f)) != 0ull && lane == 0) atomicOr(&A.status[ST_NONFINITE], 1u);
 }
+#endif  // GS_ORACLE_KERNELS
 
 // ---- backward chain ------------------------------------------------------------------------------------------------
 // Per 64-row tile, from the top: G = g_out (x) w_out;  for l = L-1 .. 0:  D_l = (dL/dz_l) from G and the saved activations
@@ -2165,7 +2167,14 @@ extern "C" int gs_sdf_mlp_fwd_h2(const float* x, int64_t N, const void* packed, 
 // only while impl == 1 is selected.
 extern "C" int gs_sdf_mlp_h1_impl(int impl) {
     const int old = g_h1_impl;
+#if GS_ORACLE_KERNELS
     if (impl == 0 || impl == 1) g_h1_impl = impl;
+#else
+    if (impl == 1) {          // the shipped library holds ONE forward design
+        gs::set_error("gs_sdf_mlp_h1_impl(1): k_h1r_fwd is an alternate-design kernel, not in the shipped library -- use gshell_amd/lib/variants/oracles.so");
+        return -1;
+    }
+#endif
     return old;
 }
 
@@ -2178,12 +2187,14 @@ extern "C" int gs_sdf_mlp_fwd_h1(const float* x, int64_t N, const void* packed, 
     H2Args A{};
     A.x = x; A.out = out; A.occ = occ_bits; A.status = status; A.N = N; A.n_freq = n_freq;
     fill_fwd_args(A, packed, make_layout(n_freq, n_hidden, skip_layer));
+#if GS_ORACLE_KERNELS
     if (g_h1_impl == 1) {          // register-resident activations (round 5)
         GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h1r_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_H1R_BYTES));
         hipLaunchKernelGGL(k_h1r_fwd, dim3((unsigned)gs::cdiv(N, 32 * R1_NW)), dim3(R1_NT), SMEM_H1R_BYTES, (hipStream_t)stream, A);
         GS_LAUNCH_CHECK();
         return 0;
     }
+#endif
     constexpr size_t smem = smem_h1_bytes<GS_H1_RM>();
     GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h1_fwd<GS_H1_NW, GS_H1_RM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL((k_h1_fwd<GS_H1_NW, GS_H1_RM>), dim3((unsigned)gs::cdiv(N, 32 * GS_H1_RM)), dim3(64 * GS_H1_NW), smem, (hipStream_t)stream, A);
@@ -2244,7 +2255,12 @@ extern "C" int gs_sdf_mlp_h2_save_fwd(int mode, const float* x, const int32_t* r
     A.x = x; A.rows = rows; A.out = out; A.N = n; A.n_dev = mode == MODE_ROWS ? n_dev : nullptr; A.n_freq = n_freq; A.A = A_save; A.EMB = EMB_save;
     A.Rpad = gs_sdf_mlp_h2_rows_padded(mode, n);
     fill_fwd_args(A, packed, make_layout(n_freq, n_hidden, skip_layer));
+#if GS_ORACLE_KERNELS
     return mode == MODE_ROWS ? launch_fwd<MODE_ROWS>(A, A.Rpad / TM, (hipStream_t)stream) : launch_fwd<MODE_EIK>(A, A.Rpad / TM, (hipStream_t)stream);
+#else
+    if (mode != MODE_ROWS) GS_ORACLE_ONLY("gs_sdf_mlp_h2_save_fwd(mode 2: tangent-row eikonal planes)");      // the shipped eikonal term is gs_sdf_eikonal_rr_*
+    return launch_fwd<MODE_ROWS>(A, A.Rpad / TM, (hipStream_t)stream);
+#endif
 }
 
 // Backward chain over the saved planes: D [n_hidden+1][Rpad][256] WRITTEN (dL/d pre-activation of every layer, per virtual
@@ -2271,8 +2287,12 @@ extern "C" int gs_sdf_mlp_h2_bwd(int mode, const float* g_out, const int32_t* ro
         GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_bwd<MODE_ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BWD_BYTES));
         hipLaunchKernelGGL(k_h2_bwd<MODE_ROWS>, dim3((unsigned)(B.Rpad / TM)), dim3(NT), SMEM_BWD_BYTES, st, B);
     } else {
+#if GS_ORACLE_KERNELS
         GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_h2_bwd<MODE_EIK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BWD_BYTES));
         hipLaunchKernelGGL(k_h2_bwd<MODE_EIK>, dim3((unsigned)(B.Rpad / TM)), dim3(NT), SMEM_BWD_BYTES, st, B);
+#else
+        GS_ORACLE_ONLY("gs_sdf_mlp_h2_bwd(mode 2: tangent-row eikonal planes)");
+#endif
     }
     GS_LAUNCH_CHECK();
     return 0;

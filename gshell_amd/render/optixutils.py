@@ -124,7 +124,8 @@ class CoveredPixels:
 
 PENDING_PIXELS = None           # the CoveredPixels request of the frame being rendered (render.render_mesh issues it right after rasterisation)
 last_covered_pixels = None      # covered pixels of the last optix_env_shade call (bench.py: rays per second)
-SAVED_SAMPLES = True      # backward from the forward pass's saved ray buffer (gs_env_shade_bwd_saved) instead of replaying the sampler.
+SAVED_SAMPLES = True      # backward from the forward pass's saved ray buffer (gs_env_shade_bwd_saved); False = the one-kernel sampler replay of round 1
+                          # (gs_env_shade_bwd: an oracle kernel, present in lib/variants/oracles.so only -- tests compare the two).
                           # The buffer (40 B per ray: ~0.8 GB at 4 x 512^2, n = 8, 15 % coverage) stays alive from forward to backward;
                           # the first backward overwrites it in place, a second one (retain_graph) replays the sampler instead.
 SCRATCH_BOUND = 16 << 30   # bytes of per-sample records one env-shade call may hold (5.5 % of the MI355X's 288 GB).  A frame above it -- e.g. 4 views of
@@ -252,13 +253,15 @@ class _optix_env_shade_func(torch.autograd.Function):
             need = max(int(_lib.lib().gs_env_shade_scratch_bytes(c_int64(pix.shape[0]), c_int(n_samples_x))), 8)
             if scratch is not None:
                 fn, extra = _lib.lib().gs_env_shade_bwd_saved, (ptr(scratch),)
-            elif SAVED_SAMPLES and SCRATCH_BOUND is not None and need > SCRATCH_BOUND:
-                # the frame was shaded in chunks (gs_env_shade_fwd_bounded): regenerate each chunk's records into one scratch of the same size
-                nbytes = max(int(SCRATCH_BOUND), 64 * 2 * n_samples_x * n_samples_x * 40 + 256)
-                scratch = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
+            elif SAVED_SAMPLES:
+                # no records at hand -- the frame was shaded in chunks (gs_env_shade_fwd_bounded), or this is a second backward through a retained
+                # graph (the first consumed them in place): the sampler regenerates them (no rays: the visibility bits are cached) into a scratch
+                # of at most SCRATCH_BOUND bytes, chunk by chunk
+                nbytes = need if (SCRATCH_BOUND is None or need <= SCRATCH_BOUND) else max(int(SCRATCH_BOUND), 64 * 2 * n_samples_x * n_samples_x * 40 + 256)
+                scratch = torch.empty(_padded((nbytes + 7) // 8), dtype=torch.int64, device=dev)
                 fn, extra = _lib.lib().gs_env_shade_bwd_bounded, (ptr(scratch), c_int64(nbytes))
             else:
-                fn, extra = _lib.lib().gs_env_shade_bwd, ()
+                fn, extra = _lib.lib().gs_env_shade_bwd, ()      # sampler replay in one kernel (round 1's path): lib/variants/oracles.so only
             check(fn(optix_ctx.handle, ptr(pix), c_int64(pix.shape[0]), ptr(t["pos"]), ptr(t["nrm"]), ptr(view), t["kd_ptr"],
                                               t["ks_ptr"], ptr(lgt), ptr(t_pdf), ptr(t_rows), ptr(t_cols), c_int64(lgt.shape[0]),
                                               c_int64(lgt.shape[1]), ptr(perms), c_int64(perms.shape[0]), c_int64(B), c_int64(H), c_int64(W),

@@ -35,3 +35,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def oracle_kernels():
+    """The test runs against gshell_amd/lib/variants/oracles.so (= the shipped sources + the oracle / alternate-design kernels, csrc/common.hpp
+    GS_ORACLE_KERNELS): for tests whose CHECKER is one of those kernels (exact-fp32 SDF forward, tangent-row eikonal, sampler-replay backward) or
+    that keep an unshipped design correct (k_h1r_fwd)."""
+    from gshell_amd import _lib
+    if not os.path.isfile(_lib.variant_path("oracles")):
+        pytest.skip("gshell_amd/lib/variants/oracles.so not built")
+    with _lib.use_variant("oracles") as L:
+        yield L

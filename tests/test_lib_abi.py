@@ -38,3 +38,22 @@ def test_the_in_tree_library_is_the_shipped_build():
     flags = L.gs_build_flags().decode()
     assert flags == "", f"libgshell_hip.so was built with non-default compile-time flags: {flags}"
     assert len(_lib.declared_symbols()) >= 130
+
+
+def test_oracle_variant_reports_itself_and_the_shipped_library_holds_one_design_per_stage():
+    """lib/variants/oracles.so = the same sources + the oracle / alternate-design kernels (csrc/common.hpp GS_ORACLE_KERNELS): it exports the same
+    ABI and announces itself through gs_build_flags() (bench.py refuses such a library); the SHIPPED library refuses to select the register-resident
+    forward (host-side calls only: no device work)."""
+    path = _lib.variant_path("oracles")
+    if not os.path.isfile(path):
+        pytest.skip("variant not built")
+    V = _lib._load(path)
+    assert "GS_ORACLE_KERNELS=1" in V.gs_build_flags().decode()
+    assert not [n for n in _lib.declared_symbols() if not hasattr(V, n)]
+    assert V.gs_sdf_mlp_h1_impl(ctypes.c_int(-1)) == 0
+    L = _lib._load(_lib.LIB_PATH)
+    assert L.gs_sdf_mlp_h1_impl(ctypes.c_int(1)) == -1 and b"alternate-design" in L.gs_last_error()
+    assert L.gs_sdf_mlp_h1_impl(ctypes.c_int(-1)) == 0
+    with _lib.use_variant("oracles") as inside:
+        assert "GS_ORACLE_KERNELS=1" in inside.gs_build_flags().decode() and _lib.lib().gs_build_flags() == inside.gs_build_flags()
+    assert _lib.lib().gs_build_flags().decode() == ""

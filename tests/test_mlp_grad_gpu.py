@@ -66,7 +66,7 @@ def test_row_sparse_backward_matches_float64_autograd(n_hidden, skip_in, need_x,
 
 @pytest.mark.parametrize("formulation,n,n_hidden,skip_in", [("reverse", 1000 + 7, 6, (3,)), ("reverse", 16, 6, (3,)), ("reverse", 1, 6, (3,)), ("reverse", 129, 2, ()),
                                                              ("reverse-fp32-wgrad", 300, 6, (3,)), ("tangent", 1000 + 7, 6, (3,)), ("tangent", 16, 6, (3,))])
-def test_eikonal_term_matches_float64_double_backward(formulation, n, n_hidden, skip_in, monkeypatch):
+def test_eikonal_term_matches_float64_double_backward(formulation, n, n_hidden, skip_in, monkeypatch, request):
     """both formulations of the term (reverse over reverse = the reference's; forward-mode tangent rows) against float64 autograd"""
     from gshell_amd.geometry import mlp as M
     from gshell_amd.geometry.mlp import eikonal_sq_sum
@@ -74,6 +74,14 @@ def test_eikonal_term_matches_float64_double_backward(formulation, n, n_hidden, 
         monkeypatch.setattr(M, "SDF_MLP_WGRAD_FP32", True)
         formulation = formulation.split("-")[0]
     monkeypatch.setattr(M, "EIKONAL_FORMULATION", formulation)
+    if formulation == "tangent":          # the forward-mode formulation's <EIK> kernels are oracle kernels (lib/variants/oracles.so)
+        from gshell_amd import _lib
+        import os
+        if not os.path.isfile(_lib.variant_path("oracles")):
+            pytest.skip("lib/variants/oracles.so not built")
+        variant = _lib.use_variant("oracles")
+        variant.__enter__()
+        request.addfinalizer(lambda: variant.__exit__(None, None, None))
     net = _net(n_hidden, skip_in)
     g = torch.Generator(device=DEV).manual_seed(2)
     pts = (torch.rand(n, 3, device=DEV, generator=g) * 1.2 - 0.6).contiguous()
@@ -117,8 +125,9 @@ def test_eikonal_reverse_formulation_gradient_of_network_output_and_empty_input(
     assert all(float(t.abs().max()) == 0.0 for t in grads)
 
 
-def test_eikonal_gradient_of_network_output_equals_autograd():
-    """The tangent rows themselves: df/dx from the forward-mode pass vs autograd of the fp64 network."""
+def test_eikonal_gradient_of_network_output_equals_autograd(oracle_kernels):
+    """The tangent rows themselves: df/dx from the forward-mode pass (<EIK> planes: an oracle kernel, lib/variants/oracles.so) vs autograd of the
+    fp64 network."""
     from gshell_amd.geometry.mlp import _SavedChain
     net = _net()
     g = torch.Generator(device=DEV).manual_seed(3)

@@ -154,8 +154,15 @@ def test_fused_sdf_mlp_forward(n_hidden, skip_in):
     netd = net.to(DEV)
     xd = x.to(DEV)
     err_torch = float((ref[:, 0].double() - ref64).abs().max())          # what ANY fp32 evaluation order costs (torch CPU SGEMM)
+    from gshell_amd import _lib
     for precision in ("fp32", "h2"):
-        out = fused_forward(netd, xd, precision)
+        if precision == "fp32":      # the exact-fp32 MFMA kernel of round 1: an oracle kernel (lib/variants/oracles.so); the shipped library refuses it
+            with pytest.raises(_lib.GShellHipError, match="oracle"):
+                fused_forward(netd, xd, precision)
+            with _lib.use_variant("oracles"):
+                out = fused_forward(netd, xd, precision)
+        else:
+            out = fused_forward(netd, xd, precision)
         assert out.shape == (x.shape[0], 1)
         # fp32: k-ordered fma chain on the matrix core.  h2: fp16-pair operands (2^-22), three MFMAs per product, fp32
         # accumulate.  Both must sit at fp32 round-off of a 256-term dot product chain -- measured against float64 and

@@ -120,9 +120,9 @@ def test_bilateral_mask_only_skips_pixels_nobody_reads(sigma):
 
 
 @pytest.mark.parametrize("bsdf,n,shadow", [("pbr", 4, 0.6), ("diffuse", 3, 1.0), ("pbr", 8, 1.0)])
-def test_env_shade_backward_from_saved_samples_equals_the_replayed_sampler(bsdf, n, shadow, monkeypatch):
-    """gs_env_shade_bwd_saved (directions + MIS weights kept from the forward pass) vs gs_env_shade_bwd (RNG replay, the path
-    pinned to the oracle above): per-pixel gradients bit-identical, the light gradient equal up to float-atomic order."""
+def test_env_shade_backward_from_saved_samples_equals_the_replayed_sampler(bsdf, n, shadow, monkeypatch, oracle_kernels):
+    """gs_env_shade_bwd_saved (directions + MIS weights kept from the forward pass) vs gs_env_shade_bwd (RNG replay in ONE kernel: round 1's
+    backward, an oracle kernel in lib/variants/oracles.so): per-pixel gradients bit-identical, the light gradient equal up to float-atomic order."""
     from gshell_amd.render import optixutils as ou
     B, H, W = 2, 40, 36
     verts, tri, mask, gb_pos, gb_nrm, view, kd, ks = scenes.sheet_gbuffer(B, H, W, 5)
@@ -195,7 +195,8 @@ def test_env_shade_with_a_bounded_scratch_is_bit_identical(bound_pixels, monkeyp
 
 def test_env_shade_second_backward_through_a_retained_graph_equals_the_first():
     """The forward pass's ray buffer is consumed (overwritten in place) by the first backward pass; a second backward through a
-    retained graph falls back to the replaying kernel and must return the same gradients."""
+    retained graph has the sampler regenerate the records (gs_env_shade_bwd_bounded: no rays, the visibility bits are cached) and must return
+    the same gradients."""
     from gshell_amd.render import optixutils as ou
     B, H, W, n = 1, 32, 32, 4
     verts, tri, mask, gb_pos, gb_nrm, view, kd, ks = scenes.sheet_gbuffer(B, H, W, 5)

@@ -125,7 +125,8 @@ def test_h2_range_guard_detects_overflow_and_the_exact_kernel_is_finite():
                 m.weight.mul_(1e3 if m.out_features == 256 and m.in_features == 256 else 1.0)
         ref = net(verts[:4096])
         assert float(ref.abs().max()) > 1e6 and torch.isfinite(ref).all()          # finite in fp32, far beyond fp16 inside
-        y32 = mlp.fused_forward(net, verts[:4096], "fp32")
+        with _lib.use_variant("oracles"):          # the exact-fp32 kernel (no fp16 range limit) is an oracle kernel
+            y32 = mlp.fused_forward(net, verts[:4096], "fp32")
         assert torch.allclose(y32, ref, rtol=1e-4, atol=1e-3 * float(ref.abs().max()))
         with pytest.raises(_lib.GShellHipError, match="fp16 range"):
             mlp.fused_forward(net, verts, "h2")
@@ -201,10 +202,11 @@ def test_flexicubes_getmesh_is_identical_with_the_two_pass_forward():
 
 
 @pytest.mark.parametrize("n_rows", [70001, 64, 1])
-def test_register_resident_first_pass_kernel_computes_the_same_function(n_rows):
+def test_register_resident_first_pass_kernel_computes_the_same_function(n_rows, oracle_kernels):
     """gs_sdf_mlp_h1_impl(1): k_h1r_fwd (round 5; activations register-resident across the layers, weights through LDS, scaled variables z' = 100 log2(e) z,
     hardware sin / cos) against the three-product kernel on random rows of a random network: the one-product error bound of the first pass (5e-4 = tau / 4),
-    sign words consistent with the values, rows past N untouched.  The kernel is not the default (slower on MI355X) -- this keeps it correct."""
+    sign words consistent with the values, rows past N untouched.  The kernel is not shipped (slower on MI355X, DESIGN.md 7.2: it lives in lib/variants/oracles.so, the `oracle_kernels` fixture) -- this keeps it correct;
+    the shipped library refuses to select it."""
     from gshell_amd import _lib
     from gshell_amd.geometry import mlp
     from gshell_amd.geometry.mlp import MLP
@@ -212,6 +214,7 @@ def test_register_resident_first_pass_kernel_computes_the_same_function(n_rows):
     net = MLP(n_freq=6, d_hidden=256, n_hidden=6, skip_in=[3]).to(DEV)
     x = (torch.rand(n_rows, 3, device=DEV) * 2 - 1) * 1.05
     L = _lib.lib()
+    assert _lib._load(_lib.LIB_PATH).gs_sdf_mlp_h1_impl(_lib.c_int(1)) == -1          # shipped library: one forward design
     old = L.gs_sdf_mlp_h1_impl(_lib.c_int(1))
     try:
         with torch.no_grad():

@@ -4,6 +4,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# this tool measures oracle / alternate-design kernels: they live in lib/variants/oracles.so (csrc/common.hpp GS_ORACLE_KERNELS), not in the shipped library
+os.environ.setdefault("GSHELL_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gshell_amd", "lib", "variants", "oracles.so"))
 import torch
 
 from gshell_amd import _lib, grid
