@@ -172,15 +172,15 @@ def main():
                                 "what": "same iteration with SDF_TWO_PASS = False: every grid row through the three-product fp16-pair kernel (k_h2_fwd<GRID>)"}
         # (2) coverage sensitivity: S2 / R5 / S3 scale with the covered pixels; the headline camera leaves 86 % of the frame empty
         near = [workload.make_targets(trainer, [(it * B_global + v) % 72 for v in shard.local_views(B_global)], (H, W), radius=1.4) for it in range(2)]
-        # new tensor sizes (3 x the covered pixels: GBs of ray records, bin scratch): the headline run's cached blocks are returned first, the new
-        # sizes settle in 8 warm-up steps, and the figure is the better of two timed batches -- a first-size hipMalloc inside one batch of 5 steps
-        # made this line read 37 - 40 ms on some boxes and 25.6 on others
+        # new tensor sizes (3 x the covered pixels: GBs of ray records, bin scratch): the headline run's cached blocks are returned first and the new
+        # sizes settle in 8 warm-up steps; two timed batches, BOTH printed.  (A first-size hipMalloc inside a batch made this line read 50 ms for one
+        # batch on the driver's box in round 5; the coverage-dependent buffers are now allocated at padded sizes, optixutils._padded.)
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         dt2, _ = timed(a.schedule_it, 8, a.extra_steps, tgts=near)
         dt2b, _ = timed(a.schedule_it + 8 + a.extra_steps, 0, a.extra_steps, tgts=near)
         dt2_all = [round(dt2 / a.extra_steps * 1e3, 3), round(dt2b / a.extra_steps * 1e3, 3)]
-        dt2 = min(dt2, dt2b)
+        dt2 = max(dt2, dt2b)          # the slower batch is the headline of this side record (both are printed); round 5 reported the faster one
         cov2 = _ou.last_covered_pixels
         side["coverage_sensitivity"] = {"camera_radius": 1.4, "ms_per_step": round(dt2 / a.extra_steps * 1e3, 3), "value": round(B_global * H * W * a.extra_steps / dt2 / 1e6, 4),
                                         "covered_pixels_per_rank": cov2, "coverage": None if cov2 is None else round(cov2 / (B_local * H * W), 4), "steps": a.extra_steps,
@@ -258,6 +258,8 @@ def main():
                 out["cpu_baseline"].setdefault("stages", {})["env_shade_reference_kernel"] = cpu_reference_env_shade(trainer, a, H, W, op_times, B_local)
             except Exception as e:           # pragma: no cover
                 out["cpu_baseline"].setdefault("stages", {})["env_shade_reference_kernel"] = {"error": f"{type(e).__name__}: {e}"}
+            if a.geometry == "tets" and a.res == 256:
+                out["cpu_baseline"]["headline_cpu_estimate"] = headline_cpu_estimate(out["cpu_baseline"], B_local, H, W)
             ref = gpu_reference_formulation(trainer)
             if ref:
                 out["gpu_reference_formulation"] = ref
@@ -313,7 +315,7 @@ ROOFLINE_CANDIDATES = {"gs_env_shade_fwd", "gs_env_shade_fwd_bounded", "gs_env_s
                        "gs_sdf_mlp_h2_save_fwd", "gs_sdf_eikonal_rr_fwd", "gs_sdf_eikonal_rr_bwd", "gs_flexi_vd_bwd", "gs_flexi_vd_fwd"}
 
 
-EVIDENCE_ROUND = "r05"          # bench.py reads ONLY this round's PMC files (profiles/r05_*, written by tools/collect_r05.sh + tools/assemble_r05.py)
+EVIDENCE_ROUND = "r06"          # bench.py reads ONLY this round's PMC files (profiles/r06_*, written by tools/collect_r06.sh + tools/assemble_r06.py)
 
 
 def _evidence(name):
@@ -325,7 +327,7 @@ def _evidence(name):
 
 
 def source_hash():
-    """sha256 over the product's sources (gshell_amd/**/*.py|hip|hpp, include/*.h): what the PMC evidence is stamped with (tools/assemble_r05.py) and
+    """sha256 over the product's sources (gshell_amd/**/*.py|hip|hpp, include/*.h): what the PMC evidence is stamped with (tools/assemble_r06.py) and
     compared against here -- a commit id would go stale the moment the evidence itself is committed."""
     import hashlib
     h = hashlib.sha256()
@@ -342,7 +344,7 @@ def source_hash():
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from THIS round's committed PMC passes (profiles/r05_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
+    """HBM bytes per launch of `kernel` from THIS round's committed PMC passes (profiles/r06_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
     WRITE_SIZE in separate runs, bytes = 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950) -- None if not measured."""
     d = _evidence("pmc_traffic.json")
     try:
@@ -403,8 +405,8 @@ def rooflines(op_times, N, Ftets, V_aug, T, B, H, W, n, trainer):
 
 
 def binding_metric(key):
-    """What this round's rocprofv3 --pmc passes say binds a kernel family: the resource and its measured utilisation (profiles/r05_binding.json,
-    written by tools/assemble_r05.py).  The record names the hash of the product sources it was collected on; `stale_sources_now` is set when they have
+    """What this round's rocprofv3 --pmc passes say binds a kernel family: the resource and its measured utilisation (profiles/r06_binding.json,
+    written by tools/assemble_r06.py).  The record names the hash of the product sources it was collected on; `stale_sources_now` is set when they have
     changed since -- kernel times in the line are live, the utilisation figures are then those of the named source state."""
     d = _evidence("binding.json")
     if not d or key not in d:
@@ -499,12 +501,24 @@ def roofline_of(name, rec, op_times, N, Ftets, V_aug, T, B, H, W, n, trainer):
                     note="fp16-pair / bf16-pair operands: three products per algorithmic product; bound by the fp32 planes it writes and reads "
                          "(3 plane passes in _fwd, 11 in _bwd)")
     if name == "gs_env_shade_fwd":
-        # 68 B/px in + 24 B/px out; 2 n^2 shadow rays per covered pixel are the work that binds it
+        # 2 n^2 shadow rays per covered pixel through a software BVH: the family is VALU-issue bound (this round's SQ counters of k_shade_trace, `binding`),
+        # so its roofline is the vector ALU -- achieved = the fraction of VALU lane-cycles doing useful work = issue-busy x useful-lane fraction, measured
+        # by rocprofv3 --pmc on this workload; the live figure of merit is rays / s.  The HBM record SURVEY.md 8(d) defines for the stage (68 B/px in +
+        # 24 B/px out) is carried as `hbm`: a fraction of a per cent, because bytes are not what the stage is short of.
         n_cov = _ou.last_covered_pixels
         rays = None if n_cov is None else n_cov * 2 * n * n
-        return hbm("gs_env_shade_fwd (k_shade_samples + k_shade_trace + k_shade_accumulate)", npix * 92.0, covered_pixels=n_cov, shadow_rays=rays,
-                   rays_per_s=None if not rays else round(rays / t / 1e9, 3),
-                   note="software BVH any-hit traversal: VALU-issue bound, not an HBM stream (`binding`); G rays/s over the whole family")
+        h = hbm("gs_env_shade_fwd (k_shade_samples + k_shade_trace + k_shade_accumulate)", npix * 92.0)
+        b = h.pop("binding", None)
+        busy, useful = (b or {}).get("valu_issue_busy"), (b or {}).get("useful_valu_lane_fraction")
+        frac = None if (busy is None or useful is None) else round(busy * useful, 4)
+        out = {"kernel": h["kernel"], "bound": "valu", "achieved": frac, "peak": 1.0, "unit": "fraction of VALU lane-cycles doing useful work (issue-busy x useful lanes, rocprofv3 --pmc)",
+               "frac": frac, "valu_issue_busy": busy, "useful_valu_lane_fraction": useful, "avg_launch_ms": h["avg_launch_ms"], "covered_pixels": n_cov, "shadow_rays": rays,
+               "rays_per_s": None if not rays else round(rays / t / 1e9, 3), "traffic": h.get("traffic"),
+               "hbm": {k: h.get(k) for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes", "traffic", "traffic_over_algorithmic")},
+               "note": "software BVH any-hit traversal; rays_per_s = G rays / s over the whole family (live); the VALU fractions are this round's counters"}
+        if b:
+            out["binding"] = b
+        return out
     if name in ("gs_env_shade_bwd_saved", "gs_env_shade_bwd"):
         return hbm("gs_env_shade_bwd_saved (k_shade_grad + light-gradient counting sort)", npix * 140.0, covered_pixels=_ou.last_covered_pixels,
                    note="SURVEY.md 8d: 92 B/px in + 48 B/px out; streams the forward pass's saved 16 B/ray records")
@@ -533,6 +547,37 @@ def cpu_baseline(res=256):
         out["stages"] = cpu_stage_times(res)
     except Exception as e:           # pragma: no cover
         out["stages"] = {"error": str(e)}
+    return out
+
+
+def headline_cpu_estimate(cpu, views, H, W):
+    """What the per-stage CPU numbers imply for the HEADLINE config: the stages that were timed at configs[2]'s size on this box,
+    summed -- a LOWER bound of one CPU iteration (the SDF network's backward, rasterisation, texture, antialiasing, denoiser and losses are not in it) --
+    and, beside it, the one complete measurement that exists: the oracle chain of configs[2] (network -> extraction -> render -> tick -> backward, float32)
+    as minted on the build container's 8 cores (profiles/r06_mint_chains.log)."""
+    st = (cpu or {}).get("stages") or {}
+    parts = {}
+    if "sdf_mlp_fwd" in st:
+        parts["sdf_mlp_fwd"] = st["sdf_mlp_fwd"]["s"]
+    if "extraction_fwd" in st:
+        parts["extraction_fwd"] = st["extraction_fwd"]["s"]
+    es = st.get("env_shade_reference_kernel") or {}
+    if "s_fwd_launch" in es:
+        parts["env_shade_reference_kernel_fwd_bwd_all_views"] = round((es["s_fwd_launch"] + es["s_bwd_launch"]) * views, 3)
+    out = {"config": "BASELINE.json configs[2]: tet-res256, 4 views 512x512, n_samples 8", "stages_summed_s": parts}
+    if parts:
+        tot = sum(parts.values())
+        out.update(s_per_iteration_lower_bound=round(tot, 2), Mpixels_per_s_upper_bound=round(views * H * W / tot / 1e6, 5), cores=st.get("cores"))
+    try:
+        import re
+        log = open(os.path.join(ROOT, "profiles", f"{EVIDENCE_ROUND}_mint_chains.log")).read()
+        sec = log[log.index("chain config2"):]
+        m = re.search(r"\[torch\.float32\] network Jacobian on \d+ rows: (\d+) s", sec)
+        if m:
+            out["full_oracle_chain_float32"] = {"s": int(m.group(1)), "Mpixels_per_s": round(4 * 512 * 512 / int(m.group(1)) / 1e6, 5), "cores": 8,
+                                                "what": "oracle/make_golden_chain.py config2, float32 run (one whole tick + backward), build container"}
+    except Exception:
+        pass
     return out
 
 

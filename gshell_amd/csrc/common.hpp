@@ -66,7 +66,7 @@ struct FlagReporter {
 #ifdef GS_EXPERIMENT
 #define GS_EXPERIMENT_ONLY(name)
 #if !defined(__HIP_DEVICE_COMPILE__)
-static const ::gs::FlagReporter gs_flag_reporter_experiment("GS_EXPERIMENT(" __FILE__ ")", 1, 0);      // one entry per file built that way
+static const ::gs::FlagReporter gs_flag_reporter_experiment("GS_EXPERIMENT(" __BASE_FILE__ ")", 1, 0);      // one entry per .hip built that way (__BASE_FILE__: the translation unit, not this header)
 #endif
 #else
 #define GS_EXPERIMENT_ONLY(name) static_assert(false, #name " gives wrong results (timing-only ablation): it compiles only with -DGS_EXPERIMENT");

@@ -2466,6 +2466,7 @@ GS_TUNABLE(GS_H1_ASMMAX, 1)
 GS_TUNABLE(GS_H1_WAVES, 6)
 GS_TUNABLE(GS_H1_NW, 8)
 GS_TUNABLE(GS_H1_RM, 2)
+GS_TUNABLE(GS_H1_WAVES4, (GS_H1_RM == 4 ? 2 : 3))
 GS_TUNABLE(GS_H1R_ABL, 0)
 GS_TUNABLE(GS_H1R_PD, 1)
 GS_TUNABLE(GS_H1R_FENCE, 1)

@@ -321,16 +321,17 @@ class GShellTetsGeometry(torch.nn.Module):
 
     def _launch_eikonal(self, pts):
         """sum_i (|grad f(p_i)| - 1)^2 over this rank's share of the surface samples (reference :302-324), launched as soon as the
-        samples exist.  It does not depend on the rendering, so FLAGS.eikonal_side_stream can put it on a SIDE STREAM (autograd
-        replays the backward there too).  Measured on MI355X (r02): 35.0 ms / iteration with the side stream, 34.7 without -- the
-        render pass leaves no idle matrix-pipe time for the chain kernels to fill, so the default is off.
+        samples exist.  It does not depend on the rendering, so FLAGS.eikonal_side_stream puts it on a SIDE STREAM (autograd
+        replays the backward there too): the chain kernels (matrix pipe, HBM planes) then share the chip with the render pass's
+        VALU-bound stages.  Measured on MI355X: round 2, 35.0 ms / iteration with the side stream against 34.7 without (off); round 6,
+        on the 14.7 ms iteration, 14.27 - 14.70 (mean 14.49 of 5 runs) with it against 14.61 - 15.13 (mean 14.75) without: on by default.
         -> (sum, number of samples of the GLOBAL batch, stream or None)"""
         FL = self.FLAGS
         shard = getattr(FL, "view_shard", None)
         n_total = pts.shape[0]
         if shard is not None and shard.world > 1:      # identical sample set on every rank (seeded): rank r takes samples r, r + world, ...
             pts = pts[shard.rank::shard.world].contiguous()
-        if getattr(FL, "eikonal_side_stream", False) and pts.is_cuda:
+        if getattr(FL, "eikonal_side_stream", True) and pts.is_cuda:
             main = torch.cuda.current_stream()
             side = getattr(self, "_side_stream", None)
             if side is None:
