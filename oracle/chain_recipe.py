@@ -39,6 +39,9 @@ CHAINS = {
     "flexi80": dict(kind="flexicubes", res=80, iteration=500, seed=37, B=1, n=2, frame=512, textured=False, flags=dict(msdf_reg_open_scale=0.0)),
     # configs[2], the HEADLINE: tet-res256, 4 views 512^2, n = 8 (128 shadow rays / covered pixel / pass), the config's own 16-level texture
     "config2": dict(kind="tets", res=256, iteration=1500, seed=47, B=4, n=8, frame=512, textured=True, tex_levels=16),
+    # the same frames with the texture's 6 coarse levels only: position-linked gradients defined to ~3e-4 instead of ~3e-2, i.e. the headline GEOMETRY
+    # (13.4 M tets, 2.3 10^5 one-pixel triangles, 18.8 M samples) under bars that have power
+    "config2_l6": dict(kind="tets", res=256, iteration=1500, seed=47, B=4, n=8, frame=512, textured=True, tex_levels=6),
 }
 VIEW_IDS = [3, 11, 20, 41]
 PERM_ROWS = 32768                      # optixutils/ops.py:89

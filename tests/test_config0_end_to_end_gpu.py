@@ -437,8 +437,10 @@ def test_flexicubes_tick_chain_at_config4_grid_size_res80():
     _run_chain("flexi80")
 
 
-def test_headline_config2_tick_and_every_parameter_gradient_match_the_oracle_chain():
+@pytest.mark.parametrize("name", ["config2", "config2_l6"])
+def test_headline_config2_tick_and_every_parameter_gradient_match_the_oracle_chain(name):
     """BASELINE configs[2], the config the benchmark's number is quoted on: tet-res256 (2.28 M grid vertices, 13.4 M tets), 4 views 512 x 512,
     n = 8 (128 shadow rays per covered pixel and pass), 16-level hash-grid texture, steady-state schedule (iteration 1500: full shadows, 23 x 23
-    denoiser)."""
-    _run_chain("config2")
+    denoiser).  `_l6`: the same state and frames with the texture's 6 coarse levels only -- there float32 defines the position-linked gradients to a few 1e-4,
+    so the headline geometry is held to bars with power; with the config's own 16 levels the float64 arbiter measures ~3e-2 for them."""
+    _run_chain(name)
