@@ -154,13 +154,21 @@ class _InterpolateFn(torch.autograd.Function):
 
 
 def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
-    """-> (out [B,H,W,A], out_da [B,H,W,2A] or None); diff_attrs must be None or 'all'."""
-    if diff_attrs not in (None, 'all'):
-        raise NotImplementedError("diff_attrs subsets are not used by the reference")
-    if rast_db is not None and diff_attrs == 'all':
-        out, out_da = _InterpolateFn.apply(attr, rast, tri, rast_db)
+    """-> (out [B,H,W,A], out_da or None).  diff_attrs: None, 'all' (out_da [B,H,W,2A], what the reference passes, render.py:275) or a list of attribute
+    indices (out_da [B,H,W,2 len(list)], pairs in the order given -- nvdiffrast's convention; computed as the 'all' pass and sliced)."""
+    if diff_attrs is None or rast_db is None:
+        return _InterpolateFn.apply(attr, rast, tri, None), None
+    out, out_da = _InterpolateFn.apply(attr, rast, tri, rast_db)
+    if isinstance(diff_attrs, str):
+        if diff_attrs != 'all':
+            raise ValueError(f"diff_attrs must be None, 'all' or a list of attribute indices, got {diff_attrs!r}")
         return out, out_da
-    return _InterpolateFn.apply(attr, rast, tri, None), None
+    A = out.shape[-1]
+    idx = [int(i) for i in diff_attrs]
+    if any(i < 0 or i >= A for i in idx):
+        raise ValueError(f"diff_attrs index out of range for {A} attributes: {idx}")
+    cols = torch.tensor([c for i in idx for c in (2 * i, 2 * i + 1)], dtype=torch.long, device=out_da.device)
+    return out, out_da.index_select(-1, cols)
 
 
 class _InterpolateGroupsFn(torch.autograd.Function):

@@ -365,6 +365,8 @@ int gs_env_shade_fwd_bounded(const gs_bvh* bvh, const int32_t* pix, int64_t n_co
                              int n_samples_x, uint32_t rnd_seed, float shadow_scale, void* scratch,
                              int64_t scratch_bytes, uint64_t* vis_bits, float* diff, float* spec,
                              gs_stream_t stream);
+/* (gs_env_shade_bwd = the sampler replayed in ONE kernel, round 1's backward: an ORACLE KERNEL since round 6 -- lib/variants/oracles.so only; the shipped
+ *  backward passes are gs_env_shade_bwd_saved and gs_env_shade_bwd_bounded below.) */
 int gs_env_shade_bwd(const gs_bvh* bvh, const int32_t* pix, int64_t n_cov, const float* gb_pos,
                      const float* gb_normal, const float* view_pos, const float* gb_kd,
                      const float* gb_ks, const float* light, const float* pdf, const float* rows,
@@ -675,6 +677,8 @@ int gs_shade_assemble_bwd(const float* rast, const float* tex, const float* tex_
  *   rows (E = 3 (2 n_freq + 1)); K_l = 256, plus the zero-padded E rows of the embedding for the skip layer
  *   (input order [h | emb], geometry/mlp.py:37).  skip_layer: 1-based index among the hidden layers' Linear
  *   modules counted from the first Linear as 0 (reference skip_in=[3] -> skip_layer = 4), or -1.
+ *   ORACLE KERNEL (round 6): the exact-fp32 MFMA forward is what the fp16-pair kernels below are checked against; it is built into
+ *   lib/variants/oracles.so only -- in the shipped library gs_sdf_mlp_fwd fails with a message naming the variant (gs_sdf_mlp_packed_floats works).
  * ---------------------------------------------------------------------------------- */
 int64_t gs_sdf_mlp_packed_floats(int n_freq, int n_hidden, int skip_layer);
 int gs_sdf_mlp_fwd(const float* x, int64_t N, const float* packed, int n_freq, int n_hidden,
@@ -719,11 +723,11 @@ int gs_sdf_mlp_fwd_h2(const float* x, int64_t N, const void* packed, int n_freq,
  *   points of every sign-crossing edge -- all the reference consumes (gshell_tets.py:250, :277-290; gshell_tets_geometry.py:33-39). */
 int gs_sdf_mlp_fwd_h1(const float* x, int64_t N, const void* packed, int n_freq, int n_hidden,
                       int skip_layer, float* out, uint64_t* occ_bits, uint32_t* status, gs_stream_t stream);
-/* Kernel behind gs_sdf_mlp_fwd_h1: 0 (default) = the round-3 kernel (activations in LDS, weights through L1); 1 = activations register-resident
- * across the layers, weights staged through LDS once per 256 rows (k_h1r_fwd, round 5: correct but slower on MI355X, kept as a measured record --
- * DESIGN.md 7.2).  Same function and arithmetic class (geometry/mlp.py:32-40 with fp16 operands and fp32 accumulation); sums are taken in a
- * different order.  Select BEFORE gs_sdf_mlp_h2_pack (the packer writes kernel 1's fragments only while it is selected).  impl < 0 only queries.
- * Returns the previous setting. */
+/* Kernel behind gs_sdf_mlp_fwd_h1: 0 = the shipped kernel (activations in LDS, weights through L1); 1 = activations register-resident across the
+ * layers, weights staged through LDS once per 256 rows (k_h1r_fwd, round 5: correct, on par on MI355X) -- an ALTERNATE DESIGN that
+ * exists in lib/variants/oracles.so only (GS_ORACLE_KERNELS): the shipped library answers impl == 1 with -1 and gs_last_error().  Same function and
+ * arithmetic class (geometry/mlp.py:32-40 with fp16 operands and fp32 accumulation); sums are taken in a different order.  Select BEFORE
+ * gs_sdf_mlp_h2_pack (the packer writes kernel 1's fragments only while it is selected).  impl < 0 only queries.  Returns the previous setting. */
 int gs_sdf_mlp_h1_impl(int impl);
 int gs_sdf_mlp_h2_refine_rows(const float* x, const int32_t* rows, int64_t cap, const int64_t* count_dev,
                               const void* packed, int n_freq, int n_hidden, int skip_layer, float* out,
@@ -743,6 +747,8 @@ int gs_sdf_mlp_h2_refine_rows(const float* x, const int32_t* rows, int64_t cap, 
  *   of sample 16 t + i (c = 1..3), and ONE reverse pass over the virtual rows yields the parameter gradient of any loss of
  *   grad_x f (g_out = d loss / d out on the tangent rows, 0 on the value rows).  Rpad = gs_sdf_mlp_h2_rows_padded(mode, n).
  *   dW / db: HOST arrays of n_hidden + 2 DEVICE pointers (torch layout, output layer last), ACCUMULATED; db[last] untouched.
+ *   mode 2 is the forward-mode formulation of the eikonal term, superseded in round 4 by reverse over reverse (gs_sdf_eikonal_rr_* below) and since
+ *   round 6 an ORACLE formulation: its save_fwd / bwd instantiations exist in lib/variants/oracles.so only; the shipped library refuses mode 2.
  * ---------------------------------------------------------------------------------- */
 int64_t gs_sdf_mlp_h2_rows_padded(int mode, int64_t n);
 /*   Without a host sync (mode 1): gs_compact_rows turns d loss / d sdf [N] into (rows, g_rows, count) entirely on the device;

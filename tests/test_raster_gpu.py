@@ -115,6 +115,17 @@ def test_interpolate(A, Ba):
     assert torch.allclose(r.grad.cpu()[..., :2], r_ref.grad[..., :2], rtol=1e-4, atol=1e-5)
     out2, none = dr.interpolate(a, r, torch.tensor(tri, device=DEV))
     assert none is None and torch.equal(out2, out)
+    # diff_attrs as a list of attribute indices (nvdiffrast's other form; the reference passes 'all'): the chosen pairs, in the order given
+    pick = [A - 1, 0] if A > 1 else [0]
+    a3, r3 = attr.to(DEV).requires_grad_(True), rast_ref.to(DEV).requires_grad_(True)
+    out3, da3 = dr.interpolate(a3, r3, torch.tensor(tri, device=DEV), rast_db=db_ref.to(DEV), diff_attrs=pick)
+    cols = [c for i in pick for c in (2 * i, 2 * i + 1)]
+    assert torch.equal(out3, out) and da3.shape[-1] == 2 * len(pick) and torch.equal(da3, da[..., cols])
+    assert torch.allclose(da3.cpu(), da_ref[..., cols], rtol=1e-4, atol=1e-5)
+    (out3 * wgt.to(DEV)).sum().backward()                    # (the derivative output carries no gradient here, as on the reference's path: render.py:273-279 is no_grad)
+    assert (a3.grad - a.grad).abs().max() <= 1e-5 * a.grad.abs().max()      # float atomics: order differs between the two launches
+    with pytest.raises(ValueError):
+        dr.interpolate(a, r, torch.tensor(tri, device=DEV), rast_db=db_ref.to(DEV), diff_attrs=[A])
 
 
 @pytest.mark.parametrize("kind", ["soup", "sheet", "big"])
