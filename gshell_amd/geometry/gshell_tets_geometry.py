@@ -321,17 +321,20 @@ class GShellTetsGeometry(torch.nn.Module):
 
     def _launch_eikonal(self, pts):
         """sum_i (|grad f(p_i)| - 1)^2 over this rank's share of the surface samples (reference :302-324), launched as soon as the
-        samples exist.  It does not depend on the rendering, so FLAGS.eikonal_side_stream puts it on a SIDE STREAM (autograd
+        samples exist.  It does not depend on the rendering, so FLAGS.eikonal_side_stream can put it on a SIDE STREAM (autograd
         replays the backward there too): the chain kernels (matrix pipe, HBM planes) then share the chip with the render pass's
-        VALU-bound stages.  Measured on MI355X: round 2, 35.0 ms / iteration with the side stream against 34.7 without (off); round 6,
-        on the 14.7 ms iteration, 14.27 - 14.70 (mean 14.49 of 5 runs) with it against 14.61 - 15.13 (mean 14.75) without: on by default.
+        VALU-bound stages.  Measured on MI355X: round 2, 35.0 ms / iteration with the side stream against 34.7 without; round 6, on the
+        14.7 ms iteration, 14.49 (mean of 5 runs) with it against 14.75 without -- BUT with two queues active the rasteriser's z-buffer
+        showed stale 128-byte lines (16-pixel row strips resolving to another triangle: wrong geometric normals, a different
+        visible-triangle set) in 6 of 25 runs of the chain tests and in none of 25 without; the cause was not found in the time left
+        (every tensor involved is allocated and consumed on the stream that wrote it).  OFF by default; the flag stays for that work.
         -> (sum, number of samples of the GLOBAL batch, stream or None)"""
         FL = self.FLAGS
         shard = getattr(FL, "view_shard", None)
         n_total = pts.shape[0]
         if shard is not None and shard.world > 1:      # identical sample set on every rank (seeded): rank r takes samples r, r + world, ...
             pts = pts[shard.rank::shard.world].contiguous()
-        if getattr(FL, "eikonal_side_stream", True) and pts.is_cuda:
+        if getattr(FL, "eikonal_side_stream", False) and pts.is_cuda:
             main = torch.cuda.current_stream()
             side = getattr(self, "_side_stream", None)
             if side is None:

@@ -7,6 +7,7 @@ RCCL all-reduce of the flattened gradient per iteration.
     trainer = Trainer(flags, tet_grid=(verts, indices))
     losses  = trainer.step(target)          # target: dict(mvp [B,4,4], campos [B,3], img [B,H,W,4], background [B,H,W,3], resolution, spp)
 """
+import os
 import types
 
 import numpy as np
@@ -32,7 +33,9 @@ def default_flags(**overrides):
         lambda_kd=0.1, lambda_ks=0.05, lambda_nrm=0.025, lambda_chroma=0.0, lambda_diffuse=0.15, lambda_specular=0.0025,
         use_tanh_deform=False, use_sdf_mlp=True, use_msdf_mlp=False, use_eikonal=True, sdf_mlp_pretrain_steps=1000, use_mesh_msdf_reg=True,
         sphere_init=False, sphere_init_norm=0.5, n_hidden=6, d_hidden=256, n_freq=6, skip_in=[3], use_float16=False, visualize_watertight=False,
-        boxscale=[1, 1, 1], use_depth=False, use_img_2nd_layer=False, view_shard=None, shard_mlp_rows=True, seed=0, eikonal_side_stream=True, fused_assemble=True, sync_free_rows=False)
+        boxscale=[1, 1, 1], use_depth=False, use_img_2nd_layer=False, view_shard=None, shard_mlp_rows=True, seed=0, eikonal_side_stream=False, fused_assemble=True, sync_free_rows=False)
+    if os.environ.get("GSHELL_EIKONAL_SIDE_STREAM") in ("0", "1"):          # diagnostics: A / B of the side stream without touching the callers
+        F.eikonal_side_stream = os.environ["GSHELL_EIKONAL_SIDE_STREAM"] == "1"
     for k, v in overrides.items():
         setattr(F, k, v)
     return F

@@ -330,7 +330,7 @@ def _run_chain(name):
     flip_cap = 2.0 * float((g64[near].square().sum() / tot) ** 0.5)
     far_rel = float((e2r[~near].sum() / tot) ** 0.5)
     e32_v = float(z['g_v_pos_rel32'])
-    tail_excess = max(0.0, top_share - REL_FACTOR * e32_v)
+    tail_excess = max(0.0, 2.0 * top_share - REL_FACTOR * e32_v)      # (2 x: a parameter tensor is a linear image of these ten rows, not a norm-preserving one)
     print(f"  d/d v_pos vs float64: total {float((e2.sum() / tot) ** 0.5):.2e} (float32 oracle: {e32_v:.2e}); its 10 worst vertices carry {top_share:.2e} "
           f"({float(top.values.sum() / e2.sum().clamp_min(1e-300)):.2f} of the squared error; |g| / max |g| there: {[round(float(t), 3) for t in (g64[top.indices].norm(dim=-1) / g64.norm(dim=-1).max())]}); "
           f"without them: {int(near.sum())} vertices within 3 px of the {len(all_roots)} flipped samples carry {flip_share:.2e} (cap: 2 x the gradient living there = {flip_cap:.2e}), "
