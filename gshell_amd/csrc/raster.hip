@@ -19,6 +19,16 @@
 // workgroup each.  A per-pixel resolve pass recomputes barycentrics, z/w and their pixel
 // derivatives in fp32 from the clip-space vertices (2-D homogeneous form), which is also the
 // function whose analytic adjoint the backward kernel evaluates.
+//
+// GS_CXXFLAGS: -fno-slp-vectorize
+// ^ per-file compiler flag (csrc/Makefile): no packed-fp32 instructions in this file.  Round 6, MI355X: with hipcc's SLP vectoriser the per-sample
+// barycentric / depth arithmetic of k_rast_small becomes v_pk_mul_f32 / v_pk_add_f32 (op_sel / neg modifiers).  Stand-alone that code is deterministic
+// (thousands of frames, bit for bit).  While k_h2_fwd / k_h2_bwd of csrc/mlp_h2.hip run on ANOTHER HIP stream, single samples of a frame come out with a
+// wrong depth -- right pixel, right triangle, one packed product wrong (a0 of bary_eval in the self-checking build, GS_RAST_DEBUG=2) -- in 13 % / 71 % of
+// the frames (tools/raster_race_probe6.py), never under k_h1_fwd, k_h2_wgrad16, hipBLASLt GEMMs, a device copy or a synthetic scratch kernel, never with
+// agent- / system-scope z-buffer accesses making a difference (GS_RAST_COHERENT), never after a register-file poison (no uninitialised read), and never
+// (0 of 1000 frames, 0 of 25 chain-test runs with the eikonal side stream on) once this file is compiled without packed-fp32 instructions.  Same IEEE
+// results either way (-ffp-contract=off); the rasteriser is 0.06 ms of a 14.5 ms iteration.  The record: profiles/r06_two_queue_probes.txt; DESIGN.md 5.4.
 #include <hip/hip_runtime.h>
 
 #include "../../include/gshell_hip.h"
@@ -30,6 +40,28 @@ constexpr int SUBPIX_BITS = 8;
 constexpr int SUBPIX = 1 << SUBPIX_BITS;
 constexpr int LARGE_BBOX = 1024;  // pixels; larger bounding boxes go to the workgroup-per-triangle path
 constexpr float W_EPS = 1e-6f;
+
+// Diagnostic switch (tools/raster_race_probe.py): how the z-buffer words are written / read around the atomicMin pass.
+//   bit 0: k_rast_resolve reads the keys with agent-scope loads;  bit 1: k_rast_clear writes them with agent-scope stores;  bit 2: system-scope atomicMin
+#ifndef GS_RAST_COHERENT
+#define GS_RAST_COHERENT 0
+#endif
+GS_TUNABLE(GS_RAST_COHERENT, 0)
+
+// Diagnostic build (tools/raster_race_probe3.py): every sample k_rast_small issues is also logged with the operands its depth came from.
+#ifndef GS_RAST_DEBUG
+#define GS_RAST_DEBUG 0
+#endif
+GS_TUNABLE(GS_RAST_DEBUG, 0)
+constexpr int64_t RAST_DEBUG_CAP = 1 << 20;          // records of 16 words
+
+__device__ __forceinline__ void zkey_min(uint64_t* p, uint64_t key) {
+#if GS_RAST_COHERENT & 4
+    __hip_atomic_fetch_min((unsigned long long*)p, (unsigned long long)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    atomicMin((unsigned long long*)p, (unsigned long long)key);
+#endif
+}
 
 struct TriFix {  // fixed-point setup of one projected triangle
     int32_t x[3], y[3];
@@ -96,11 +128,42 @@ __device__ __forceinline__ EdgeEq edge_setup(int32_t ax, int32_t ay, int32_t bx,
 __device__ __forceinline__ bool edge_in(const EdgeEq& e, int64_t v) { return v > 0 || (v == 0 && e.own); }
 
 __device__ __forceinline__ void raster_sample(uint64_t* __restrict__ zrow, int px, int py, int H, int W, const float4 p0,
-                                              const float4 p1, const float4 p2, uint32_t tri_id) {
+                                              const float4 p1, const float4 p2, uint32_t tri_id, int32_t* dbg = nullptr, int view = 0) {
     Bary r = bary_eval(p0, p1, p2, pix_ndc(px, W), pix_ndc(py, H));
+#if GS_RAST_DEBUG == 1
+    if (dbg) {
+        int32_t slot = atomicAdd(dbg, 1);
+        if (slot < RAST_DEBUG_CAP) {
+            int32_t* q = dbg + 2 + 16 * (int64_t)slot;
+            q[0] = px; q[1] = py; q[2] = view; q[3] = (int32_t)tri_id; q[4] = __float_as_int(r.zw); q[5] = __float_as_int(pix_ndc(px, W)); q[6] = __float_as_int(pix_ndc(py, H));
+            q[7] = __float_as_int(p0.z); q[8] = __float_as_int(p1.z); q[9] = __float_as_int(p2.z); q[10] = __float_as_int(r.a0); q[11] = __float_as_int(r.a1);
+            q[12] = __float_as_int(r.a2); q[13] = W; q[14] = H; q[15] = __float_as_int(p0.w);
+        }
+    }
+#elif GS_RAST_DEBUG == 2
+    // self-check, logged only when it fails: the same depth from operands the compiler must treat as new (asm barriers), bit for bit
+    if (dbg) {
+        float4 q0 = p0, q1 = p1, q2 = p2;
+        asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
+        asm volatile("" : "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w));
+        Bary r2 = bary_eval(q0, q1, q2, pix_ndc(px, W), pix_ndc(py, H));
+        float z1 = p0.z * r.a0 + p1.z * r.a1 + p2.z * r.a2, w1 = p0.w * r.a0 + p1.w * r.a1 + p2.w * r.a2;
+        asm volatile("" : "+v"(z1), "+v"(w1));
+        const float zw3 = z1 / w1;
+        if (__float_as_int(r2.zw) != __float_as_int(r.zw) || __float_as_int(zw3) != __float_as_int(r.zw)) {
+            int32_t slot = atomicAdd(dbg, 1);
+            if (slot < RAST_DEBUG_CAP) {
+                int32_t* q = dbg + 2 + 16 * (int64_t)slot;
+                q[0] = px; q[1] = py; q[2] = view; q[3] = (int32_t)tri_id; q[4] = __float_as_int(r.zw); q[5] = __float_as_int(r2.zw); q[6] = __float_as_int(zw3);
+                q[7] = __float_as_int(z1); q[8] = __float_as_int(w1); q[9] = __float_as_int(r.a0); q[10] = __float_as_int(r2.a0); q[11] = __float_as_int(r.a1);
+                q[12] = __float_as_int(r2.a1); q[13] = __float_as_int(r.a2); q[14] = __float_as_int(r2.a2); q[15] = __float_as_int(r.s);
+            }
+        }
+    }
+#endif
     if (!(r.zw >= -1.0f && r.zw <= 1.0f)) return;  // near/far clip (also rejects NaN)
     uint64_t key = ((uint64_t)depth_key(r.zw) << 32) | tri_id;
-    atomicMin((unsigned long long*)&zrow[px], (unsigned long long)key);
+    zkey_min(&zrow[px], key);
 }
 
 struct TriJob {
@@ -155,7 +218,7 @@ __device__ __forceinline__ void raster_sample_homogeneous(uint64_t* __restrict__
     const float w = p0.w * r.b0 + p1.w * r.b1 + p2.w * b2;    // clip-space w of the point hit by the pixel's ray
     if (!(w > 0.0f) || !(r.zw >= -1.0f && r.zw <= 1.0f)) return;
     uint64_t key = ((uint64_t)depth_key(r.zw) << 32) | tri_id;
-    atomicMin((unsigned long long*)&zrow[px], (unsigned long long)key);
+    zkey_min(&zrow[px], key);
 }
 
 __device__ __forceinline__ int tri_setup(const float4* __restrict__ pos, const int32_t* __restrict__ tri, int64_t t, int64_t V, int H,
@@ -189,10 +252,17 @@ __device__ __forceinline__ int tri_setup(const float4* __restrict__ pos, const i
     return (j.x0 <= j.x1 && j.y0 <= j.y1) ? TRI_FIXED : TRI_REJECT;
 }
 
-__global__ void __launch_bounds__(256) k_rast_clear(uint64_t* __restrict__ zbuf, int64_t n, int32_t* __restrict__ qcount) {
+__global__ void __launch_bounds__(256) k_rast_clear(uint64_t* __restrict__ zbuf, int64_t n, int32_t* __restrict__ qcount, int32_t* __restrict__ dbg = nullptr) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *qcount = 0;
+#if GS_RAST_DEBUG
+    if (i == 0 && dbg) *dbg = 0;
+#endif
+#if GS_RAST_COHERENT & 2
+    for (; i < n; i += (int64_t)gridDim.x * blockDim.x) __hip_atomic_store((unsigned long long*)&zbuf[i], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
     for (; i < n; i += (int64_t)gridDim.x * blockDim.x) zbuf[i] = ~0ull;
+#endif
 }
 
 __global__ void __launch_bounds__(256) k_rast_small(const float4* __restrict__ pos, const int32_t* __restrict__ tri, int64_t B, int64_t V,
@@ -219,7 +289,11 @@ __global__ void __launch_bounds__(256) k_rast_small(const float4* __restrict__ p
         int64_t v2 = j.e2.A * cx0 + j.e2.B * cy + j.e2.C;
         for (int px = j.x0; px <= j.x1; ++px) {
             if (edge_in(j.e0, v0) && edge_in(j.e1, v1) && edge_in(j.e2, v2))
+#if GS_RAST_DEBUG
+                raster_sample(zview + (int64_t)py * W, px, py, H, W, j.p0, j.p1, j.p2, (uint32_t)t, (int32_t*)(queue + B * T), (int)b);
+#else
                 raster_sample(zview + (int64_t)py * W, px, py, H, W, j.p0, j.p1, j.p2, (uint32_t)t);
+#endif
             v0 += j.e0.A * SUBPIX;
             v1 += j.e1.A * SUBPIX;
             v2 += j.e2.A * SUBPIX;
@@ -265,7 +339,11 @@ __global__ void __launch_bounds__(256) k_rast_resolve(const float4* __restrict__
     int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t npix = B * (int64_t)H * W;
     if (pix >= npix) return;
+#if GS_RAST_COHERENT & 1
+    uint64_t key = __hip_atomic_load((const unsigned long long*)&zbuf[pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
     uint64_t key = zbuf[pix];
+#endif
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
     if (key != ~0ull) {
         uint32_t t = (uint32_t)(key & 0xffffffffu);
@@ -618,7 +696,7 @@ extern "C" int gs_xfm_points_bwd(const float* g_out, int64_t Bp, const float* mt
 }
 
 extern "C" int64_t gs_rasterize_scratch_bytes(int64_t B, int64_t T, int64_t H, int64_t W) {
-    return B * H * W * 8 + 16 + B * T * 8;
+    return B * H * W * 8 + 16 + B * T * 8 + (GS_RAST_DEBUG ? 8 + RAST_DEBUG_CAP * 64 : 0);
 }
 
 extern "C" int gs_rasterize_fwd(const float* pos_clip, int64_t B, int64_t V, const int32_t* tri, int64_t T, int64_t H, int64_t W,
@@ -632,7 +710,8 @@ extern "C" int gs_rasterize_fwd(const float* pos_clip, int64_t B, int64_t V, con
     uint64_t* zbuf = (uint64_t*)scratch;
     int32_t* qcount = (int32_t*)(zbuf + npix);
     int64_t* queue = (int64_t*)(zbuf + npix + 2);
-    hipLaunchKernelGGL(k_rast_clear, dim3((unsigned)std::min<int64_t>(gs::cdiv(npix, 256), 4096)), dim3(256), 0, stream, zbuf, npix, qcount);
+    hipLaunchKernelGGL(k_rast_clear, dim3((unsigned)std::min<int64_t>(gs::cdiv(npix, 256), 4096)), dim3(256), 0, stream, zbuf, npix, qcount,
+                       GS_RAST_DEBUG ? (int32_t*)(queue + B * T) : (int32_t*)nullptr);
     if (T > 0 && V > 0) {
         GS_REQUIRE(pos_clip && tri, "gs_rasterize_fwd: null mesh pointer");
         hipLaunchKernelGGL(k_rast_small, dim3((unsigned)gs::cdiv(B * T, 256)), dim3(256), 0, stream, (const float4*)pos_clip, tri, B, V, T,

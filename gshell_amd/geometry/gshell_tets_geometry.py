@@ -324,10 +324,13 @@ class GShellTetsGeometry(torch.nn.Module):
         samples exist.  It does not depend on the rendering, so FLAGS.eikonal_side_stream can put it on a SIDE STREAM (autograd
         replays the backward there too): the chain kernels (matrix pipe, HBM planes) then share the chip with the render pass's
         VALU-bound stages.  Measured on MI355X: round 2, 35.0 ms / iteration with the side stream against 34.7 without; round 6, on the
-        14.7 ms iteration, 14.49 (mean of 5 runs) with it against 14.75 without -- BUT with two queues active the rasteriser's z-buffer
-        showed stale 128-byte lines (16-pixel row strips resolving to another triangle: wrong geometric normals, a different
-        visible-triangle set) in 6 of 25 runs of the chain tests and in none of 25 without; the cause was not found in the time left
-        (every tensor involved is allocated and consumed on the stream that wrote it).  OFF by default; the flag stays for that work.
+        14.7 ms iteration, 14.49 (mean of 5 runs) with it against 14.75 without.  OFF by default all the same: while k_h2_fwd / k_h2_bwd
+        (the chain) run on another queue, packed-fp32 arithmetic of the rasteriser's k_rast_small returned wrong products now and then
+        (single samples with a wrong depth in 13 - 71 % of the frames of tools/raster_race_probe6.py: 6 of 25 chain-test runs failed on
+        their visible-triangle sets; none of 40 without the side stream).  The rasteriser is immune since (raster.hip is compiled without
+        packed-fp32 instructions: 0 of 1000 frames, 0 of 25 runs), but what makes a co-resident kernel a victim is not understood, and
+        the render pass's other kernels were not audited -- so nothing of the product runs two kernels at once.  Record:
+        profiles/r06_two_queue_probes.txt, DESIGN.md 5.4.
         -> (sum, number of samples of the GLOBAL batch, stream or None)"""
         FL = self.FLAGS
         shard = getattr(FL, "view_shard", None)

@@ -10,7 +10,9 @@ objs=""
 for o in gshell_amd/lib/obj/*.o; do
   b=$(basename "$o" .o)
   if [ "$b.hip" = "$src" ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-value -Wno-unused-result "$@" \
+    fileflags=$(sed -n 's|^// GS_CXXFLAGS: ||p' "gshell_amd/csrc/$src")       # the source's own per-file flags (csrc/Makefile); GS_NO_FILEFLAGS=1 drops them
+    [ -n "$GS_NO_FILEFLAGS" ] && fileflags=""
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-value -Wno-unused-result $fileflags "$@" \
       -c "gshell_amd/csrc/$src" -o "/tmp/gs_variant_$name/$b.o"
     objs="$objs /tmp/gs_variant_$name/$b.o"
   else
