@@ -128,3 +128,24 @@ def test_bench_runs_two_ranks_over_rccl():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
     assert r["n_gpus"] == 2 and r["steps"] == 3 and r["value"] > 0 and r["scaling"] == "weak"
+
+
+def test_bench_multi_rank_plumbing_with_two_ranks_on_one_device():
+    """What the driver's `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` exercises beyond a single-GPU run -- the launcher's environment,
+    the process group, sharded views and SDF rows, the barrier + max-over-ranks timing, rank 0's ONE JSON line -- on the one-device box: GSHELL_BENCH_SAME_DEVICE=1
+    puts both ranks on device 0 over gloo (RCCL refuses two ranks on one device).  The line says it is not a performance number."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GSHELL_BENCH_SAME_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--res", "64", "--fit-steps", "60", "--early-steps", "0", "--extra-steps", "0",
+                          "--no-cpu-baseline", "--no-reference-config"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"{len(lines)} JSON lines (only rank 0 prints)"
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["value"] > 0 and r["scaling"] == "weak" and "PLUMBING TEST" in r["data"]
+    assert r["config"]["global_batch"] == 2 * r["config"]["views_per_gpu"]
