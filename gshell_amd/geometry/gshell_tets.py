@@ -24,7 +24,9 @@ from .._lib import c_int64, c_void_p, check, ptr, stream
 class TetTopology:
     """Static per-grid topology living in HBM (sorted unique edges, tet->edge table)."""
 
-    def __init__(self, tet_fx4: torch.Tensor, num_verts: int):
+    def __init__(self, tet_fx4: torch.Tensor, num_verts: int, uv_tets: int = None):
+        """`uv_tets`: the tet count the tangents' uv atlas is sized by (reference :301-309: `num_tets` of the WHOLE grid even when the valid tets were
+        pre-filtered) -- default: this topology's own tet count."""
         if tet_fx4.dtype != torch.int64:
             tet_fx4 = tet_fx4.long()
         tet_fx4 = tet_fx4.contiguous()
@@ -43,7 +45,8 @@ class TetTopology:
         self.E = int(e.value)
         self._edges = None
         self.sign_epoch = 0          # bumped by every writer of the occupancy bits
-        nuv = int(math.ceil(math.sqrt((2 * self.F + 1) // 2))) if self.F > 0 else 1
+        f_uv = self.F if uv_tets is None else int(uv_tets)
+        nuv = int(math.ceil(math.sqrt((2 * f_uv + 1) // 2))) if f_uv > 0 else 1
         self.Nuv = nuv
         # torch.linspace(0, 1 - 1/N, N): the uv atlas axis of the reference's map_uv (gshell_tets.py:211-216)
         self.uv_lin = torch.linspace(0, 1 - (1 / nuv), nuv, dtype=torch.float32, device=self.device)
@@ -184,8 +187,7 @@ class GShell_Tets:
 
     def __call__(self, pos_nx3, sdf_n, msdf_n, tet_fx4, output_watertight_template=True):
         if not output_watertight_template:
-            raise NotImplementedError("output_watertight_template=False (mSDF pre-filter, gshell_tets.py:263) is never used "
-                                      "by the reference's call sites and is not implemented")
+            return self._without_watertight_template(pos_nx3, sdf_n, msdf_n, tet_fx4)
         topo = self.topology(tet_fx4, pos_nx3.shape[0])
         # fused geometry front end: an sdf tensor that comes straight out of the SDF-network kernel carries the tag of the
         # occupancy bits its epilogue wrote into THIS topology; any later writer of those bits invalidates the tag (epoch)
@@ -208,6 +210,29 @@ class GShell_Tets:
             'faces_i32': faces_i32,
             'polygon_tet_id': tet_id,
         }
+        return verts_aug, faces_aug, None, None, v_tng_aug, extra
+
+    def _without_watertight_template(self, pos_nx3, sdf_n, msdf_n, tet_fx4):
+        """output_watertight_template=False (reference gshell_tets.py:256-263, :436-441): tets whose four mSDF values are all <= 0 are dropped before anything
+        else, so the edge set -- and with it the vertex numbering -- is that of the remaining tets, and `extra` carries the three mSDF entries only.  No call
+        site of the reference passes False, so this is the plain route: the surviving tets form a topology of their own, built for this call (its edge list is
+        sorted on the device every time; the static topology of the default mode is what makes that mode fast), and the same kernels run on it."""
+        with torch.no_grad():
+            keep = (msdf_n.detach().reshape(-1)[tet_fx4.reshape(-1)].reshape(-1, 4) > 0).sum(-1) > 0
+            tets = tet_fx4[keep].contiguous()
+        if tets.shape[0] == 0:        # nothing survives: the reference's gathers over empty index sets (:264-443)
+            f32 = dict(dtype=torch.float32, device=pos_nx3.device)
+            z3, z1 = torch.zeros((0, 3), **f32), torch.zeros((0,), **f32)
+            extra = {'msdf': z1, 'msdf_watertight': z1, 'msdf_boundary': z1, 'faces_i32': torch.zeros((0, 3), dtype=torch.int32, device=pos_nx3.device)}
+            return z3, torch.zeros((0, 3), dtype=torch.long, device=pos_nx3.device), None, None, z3, extra
+        topo = TetTopology(tets, pos_nx3.shape[0], uv_tets=tet_fx4.shape[0])
+        topo.sign_epoch += 1
+        verts_aug, msdf_aug, verts_wt, faces_aug, faces_wt, faces_i32, v_tng_aug, tet_id = _MarchingTetsFn.apply(
+            pos_nx3, sdf_n, msdf_n, topo, self.compute_tangents, False)
+        V = verts_wt.shape[0]
+        extra = {'msdf': msdf_aug, 'msdf_watertight': msdf_aug[:V], 'msdf_boundary': msdf_aug[V:],
+                 # extras of this implementation (polygon_tet_id indexes the SURVIVING tets)
+                 'faces_i32': faces_i32, 'polygon_tet_id': tet_id}
         return verts_aug, faces_aug, None, None, v_tng_aug, extra
 
     @torch.no_grad()

@@ -72,6 +72,41 @@ def test_hip_matches_reference_golden(path):
     _compare(out, g, tets.shape[0])
 
 
+NOWT_FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mtetsnowt_*.npz")))
+
+
+@pytest.mark.parametrize("path", NOWT_FILES, ids=[os.path.basename(p)[10:-4] for p in NOWT_FILES])
+def test_hip_matches_reference_golden_without_the_watertight_template(path):
+    """GShell_Tets()(..., output_watertight_template=False) against the real reference's output (gshell_tets.py:256-263, :436-441): topology bit-exact (vertex
+    numbering of the mSDF-filtered tet set), forward floats bit-exact, gradients to 1e-4, three mSDF entries in `extra`; one case filters every tet away."""
+    from gshell_amd.geometry.gshell_tets import GShell_Tets
+    g = np.load(path)
+    verts, tets, sdf, msdf = golden_inputs(g)
+    dev = torch.device("cuda")
+    pos = torch.tensor(verts, device=dev, requires_grad=True)
+    s = torch.tensor(sdf, device=dev, requires_grad=True)
+    m = torch.tensor(msdf, device=dev, requires_grad=True)
+    v_aug, f_aug, uvs, uv_idx, tng, extra = GShell_Tets()(pos, s, m, torch.tensor(tets, dtype=torch.long, device=dev), output_watertight_template=False)
+    assert uvs is None and uv_idx is None and f_aug.dtype == torch.int64
+    assert {"msdf", "msdf_watertight", "msdf_boundary"} <= set(extra) and not any("watertight" in k and k != "msdf_watertight" for k in extra)
+    np.testing.assert_array_equal(f_aug.cpu().numpy().reshape(-1, 3), g["faces_aug"].reshape(-1, 3))
+    for k, t in (("verts_aug", v_aug), ("msdf", extra["msdf"]), ("msdf_watertight", extra["msdf_watertight"]), ("msdf_boundary", extra["msdf_boundary"])):
+        np.testing.assert_array_equal(t.detach().cpu().numpy().reshape(g[k].shape), g[k], err_msg=k)
+    V = int(g["msdf_watertight"].shape[0])
+    if V:
+        # tangents: float atomics on both sides; the watertight faces that condition them are those of the filtered tet set (oracle, pinned to this golden on the CPU)
+        o = mtets_oracle.extract(torch.tensor(verts), torch.tensor(sdf), torch.tensor(msdf), torch.tensor(tets), output_watertight_template=False)
+        assert_tangents_match(tng.detach().cpu().numpy(), g["v_tng_aug"], o["_vertices_watertight"].numpy(), o["_faces_watertight"].numpy(), tets.shape[0])      # the uv atlas is sized by the WHOLE grid (ref :301, :309)
+    wv, wm, _ = fields.loss_weights(v_aug.shape[0], V, int(g["seed"]))
+    loss = (v_aug * torch.tensor(wv, device=dev)).sum() + (extra["msdf"] * torch.tensor(wm, device=dev)).sum()
+    if loss.requires_grad:
+        loss.backward()
+    for name, t in (("grad_pos", pos), ("grad_sdf", s), ("grad_msdf", m)):
+        r = g[name]
+        got = t.grad.reshape(r.shape).cpu().numpy() if t.grad is not None else np.zeros_like(r)
+        np.testing.assert_allclose(got, r, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(r).max())), err_msg=name)
+
+
 def _oracle(verts, tets, sdf, msdf, seed):
     pos = torch.tensor(verts, requires_grad=True)
     s = torch.tensor(sdf, requires_grad=True)
