@@ -104,6 +104,62 @@ __global__ void __launch_bounds__(256) k_aggressor(float* __restrict__ sink, int
     if (s == 1.2345e-30f) sink[0] = s;
 }
 
+// ONE kernel, ONE queue: even blocks play the aggressor (40 KB of LDS each, like k_aggressor), odd blocks the bary_eval victim -- is a second QUEUE needed, or only
+// co-resident waves of the two kinds?
+__global__ void __launch_bounds__(256) k_both(float* __restrict__ sink, int aggr_rounds, int rounds, uint32_t seed, unsigned long long* __restrict__ counts) {
+    __shared__ float lds[10240];
+    if ((blockIdx.x & 1) == 0) {
+        const int tid = threadIdx.x;
+        float x0 = 0.37f + tid * 1e-3f, x1 = x0 * 1.5f;
+        v2f p = {x0, x1}, q = {x0 - 0.25f, x1 + 0.125f};
+        v16f acc = {};
+        h8 ha, hb;
+        for (int i = 0; i < 8; ++i) { ha[i] = (_Float16)(x0 + i); hb[i] = (_Float16)(x1 - i); }
+        lds[tid] = x0;
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < aggr_rounds; ++r) {
+            asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]\n\tv_pk_add_f32 %1, %1, %0\n\t" : "+v"(p), "+v"(q));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, acc, 0, 0, 0);
+        }
+        float s = p[0] + p[1] + q[0] + q[1] + lds[(tid + 1) & 4095];
+        for (int i = 0; i < 16; ++i) s += acc[i];
+        if (s == 1.2345e-30f) sink[0] = s;
+        return;
+    }
+    uint32_t s = seed ^ ((blockIdx.x * 256u + threadIdx.x) * 0x9e3779b9u);
+    float4 p0 = make_float4(unit(lcg(s)) - 0.75f, unit(lcg(s)) - 0.75f, unit(lcg(s)) + 1.0f, unit(lcg(s)) + 1.5f);
+    float4 p1 = make_float4(p0.x + 0.01f * unit(lcg(s)), p0.y - 0.004f * unit(lcg(s)), p0.z + 0.01f, p0.w + 0.012f);
+    float4 p2 = make_float4(p0.x - 0.003f * unit(lcg(s)), p0.y + 0.009f * unit(lcg(s)), p0.z - 0.008f, p0.w - 0.01f);
+    unsigned bad = 0;
+#pragma unroll 1
+    for (int r = 0; r < rounds; ++r) {
+        if ((lcg(s) & 0x30000u) != 0) continue;
+        const float fx = (p0.x / p0.w) + 0.002f * (unit(lcg(s)) - 0.75f), fy = (p0.y / p0.w) + 0.002f * (unit(lcg(s)) - 0.75f);
+        Bary r1 = bary_eval(p0, p1, p2, fx, fy);
+        float4 q0 = p0, q1 = p1, q2 = p2;
+        float gx = fx, gy = fy;
+        asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
+        asm volatile("" : "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(gx), "+v"(gy));
+        Bary r2 = bary_eval(q0, q1, q2, gx, gy);
+        bad += (__float_as_uint(r1.a0) != __float_as_uint(r2.a0)) | (__float_as_uint(r1.a1) != __float_as_uint(r2.a1)) | (__float_as_uint(r1.a2) != __float_as_uint(r2.a2)) |
+               (__float_as_uint(r1.zw) != __float_as_uint(r2.zw));
+    }
+    if (bad) atomicAdd(&counts[0], (unsigned long long)bad);
+}
+
+static int run_both(const char* label, int iters, hipStream_t s1, unsigned long long* counts, float* sink) {
+    CHECK(hipMemsetAsync(counts, 0, 16, s1));
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL(k_both, dim3(4096), dim3(256), 0, s1, sink, 1500, 450, 777u + it, counts);
+        CHECK(hipStreamSynchronize(s1));
+    }
+    unsigned long long h[2];
+    CHECK(hipMemcpy(h, counts, 16, hipMemcpyDeviceToHost));
+    printf("  %-78s samples whose evaluations differ: %llu   (of %.3g samples)\n", label, h[0], (double)iters * 2048 * 256 * 450 * 0.25);
+    return 0;
+}
+
 template <bool PACKED, bool DIVERGENT = false, bool BARY = false>
 static int run(const char* label, int aggr_mode, int iters, hipStream_t s1, hipStream_t s2, unsigned long long* counts, float* sink) {
     CHECK(hipMemsetAsync(counts, 0, 16, s1));
@@ -149,5 +205,6 @@ int main(int argc, char** argv) {
     if (run<true, true, true>("victim = bary_eval twice, second queue: MFMA only", 2, iters, s1, s2, counts, sink)) return 1;
     if (run<true, true, true>("victim = bary_eval twice, second queue: packed fp32 + MFMA", 3, iters, s1, s2, counts, sink)) return 1;
     if (run<true>("victim with packed fp32, second queue idle (again)", 0, iters, s1, s2, counts, sink)) return 1;
+    if (run_both("ONE kernel on ONE queue: even blocks aggressor, odd blocks bary_eval victim", iters, s1, counts, sink)) return 1;
     return 0;
 }
