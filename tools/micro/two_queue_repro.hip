@@ -9,6 +9,15 @@
 #include <cstdio>
 #include <cstdlib>
 
+// -DSAME_VGPRS: both kernels of the two-stream configurations touch v255, i.e. get the same (maximal) architectural register allocation -- is it the MIX of
+// allocation sizes on a SIMD that matters?
+#define REGS
+#ifdef SAME_VGPRS
+#define PAD_REGS() asm volatile("v_mov_b32 v255, 0" ::: "v255")
+#else
+#define PAD_REGS()
+#endif
+
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -60,12 +69,13 @@ __device__ __forceinline__ Bary bary_eval(const float4 p0, const float4 p1, cons
     r.zw = z / w;
     return r;
 }
-__global__ void __launch_bounds__(256) k_victim_bary(int rounds, uint32_t seed, unsigned long long* __restrict__ counts) {
+__global__ void __launch_bounds__(256) REGS k_victim_bary(int rounds, uint32_t seed, unsigned long long* __restrict__ counts) {
     uint32_t s = seed ^ ((blockIdx.x * 256u + threadIdx.x) * 0x9e3779b9u);
     float4 p0 = make_float4(unit(lcg(s)) - 0.75f, unit(lcg(s)) - 0.75f, unit(lcg(s)) + 1.0f, unit(lcg(s)) + 1.5f);
     float4 p1 = make_float4(p0.x + 0.01f * unit(lcg(s)), p0.y - 0.004f * unit(lcg(s)), p0.z + 0.01f, p0.w + 0.012f);
     float4 p2 = make_float4(p0.x - 0.003f * unit(lcg(s)), p0.y + 0.009f * unit(lcg(s)), p0.z - 0.008f, p0.w - 0.01f);
     unsigned bad = 0;
+    PAD_REGS();
 #pragma unroll 1
     for (int r = 0; r < rounds; ++r) {
         if ((lcg(s) & 0x30000u) != 0) continue;                      // a quarter of the lanes per round (coverage-test divergence)
@@ -84,7 +94,7 @@ __global__ void __launch_bounds__(256) k_victim_bary(int rounds, uint32_t seed, 
 
 // AGGRESSOR: mode bit 0 = two packed-fp32 instructions per round, bit 1 = one dependent MFMA per round
 template <int MODE>
-__global__ void __launch_bounds__(256) k_aggressor(float* __restrict__ sink, int rounds) {
+__global__ void __launch_bounds__(256) REGS k_aggressor(float* __restrict__ sink, int rounds) {
     __shared__ float lds[10240];          // 40 KB: four blocks per CU, half of the wave slots stay free for the other queue
     const int tid = threadIdx.x;
     float x0 = 0.37f + tid * 1e-3f, x1 = x0 * 1.5f;
@@ -93,6 +103,7 @@ __global__ void __launch_bounds__(256) k_aggressor(float* __restrict__ sink, int
     h8 ha, hb;
     for (int i = 0; i < 8; ++i) { ha[i] = (_Float16)(x0 + i); hb[i] = (_Float16)(x1 - i); }
     lds[tid] = x0;
+    PAD_REGS();
     __syncthreads();
 #pragma unroll 1
     for (int r = 0; r < rounds; ++r) {
