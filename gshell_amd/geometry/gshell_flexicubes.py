@@ -153,8 +153,9 @@ class GShellFlexiCubes:
     # ---- extraction ----------------------------------------------------------------------------------------
     def __call__(self, x_nx3, s_n, nu_n, cube_fx8, res, beta_fx12=None, alpha_fx8=None, gamma_f=None, training=False, output_tetmesh=False,
                  grad_func=None):
-        if training or output_tetmesh or grad_func is not None:
-            raise NotImplementedError("training=True / output_tetmesh / grad_func are never used by the G-Shell scripts (SURVEY.md 3.4)")
+        if output_tetmesh or grad_func is not None:
+            raise NotImplementedError("output_tetmesh (the reference itself raises, gshell_flexicubes.py:224) / grad_func (the non-differentiable QEF mode) are never "
+                                      "used by the G-Shell scripts (SURVEY.md 3.4)")
         L = _lib.lib()
         dev = x_nx3.device
         topo = self.topology(cube_fx8, x_nx3.shape[0], res)
@@ -207,6 +208,28 @@ class GShellFlexiCubes:
             faces = torch.empty((2 * n_quads, 3), dtype=torch.int64, device=dev)
             check(L.gs_flexi_quads(ptr(flags), ptr(qrank), ptr(topo.inc), ptr(vd_idx_map), ptr(vd_gamma), c_int64(E), ptr(faces), ptr(None),
                                    stream()), "gs_flexi_quads")
+
+        if training:
+            # ---- training=True (:523-551; no call site of the G-Shell scripts sets it): every quad becomes a fan of four triangles around a centre vertex -- the
+            # midpoints of its two diagonals weighted by the products of the opposite gammas.  The quads are read back from the kernel's two triangles per quad
+            # ((q0,q1,q2),(q0,q2,q3) or (q0,q1,q3),(q3,q1,q2): the second starts with q0 only in the first form); the rest is the reference's own arithmetic in its
+            # own order, differentiable w.r.t. vd, nu_d and -- unlike the two-triangle split -- gamma.
+            with torch.no_grad():
+                f0, f1 = faces[0::2], faces[1::2]
+                first = f1[:, 0] == f0[:, 0]
+                quads = torch.where(first[:, None], torch.stack([f0[:, 0], f0[:, 1], f0[:, 2], f1[:, 2]], -1), torch.stack([f0[:, 0], f0[:, 1], f1[:, 2], f0[:, 2]], -1))
+            g = gamma[vd_cube.long()][quads]                                                  # [Q,4], ONE use of gamma per dual vertex (:421)
+            g02, g13 = g[:, 0:1] * g[:, 2:3], g[:, 1:2] * g[:, 3:4]
+            vq, nq, nsq = vd[quads], nu_d[quads], nu_d_sv[quads]                             # [Q,4,3], [Q,4,1], [Q,4,1]
+            mid = lambda t, a, b: (t[:, a:a + 1] + t[:, b:b + 1]) / 2
+            wsum = (g02 + g13) + 1e-8
+            vd_c = ((mid(vq, 0, 2) * g02.unsqueeze(-1) + mid(vq, 1, 3) * g13.unsqueeze(-1)) / wsum.unsqueeze(-1)).squeeze(1)
+            nu_c = ((mid(nq, 0, 2) * g02.unsqueeze(-1) + mid(nq, 1, 3) * g13.unsqueeze(-1)) / wsum.unsqueeze(-1)).squeeze(1)
+            nus_c = ((mid(nsq, 0, 2) * g02.unsqueeze(-1).detach() + mid(nsq, 1, 3) * g13.unsqueeze(-1).detach()) / wsum.unsqueeze(-1).detach()).squeeze(1)
+            centre = torch.arange(quads.shape[0], device=dev) + n_vd
+            vd, nu_d, nu_d_sv = torch.cat([vd, vd_c]), torch.cat([nu_d, nu_c]), torch.cat([nu_d_sv, nus_c])
+            faces = torch.cat([quads[:, [0, 1, 1, 2, 2, 3, 3, 0]].reshape(-1, 4, 2), centre.reshape(-1, 1, 1).repeat(1, 4, 1)], -1).reshape(-1, 3)
+            n_vd = int(vd.shape[0])                                                          # the cut numbers its vertices after ALL of these (:577)
 
         # ---- mSDF cut (:554-599)
         extra = {'n_verts_watertight': n_vd, 'vertices_watertight': vd, 'faces_watertight': faces, 'msdf_watertight': nu_d}

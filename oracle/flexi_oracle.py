@@ -63,7 +63,7 @@ def _interp(wa, wb, xa, xb):
     return (xa * wb - xb * wa) / (wb - wa)
 
 
-def extract(x, s, nu, cubes, res, beta=None, alpha=None, gamma=None, topo=None, weight_scale=0.99):
+def extract(x, s, nu, cubes, res, beta=None, alpha=None, gamma=None, topo=None, weight_scale=0.99, training=False):
     N, F = x.shape[0], cubes.shape[0]
     s1 = s.reshape(-1)
     nu1 = nu.reshape(-1)
@@ -136,7 +136,8 @@ def extract(x, s, nu, cubes, res, beta=None, alpha=None, gamma=None, topo=None, 
     n_edges = torch.zeros(n_vd, dtype=dt).index_add(0, ent_vd, torch.ones_like(dist))
     mean_l2 = torch.zeros(n_vd, dtype=dt).index_add(0, ent_vd, dist) / n_edges
     L_dev = (dist - mean_l2[ent_vd]).abs()
-    vd_gamma = torch.zeros(n_vd, dtype=dt).index_put((ent_vd,), gamma[ent_cube])
+    vd_cube = torch.zeros(n_vd, dtype=torch.long).index_put((ent_vd,), ent_cube)      # the cube of each dual vertex (all of a vertex's entries name the same cube)
+    vd_gamma = gamma[vd_cube]                                                         # ONE use of gamma per dual vertex (:421): its gradient counts (training=True)
     vd_idx_map = torch.full((F, 12), -1, dtype=torch.long)
     vd_idx_map[ent_cube, ent_e] = ent_vd
 
@@ -146,8 +147,23 @@ def extract(x, s, nu, cubes, res, beta=None, alpha=None, gamma=None, topo=None, 
     flip = s1[edges[qe, 0]] > 0
     quads = torch.cat([q[flip][:, [0, 1, 3, 2]], q[~flip][:, [2, 3, 1, 0]]])
     g = vd_gamma[quads]
-    first = (g[:, 0] * g[:, 2]) > (g[:, 1] * g[:, 3])
-    faces = torch.where(first[:, None], quads[:, [0, 1, 2, 0, 2, 3]], quads[:, [0, 1, 3, 3, 1, 2]]).reshape(-1, 3)
+    if training:
+        # :523-551: a centre vertex per quad, the diagonals' midpoints weighted by the products of the opposite gammas; four fan triangles per quad
+        g02, g13 = g[:, 0:1] * g[:, 2:3], g[:, 1:2] * g[:, 3:4]                         # [Q,1]
+        vq, nq, nsq = vd[quads], nu_d[quads], nu_d_sv[quads]                           # [Q,4,3], [Q,4,1], [Q,4,1]
+        mid = lambda t, a, b: (t[:, a:a + 1] + t[:, b:b + 1]) / 2
+        wsum = (g02 + g13) + 1e-8
+        vd_c = ((mid(vq, 0, 2) * g02.unsqueeze(-1) + mid(vq, 1, 3) * g13.unsqueeze(-1)) / wsum.unsqueeze(-1)).squeeze(1)
+        nu_c = ((mid(nq, 0, 2) * g02.unsqueeze(-1) + mid(nq, 1, 3) * g13.unsqueeze(-1)) / wsum.unsqueeze(-1)).squeeze(1)
+        nus_c = ((mid(nsq, 0, 2) * g02.unsqueeze(-1).detach() + mid(nsq, 1, 3) * g13.unsqueeze(-1).detach()) / wsum.unsqueeze(-1).detach()).squeeze(1)
+        centre = torch.arange(quads.shape[0]) + n_vd
+        vd, nu_d, nu_d_sv = torch.cat([vd, vd_c]), torch.cat([nu_d, nu_c]), torch.cat([nu_d_sv, nus_c])
+        faces = torch.cat([quads[:, [0, 1, 1, 2, 2, 3, 3, 0]].reshape(-1, 4, 2), centre.reshape(-1, 1, 1).repeat(1, 4, 1)], -1).reshape(-1, 3)
+        n_vd_dual, n_vd = n_vd, int(vd.shape[0])                                        # the cut numbers its vertices after ALL of these (:577)
+    else:
+        first = (g[:, 0] * g[:, 2]) > (g[:, 1] * g[:, 3])
+        faces = torch.where(first[:, None], quads[:, [0, 1, 2, 0, 2, 3]], quads[:, [0, 1, 3, 3, 1, 2]]).reshape(-1, 3)
+        n_vd_dual = n_vd
 
     # ---- mSDF cut of the triangles (:554-599)
     mocc = (nu_d.detach() >= 0).reshape(-1)[faces]
@@ -183,8 +199,9 @@ def extract(x, s, nu, cubes, res, beta=None, alpha=None, gamma=None, topo=None, 
         #   |dx| <~ eps |x_a - x_b| (|nu_b| A_a + |nu_a| A_b) / (nu_b - nu_a)^2.
         # Large (i) on edges whose end points lie on the SAME side of the cut (every edge of a cut triangle gets a vertex; those
         # extrapolate and no face references them) and (ii) where both values are noise around zero.
-        A = torch.zeros(n_vd, 1, dtype=dt).index_add(0, ent_vd, (nu_e_sv * bt).abs().detach())
+        A = torch.zeros(n_vd_dual, 1, dtype=dt).index_add(0, ent_vd, (nu_e_sv * bt).abs().detach())
         A = (A * (1.0 + 1.0 / beta_sum.detach())).reshape(-1)
+        A = torch.cat([A, torch.zeros(n_vd - n_vd_dual, dtype=dt)])                    # training: centre vertices (averages of four dual vertices) carry no estimate of their own
         wa, wb = nu_d[pa].reshape(-1), nu_d[pb].reshape(-1)
         den2 = (wb - wa) ** 2
         amp = torch.where(den2 > 0, (wb.abs() * A[pa] + wa.abs() * A[pb]) / den2.clamp_min(1e-38), torch.zeros_like(den2))

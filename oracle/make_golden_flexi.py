@@ -47,17 +47,22 @@ CASES = [("r6_sphere_pos_ones", 6, "sphere", "positive", "ones", 1), ("r6_noisy_
          ("r7_sphere_negative_ones", 7, "sphere", "negative", "ones", 5), ("r5_empty", 5, "empty", "positive", "ones", 6)]
 
 
+# training=True (gshell_flexicubes.py:523-551: every quad becomes a fan of four triangles around a gamma-weighted centre vertex) -> tests/golden/flexitrain_*.npz
+TRAIN_CASES = [("r6_noisy_half_rand", 6, "noisy", "half", "rand", 2), ("r8_two_rand_rand", 8, "two", "rand", "rand", 3), ("r10_noisy_rand_rand", 10, "noisy", "rand", "rand", 4),
+               ("r7_sphere_negative_ones", 7, "sphere", "negative", "ones", 5)]
+
+
 def main():
     mod = refload.load_flexicubes()
     with refload.CudaToCpu():
         fc = mod.GShellFlexiCubes(device="cpu")
-        for name, res, sk, mk, wk, seed in CASES:
+        for name, res, sk, mk, wk, seed, training in [c + (False,) for c in CASES] + [c + (True,) for c in TRAIN_CASES]:
             verts, cubes = fc.construct_voxel_grid(res)
             x, s, nu, w = make_inputs(res, sk, mk, wk, seed)
             # the recipe's grid order must be the reference's own vertex order
             assert np.allclose(verts.numpy(), (x * 0 + (np.stack(np.meshgrid(*(np.arange(res + 1),) * 3, indexing="ij"), -1).reshape(-1, 3) / res - 0.5)), atol=1e-5)
             X, S, NU, Wt = (torch.tensor(a, requires_grad=True) for a in (x, s[:, None], nu, w))
-            out = fc(X, S, NU, cubes, res, Wt[:, :12], Wt[:, 12:20], Wt[:, 20], training=False)
+            out = fc(X, S, NU, cubes, res, Wt[:, :12], Wt[:, 12:20], Wt[:, 20], training=training)
             rec = dict(res=res, sdf_kind=sk, msdf_kind=mk, weights_kind=wk, seed=seed, cubes=cubes.numpy())
             if len(out) == 3:           # empty surface early return (reference :193-202)
                 rec.update(empty=True, vertices_open=out[0].numpy(), faces_open=out[1].numpy(), L_dev=out[2].numpy())
@@ -74,8 +79,8 @@ def main():
                            w_v=wv.numpy(), w_m=wm.numpy(), w_l=wl.numpy(),
                            g_x=X.grad.numpy(), g_s=S.grad.numpy(), g_nu=NU.grad.numpy() if NU.grad is not None else np.zeros_like(nu),
                            g_w=Wt.grad.numpy() if Wt.grad is not None else np.zeros_like(w))
-                print(name, "V", v.shape[0], "T", f.shape[0], "Vwt", ex['n_verts_watertight'], "Twt", ex['faces_watertight'].shape[0], "L", L.shape[0])
-            np.savez_compressed(os.path.join(OUT, f"flexi_{name}.npz"), **rec)
+                print("training" if training else "", name, "V", v.shape[0], "T", f.shape[0], "Vwt", ex['n_verts_watertight'], "Twt", ex['faces_watertight'].shape[0], "L", L.shape[0])
+            np.savez_compressed(os.path.join(OUT, f"{'flexitrain' if training else 'flexi'}_{name}.npz"), **rec)
 
 
 if __name__ == "__main__":

@@ -14,21 +14,26 @@ DEV = "cuda"
 FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "flexi_*.npz")))
 
 
-def _run(x, s, nu, w, res):
+TRAIN_FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "flexitrain_*.npz")))
+
+
+def _run(x, s, nu, w, res, training=False):
     from gshell_amd.geometry.gshell_flexicubes import GShellFlexiCubes
     fc = GShellFlexiCubes()
     verts, cubes = fc.construct_voxel_grid(res)
     X, S, NU, Wt = (torch.tensor(a, device=DEV, requires_grad=True) for a in (x, s[:, None], nu, w))
-    out = fc(X, S, NU, cubes, res, Wt[:, :12], Wt[:, 12:20], Wt[:, 20])
+    out = fc(X, S, NU, cubes, res, Wt[:, :12], Wt[:, 12:20], Wt[:, 20], training=training)
     return fc, verts, cubes, (X, S, NU, Wt), out
 
 
-@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[6:-4] for f in FILES])
+@pytest.mark.parametrize("path", FILES + TRAIN_FILES, ids=[os.path.basename(f)[:-4] for f in FILES + TRAIN_FILES])
 def test_flexi_matches_reference_goldens(path):
+    """flexi_*: training=False; flexitrain_*: training=True (gshell_flexicubes.py:523-551: centre-vertex fans; the gamma weights then carry gradient)"""
     g = np.load(path)
+    assert len(TRAIN_FILES) >= 4
     res = int(g["res"])
     x, s, nu, w = make_inputs(res, str(g["sdf_kind"]), str(g["msdf_kind"]), str(g["weights_kind"]), int(g["seed"]))
-    fc, verts, cubes, (X, S, NU, Wt), out = _run(x, s, nu, w, res)
+    fc, verts, cubes, (X, S, NU, Wt), out = _run(x, s, nu, w, res, training=os.path.basename(path).startswith("flexitrain_"))
     np.testing.assert_array_equal(cubes.cpu().numpy(), g["cubes"])           # same grid layout as construct_voxel_grid
     if bool(g["empty"]):
         assert len(out) == 3 and out[0].shape == (0, 3) and out[1].shape == (0, 3) and out[1].dtype == torch.int64 and out[2].shape == (0,)

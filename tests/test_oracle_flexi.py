@@ -21,12 +21,17 @@ def run_case(g, extract):
     return x, s, nu, w, cubes, res
 
 
-@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[6:-4] for f in FILES])
+TRAIN_FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "flexitrain_*.npz")))
+
+
+@pytest.mark.parametrize("path", FILES + TRAIN_FILES, ids=[os.path.basename(f)[:-4] for f in FILES + TRAIN_FILES])
 def test_flexi_oracle_matches_reference(path):
+    """flexi_*: training=False; flexitrain_*: training=True (gshell_flexicubes.py:523-551, centre-vertex fans), both minted from the real reference"""
     g = np.load(path)
+    assert len(TRAIN_FILES) >= 4
     x, s, nu, w, cubes, res = run_case(g, fo.extract)
     X, S, NU, Wt = (torch.tensor(a, requires_grad=True) for a in (x, s[:, None], nu, w))
-    out = fo.extract(X, S, NU, cubes, res, Wt[:, :12], Wt[:, 12:20], Wt[:, 20])
+    out = fo.extract(X, S, NU, cubes, res, Wt[:, :12], Wt[:, 12:20], Wt[:, 20], training=os.path.basename(path).startswith("flexitrain_"))
     if bool(g["empty"]):
         assert len(out) == 3 and out[0].shape == (0, 3) and out[1].shape == (0, 3) and out[2].shape == (0,)
         return
